@@ -1,0 +1,228 @@
+/* snnqp.h -- C ABI of libsnnqp.so: the MI355X (gfx950) implementation of the
+ * quantized / pruned SNN time-stepped forward pass of
+ * Intelligent-Microsystems-Lab/SNNQuantPrune.
+ *
+ * The reference has no FFI: its hot path is Python on JAX (XLA emits the device
+ * code).  Each entry point below therefore replaces a *Python call site* of the
+ * reference; the `replaces:` lines give that call site (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add at each of them.
+ *
+ * Conventions
+ *  - every pointer named x/w/y/u/s/... is a DEVICE pointer owned by the caller
+ *    (torch); the library allocates nothing that outlives a call;
+ *  - descriptor structs (snnqp_*_t) are HOST structs read during the call;
+ *  - all work is enqueued on `stream` (a hipStream_t); no call synchronises;
+ *  - return value: 0 on success, <0 on error (SNNQP_E*); the message is
+ *    available from snnqp_last_error() on the calling thread;
+ *  - activations are time-major [T][B]...[C], channels innermost (NHWC), as
+ *    inside the reference model (examples/tcja/models.py:109); `x_stride_t` /
+ *    `x_stride_b` let a [B][T]... tensor be consumed in place;
+ *  - SNNQP_BITS tensors pack channel c of a row into bit (c & 31) of 32-bit
+ *    word (c >> 5); a row has ceil(C / 32) words.
+ */
+#ifndef SNNQP_H_
+#define SNNQP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *snnqp_stream_t; /* hipStream_t */
+
+enum {
+  SNNQP_OK = 0,
+  SNNQP_EINVAL = -1,       /* bad argument / shape */
+  SNNQP_EUNSUPPORTED = -2, /* valid request the chosen kernel cannot serve */
+  SNNQP_EHIP = -3          /* HIP runtime error */
+};
+
+/* element type of an activation tensor */
+enum { SNNQP_F32 = 0, SNNQP_U8 = 1, SNNQP_BITS = 2 };
+/* element type of a weight tensor */
+enum { SNNQP_W_F32 = 0, SNNQP_W_I8 = 1 };
+/* neuron models, spiking_learning.py:357-438 */
+enum {
+  SNNQP_NEURON_NONE = 0,
+  SNNQP_NEURON_MULTI_STEP_LIF = 1,      /* spiking_learning.py:390-416 */
+  SNNQP_NEURON_PARAMETRIC_LEAKY_IF = 2, /* spiking_learning.py:357-387 */
+  SNNQP_NEURON_LIF = 3                  /* spiking_learning.py:419-438 */
+};
+/* quantisers, quant.py */
+enum {
+  SNNQP_Q_DUQ = 0,              /* quant.py:428-469  p0 = a, p1 = c           */
+  SNNQP_Q_UNIFORM_STATIC = 1,   /* quant.py:322-358  p0 = xmax                */
+  SNNQP_Q_PARAMETRIC_D = 2,     /* quant.py:361-425  p0 = step size           */
+  SNNQP_Q_PARAMETRIC_D_XMAX = 3 /* quant.py:494-625  p0 = d, p1 = xmax (clipped) */
+};
+/* kernel selection for the fused blocks */
+enum { SNNQP_IMPL_AUTO = 0, SNNQP_IMPL_GENERIC = 1, SNNQP_IMPL_MFMA = 2 };
+
+/* flags written (OR-ed) by the checking kernels into a device int32 */
+enum {
+  SNNQP_FLAG_CODE_OVERFLOW = 1, /* |code| > 127: does not fit int8          */
+  SNNQP_FLAG_MASK_NOT_BINARY = 2,
+  SNNQP_FLAG_NOT_INTEGER = 4,   /* activation not an integer in [0, 255]    */
+  SNNQP_FLAG_GT_ONE = 8,        /* activation > 1 (not a binary spike)      */
+  SNNQP_FLAG_GT_127 = 16        /* activation > 127 (not an int8 MFMA operand) */
+};
+
+/* Weights after the transforms of flax_qdense.py:74-85 / flax_qconv.py:147-156.
+ * SNNQP_W_I8: integer codes (already multiplied by the 0/1 prune mask); the
+ * contraction accumulates exactly in int32 and the current is
+ * fl(fl(acc / L) * m)  (DuQ: L = n_lv - 1, m = c, quant.py:443,467; the other
+ * quantisers: L = 1, m = step).  SNNQP_W_F32: fake-quantised float kernel; the
+ * contraction is a float32 fmaf chain over k ascending ((kh, kw, cin) order).
+ * Layout: [K][N] for dense, HWIO for convolutions, as the reference's params. */
+typedef struct {
+  int32_t wtype;
+  const void *w;
+  float L;
+  float m;
+} snnqp_weight_t;
+
+/* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),
+ * mul = rsqrt(var + eps) * scale (examples/tcja/models.py:101-107, applied at
+ * spiking_learning.py:457-458).  All three device arrays have Cout entries. */
+typedef struct {
+  const float *mean;
+  const float *mul;
+  const float *bias;
+} snnqp_bn_t;
+
+/* Neuron parameters.  `k`: tau for MULTI_STEP_LIF, sigmoid(tau_param) for
+ * PARAMETRIC_LEAKY_IF; `decay`: device [Cout] sigmoid(tau) for LIF. */
+typedef struct {
+  int32_t kind;
+  float k;
+  float v_threshold;
+  float v_reset;
+  const float *decay;
+} snnqp_neuron_t;
+
+/* Convolution geometry (flax_qconv.py:76-94, :158-168); 1-D convolutions use
+ * H = KH = 1.  A dense layer is the 1x1 convolution on a 1x1 image. */
+typedef struct {
+  int32_t H, W, Cin, Cout;
+  int32_t KH, KW;
+  int32_t stride_h, stride_w;
+  int32_t pad_h_lo, pad_h_hi, pad_w_lo, pad_w_hi;
+  int32_t in_dil_h, in_dil_w;   /* input_dilation  (lhs) */
+  int32_t k_dil_h, k_dil_w;     /* kernel_dilation (rhs) */
+  int32_t groups;               /* feature_group_count   */
+} snnqp_conv_geom_t;
+
+int snnqp_version(void);
+const char *snnqp_last_error(void);
+
+/* Output spatial size of `g` (same rule as lax.conv_general_dilated). */
+int snnqp_conv_out_shape(const snnqp_conv_geom_t *g, int32_t *OH, int32_t *OW);
+
+/* ---- weight transforms --------------------------------------------------
+ * replaces: cfg.weight(bits, g_scale)(kernel) + prune()(kernel_fwd) at
+ *           flax_qdense.py:74-85 and flax_qconv.py:147-156
+ *           (quantiser forwards quant.py:322-625, prune quant.py:472-491).
+ * w, mask (nullable), fq_out (nullable, float32 fake-quantised*mask),
+ * codes_out (nullable, int8 codes*mask), flags (nullable int32, OR-ed).
+ * Rounding is round-half-to-even (jnp.round, quant.py:88-90). */
+int snnqp_quantize(int kind, const float *w, const float *mask, int64_t n,
+                   int bits, float p0, float p1, float *fq_out,
+                   int8_t *codes_out, int32_t *flags, snnqp_stream_t stream);
+
+/* Layout step of the pack: int8 codes [K][N] (dense kernel / flattened HWIO
+ * convolution kernel, as the reference stores them) -> [Npad][K], zero rows for
+ * n >= N: the k-contiguous order the MFMA B operand is loaded in. */
+int snnqp_transpose_codes(const int8_t *w, int64_t K, int32_t N, int32_t Npad,
+                          int8_t *wt, snnqp_stream_t stream);
+
+/* ---- activation format helpers ------------------------------------------
+ * replaces: nothing in the reference (its activations are float32 arrays);
+ * they convert between the reference's float32 layout and the packed formats
+ * the kernels read/write.  rows x C logical elements. */
+int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
+                      snnqp_stream_t stream);
+int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
+                    snnqp_stream_t stream);
+int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
+                    uint32_t *bits, snnqp_stream_t stream);
+int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
+                      snnqp_stream_t stream);
+
+/* ---- connection only (no neuron) ------------------------------------------
+ * replaces: lax.dot_general at flax_qdense.py:87-89 and
+ *           lax.conv_general_dilated at flax_qconv.py:158-168.
+ * x: NB images [NB][H][W][Cin] (type in_type); y: float32 [NB][OH][OW][Cout];
+ * acc (nullable): int32 accumulators, same shape (W_I8 with integer input). */
+int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
+                       const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                       float *y, int32_t *acc, snnqp_stream_t stream);
+
+/* ---- fused SpikingBlock ---------------------------------------------------
+ * replaces: SpikingBlock.__call__ (nn.scan over T of connection -> norm ->
+ *           neuron), spiking_learning.py:446-462, with QuantConv / QuantDense
+ *           as connection_fn, nn.BatchNorm (eval) as norm_fn, and -- when
+ *           pool == 2 -- the 2x2 max-pool that follows it in
+ *           examples/tcja/models.py:145-147.
+ * x     [T][B][H][W][Cin] with element strides x_stride_t / x_stride_b
+ *       (words for SNNQP_BITS); rows [H][W][Cin] are contiguous.
+ * bn    nullable.  u0 nullable (zeros, initialize_carry :464-472),
+ *       float32 [B][OH][OW][Cout].  u_out nullable, same shape.
+ * s_out spikes, type s_type (SNNQP_F32: 0.0/1.0, or SNNQP_BITS),
+ *       [T][B][OH/pool][OW/pool][Cout].
+ * impl  SNNQP_IMPL_GENERIC: direct form, any geometry / types.
+ *       SNNQP_IMPL_MFMA: int8 MFMA implicit GEMM; needs W_I8, 3x3 / stride 1 /
+ *       pad 1 / no dilation / groups 1, H % 8 == W % 8 == 0, Cout % 32 == 0 and
+ *       (BITS input with Cin == 128 and `wt` = the codes transposed to
+ *       [Cout][9 * Cin] by snnqp_transpose_codes, or U8 input with Cin == 2 and
+ *       values <= 127), s_type BITS.  SNNQP_IMPL_AUTO picks MFMA when it can. */
+int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
+                           int64_t x_stride_b, int32_t T, int32_t B,
+                           const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                           const int8_t *wt, const snnqp_bn_t *bn,
+                           const snnqp_neuron_t *nrn, const float *u0,
+                           float *u_out, void *s_out, int s_type, int pool,
+                           int impl, snnqp_stream_t stream);
+
+/* Same for QuantDense: x [T][B][K], weights [K][N] (GENERIC) .
+ * IMPL_MFMA additionally needs `wt`: the int8 codes transposed to [Npad][K]
+ * (Npad = N rounded up to 32, zero rows), BITS input, K % 64 == 0, s_type BITS. */
+int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
+                            int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
+                            int32_t N, const snnqp_weight_t *w,
+                            const int8_t *wt, const snnqp_bn_t *bn,
+                            const snnqp_neuron_t *nrn, const float *u0,
+                            float *u_out, void *s_out, int s_type, int impl,
+                            snnqp_stream_t stream);
+
+/* ---- element-wise pieces ----------------------------------------------------
+ * replaces: neural_dynamics(u, x) scanned over T, spiking_learning.py:460
+ *           (multi_step_LIF :403-416, parametric_leaky_IF :370-387, LIF :426-438)
+ *           with the optional norm_fn of :457-458 in front.
+ * x float32 [T][R][C] currents; u0/u_out [R][C]; s_out [T][R][C] (F32/BITS). */
+int snnqp_lif_forward(const float *x, int32_t T, int64_t R, int32_t C,
+                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
+                      const float *u0, float *u_out, void *s_out, int s_type,
+                      snnqp_stream_t stream);
+
+/* replaces: nn.BatchNorm(use_running_average=True), examples/tcja/models.py:101-107 */
+int snnqp_batchnorm_forward(const float *x, int64_t rows, int32_t C,
+                            const snnqp_bn_t *bn, float *y,
+                            snnqp_stream_t stream);
+
+/* replaces: lax.reduce_window(max, (1,1,2,2,1)), examples/tcja/models.py:145-147
+ * x [NB][H][W][C] (F32 or BITS) -> y [NB][H/2][W/2][C]. */
+int snnqp_maxpool2x2(const void *x, int type, int64_t NB, int32_t H, int32_t W,
+                     int32_t C, void *y, snnqp_stream_t stream);
+
+/* replaces: the rate "vote", examples/tcja/models.py:253-255
+ * s [T][B][N] (F32 or BITS) -> logits float32 [B][N / group]:
+ * mean over T (sequential float32 sum / T), then mean over `group` neurons. */
+int snnqp_vote(const void *s, int type, int32_t T, int32_t B, int32_t N,
+               int32_t group, float *logits, snnqp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNNQP_H_ */

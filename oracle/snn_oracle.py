@@ -1,0 +1,739 @@
+"""CPU oracle for the quantized / pruned SNN time-stepped forward pass.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``snnquantprune_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker / the reported CPU baseline.
+
+It restates, op for op and in float32, the arithmetic of the reference
+(paths relative to the reference checkout):
+
+  quant.py:88-90      round_* forward  = jnp.round (round half to even)
+  quant.py:296-314    max_init / gaussian_init / percentile_init
+  quant.py:322-358    uniform_static
+  quant.py:361-425    parametric_d
+  quant.py:428-469    DuQ
+  quant.py:472-491    prune
+  quant.py:494-625    parametric_d_xmax
+  flax_qdense.py:58-106   QuantDense.__call__
+  flax_qconv.py:93-188    QuantConv.__call__ (padding resolution :131-144)
+  spiking_learning.py:139-241  spike functions (forward = Heaviside x >= 0)
+  spiking_learning.py:357-438  parametric_leaky_IF / multi_step_LIF / LIF
+  spiking_learning.py:441-472  SpikingBlock (scan over T) / initialize_carry
+  examples/tcja/models.py:101-147,189-190,200-255  BN, 2x2 max-pool, flatten, vote
+  examples/train_utils.py:210-225,370-390          mse_loss, compute_metrics, eval_step
+  examples/train_inpt_spikingjelly.py:147-223      local / global magnitude masks
+
+Pinning status.  The reference is Python on jax==0.2.27 /
+flax==0.4.0 (README.md:15-32), neither of which is installed here, so it cannot
+be imported or run and no golden outputs of the reference exist.  The oracle is
+pinned by the invariants the reference's own tests assert:
+  (1) no-quant QuantDense == x @ W            (flax_qdense_test.py:153-250)
+  (2) no-quant QuantConv == NHWC/HWIO conv over the nine geometries of
+      flax_qconv_test.py:148-285 (output sizes listed there)
+  (3) integer data within the code range round-trips every quantiser
+      (quant_test.py:141-185)
+  (4) a signed b-bit quantiser emits 2**b - 1 distinct values (quant_test.py:187-250)
+and by source-derived known answers (LIF constant-drive sequences, DuQ code
+ranges, round-half-even ties).  For multi_step_LIF / SpikingBlock / DuQ / prune /
+BatchNorm-in-scan / pooling / vote and every end-to-end number the reference's
+tests hold no expected outputs: **parity unpinned** beyond those known answers.
+
+Three arithmetic modes for the weight x input contraction:
+
+  'int'    integer codes x integer inputs accumulated exactly, then
+           y = fl(fl(acc / L) * m) with L = n_lv - 1, m = c (DuQ) or L = 1,
+           m = step (the other quantisers).  This is the bit-exact contract
+           for spike rasters and integer accumulators.
+  'fseq'   float32 inputs x float32 (fake-quantised) weights as a k-ascending
+           fmaf chain (k = flattened (kh, kw, cin) for convolutions).  Bit-exact
+           contract for unquantised / real-valued layers.
+  'float'  reference-literal: dense float32 fake-quantised weights, float32
+           matmul / conv in BLAS order (what XLA-CPU executes, summation order
+           unspecified).  Used to report the flip rate of 'int'/'fseq' against
+           float summation order and as the timed CPU baseline.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Callable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+F32 = np.float32
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------
+# C helper (exact fmaf chains).  Built by oracle/Makefile or on first use.
+# ---------------------------------------------------------------------------
+
+_clib = None
+
+
+def build_c(force: bool = False) -> str:
+  so = os.path.join(_HERE, "liboracle_c.so")
+  src = os.path.join(_HERE, "oracle_c.c")
+  if force or not os.path.exists(so) or (
+      os.path.getmtime(so) < os.path.getmtime(src)):
+    subprocess.check_call(
+        ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared",
+         "-fPIC", "-fopenmp", "-o", so, src, "-lm"])
+  return so
+
+
+def clib():
+  global _clib
+  if _clib is None:
+    lib = ctypes.CDLL(build_c())
+    i64, fp = ctypes.c_int64, ctypes.POINTER(ctypes.c_float)
+    lib.oracle_fseq_matmul.argtypes = [fp, fp, fp, i64, i64, i64]
+    lib.oracle_fseq_matmul.restype = None
+    lib.oracle_check_div.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.oracle_check_div.restype = i64
+    _clib = lib
+  return _clib
+
+
+def _fp(a):
+  return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def fseq_matmul(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+  """y[m, n] = fmaf chain over k ascending of x[m, k] * w[k, n], start +0."""
+  x = np.ascontiguousarray(x, dtype=F32)
+  w = np.ascontiguousarray(w, dtype=F32)
+  m, k = x.shape
+  k2, n = w.shape
+  assert k == k2
+  y = np.empty((m, n), dtype=F32)
+  clib().oracle_fseq_matmul(_fp(x), _fp(w), _fp(y), m, k, n)
+  return y
+
+
+# ---------------------------------------------------------------------------
+# Rounding / calibration / quantisers   (quant.py)
+# ---------------------------------------------------------------------------
+
+
+def round_half_even(x):
+  """Forward of every round_* in quant.py:26-288 (jnp.round)."""
+  return np.rint(np.asarray(x, dtype=F32)).astype(F32)
+
+
+def max_init(x, bits, sign=True):
+  """quant.py:296-298."""
+  x = np.asarray(x, dtype=F32)
+  if np.max(x) == 0:
+    return F32(1 / 2 ** bits)
+  return F32(np.max(np.abs(x)))
+
+
+def gaussian_init(x, bits, sign=True):
+  """quant.py:305-309: max(|mu - 3 sigma|, |mu + 3 sigma|)."""
+  x = np.asarray(x, dtype=F32)
+  if np.max(x) == 0:
+    return F32(1 / 2 ** bits)
+  mu = np.mean(x, dtype=F32)
+  sigma = np.std(x, dtype=F32)
+  return F32(np.maximum(np.abs(mu - F32(3) * sigma), np.abs(mu + F32(3) * sigma)))
+
+
+def percentile_init(x, bits, sign, perc):
+  """quant.py:312-314."""
+  x = np.asarray(x, dtype=F32)
+  if np.max(x) == 0:
+    return F32(1 / 2 ** bits)
+  return F32(np.percentile(np.abs(x), perc))
+
+
+def hard_tanh(x):
+  return np.clip(x, F32(-1), F32(1))
+
+
+def duq_levels(bits: int, sign: bool = True) -> int:
+  """n_lv of quant.py:458-461."""
+  return 2 ** (bits - 1) if sign else 2 ** bits
+
+
+def duq_codes(w, a, bits, sign=True):
+  """Integer code q = round(hard_tanh(W / a) * (n_lv - 1)), quant.py:443,466-467.
+
+  Returned as integer-valued float32, range [-(n_lv-1), n_lv-1]."""
+  w = np.asarray(w, dtype=F32)
+  L = F32(duq_levels(bits, sign) - 1)
+  x = hard_tanh(w / F32(a))
+  return round_half_even(x * L)
+
+
+def duq_dequant(q, c, bits, sign=True):
+  """w = fl(fl(q / (n_lv-1)) * c), quant.py:443,467."""
+  L = F32(duq_levels(bits, sign) - 1)
+  return (np.asarray(q, dtype=F32) / L) * F32(c)
+
+
+def duq_forward(w, a, c, bits, sign=True):
+  """DuQ.__call__, quant.py:428-469."""
+  w = np.asarray(w, dtype=F32)
+  if bits == -1:                     # quant.py:453-454
+    return w
+  if F32(a) == F32(-1):              # quant.py:469
+    return w
+  return duq_dequant(duq_codes(w, a, bits, sign), c, bits, sign).astype(F32)
+
+
+def uniform_static_forward(x, xmax, bits, sign=True):
+  """uniform_static.__call__, quant.py:331-358 (xmax = dynamic_range_no_train)."""
+  assert bits > 1
+  x = np.asarray(x, dtype=F32)
+  xmax = F32(xmax)
+  num_levels = F32(2 ** (bits - 1) - 1 if sign else 2 ** bits - 1)
+  x = x / xmax
+  x = np.clip(x, F32(-1) if sign else F32(0), F32(1)) * xmax
+  scale = xmax / num_levels
+  return (round_half_even(x / scale) * scale).astype(F32)
+
+
+def uniform_static_init(x, bits, sign=True, init_fn=max_init):
+  """quant.py:345-347."""
+  v = init_fn(x, bits=bits, sign=sign)
+  return F32(1.0) if v == 0 else F32(v)
+
+
+def parametric_d_forward(x, step, bits, sign=True):
+  """parametric_d.__call__, quant.py:374-425 (forward; gradscale is identity)."""
+  x = np.asarray(x, dtype=F32)
+  s = F32(step)
+  q_pos = F32(2 ** (bits - 1) - 1 if sign else 2 ** bits - 1)
+  q_neg = -q_pos if sign else F32(0)
+  v = np.clip(x / s, q_neg, q_pos)
+  return (round_half_even(v) * s).astype(F32)
+
+
+def parametric_d_init(x, bits, sign=True, init_fn=max_init):
+  """quant.py:395-399: step = init_fn(x) / sqrt(q_pos)."""
+  q_pos = 2 ** (bits - 1) - 1 if sign else 2 ** bits - 1
+  return F32(F32(init_fn(x, bits=bits, sign=sign)) / np.sqrt(F32(q_pos)))
+
+
+def parametric_d_xmax_forward(x, d, xmax, sign=True, d_min=2 ** -12, d_max=1.0,
+                              xmax_min=2 ** -8, xmax_max=127.0):
+  """parametric_d_xmax.__call__ forward, quant.py:512-625."""
+  x = np.asarray(x, dtype=F32)
+  d = np.clip(F32(d), F32(d_min), F32(d_max))            # :579
+  xmax = np.clip(F32(xmax), F32(xmax_min), F32(xmax_max))  # :582
+  x = x / xmax
+  x = np.clip(x, F32(-1) if sign else F32(0), F32(1)) * xmax
+  return (d * round_half_even(x / d)).astype(F32)
+
+
+def parametric_d_xmax_init(x, bits, sign=True, init_fn=None, act=False,
+                           maxabs_w=None):
+  """(d, xmax) of quant.py:553-573."""
+  x = np.asarray(x, dtype=F32)
+  num_levels = 2 ** (bits - 1) - 1 if sign else 2 ** bits - 1
+  if init_fn is None:
+    if act:
+      return F32(2 ** -3), F32(2 ** -3 * (2. ** bits - 1))
+    mw = F32(maxabs_w) if maxabs_w is not None else F32(np.max(np.abs(x)))
+    lg = np.log2(mw / F32(2 ** (bits - 1) - 1))
+    d = F32(2 ** (np.ceil(lg) if bits > 4 else np.floor(lg)))
+    return d, F32(d * F32(2 ** (bits - 1) - 1))
+  xmax = F32(init_fn(x, bits=bits, sign=sign))
+  xmax = F32(1.0) if xmax == 0 else xmax
+  return F32(xmax / F32(num_levels)), xmax
+
+
+def prune_forward(w, mask):
+  """prune.__call__, quant.py:489-491: W * mask."""
+  return (np.asarray(w, dtype=F32) * np.asarray(mask, dtype=F32)).astype(F32)
+
+
+def local_prune_mask(kernel, p):
+  """update_prune_mask, examples/train_inpt_spikingjelly.py:147-157."""
+  kernel = np.asarray(kernel)
+  mask = np.ones(kernel.shape)
+  k = int(np.prod(kernel.shape) * p)
+  idx = np.argpartition(np.abs(kernel).reshape(-1), k)[:k]
+  mask.reshape(-1)[idx] = 0
+  return mask.astype(F32)
+
+
+def global_prune_masks(kernels: Sequence[np.ndarray], p):
+  """Global magnitude mask, examples/train_inpt_spikingjelly.py:174-223."""
+  flat = np.concatenate([np.reshape(np.asarray(k), (-1)) for k in kernels])
+  gm = np.ones(flat.shape)
+  k = int(np.prod(flat.shape) * p)
+  idx = np.argpartition(np.abs(flat), k)[:k]
+  gm[idx] = 0
+  out, off = [], 0
+  for kern in kernels:
+    n = int(np.prod(kern.shape))
+    out.append(gm[off:off + n].reshape(kern.shape).astype(F32))
+    off += n
+  return out
+
+
+# ---------------------------------------------------------------------------
+# Layer weights: one description consumed by every contraction mode.
+# ---------------------------------------------------------------------------
+
+
+class QWeight:
+  """A layer kernel after the weight transforms of flax_qdense.py:74-85.
+
+  kernel   float32 raw kernel ([K, N] dense, HWIO conv)
+  q        integer codes (integer-valued float32) after the mask, or None
+  L, m     dequantisation y = fl(fl(acc / L) * m); None for unquantised
+  w_fq     float32 fake-quantised + pruned kernel (the reference's kernel_fwd)
+  """
+
+  def __init__(self, kernel, quant: Optional[dict] = None, mask=None):
+    kernel = np.asarray(kernel, dtype=F32)
+    self.kernel = kernel
+    self.q = None
+    self.L = None
+    self.m = None
+    quant = quant or {}
+    kind = quant.get("kind")
+    bits = quant.get("bits", 8)
+    if kind is None or bits == -1:
+      w = kernel
+    elif kind == "duq":
+      a, c = F32(quant["a"]), F32(quant["c"])
+      if a == F32(-1):
+        w = kernel
+      else:
+        self.q = duq_codes(kernel, a, bits)
+        self.L = F32(duq_levels(bits) - 1)
+        self.m = c
+        w = duq_dequant(self.q, c, bits)
+    elif kind == "uniform_static":
+      xmax = F32(quant["xmax"])
+      L = F32(2 ** (bits - 1) - 1)
+      scale = xmax / L
+      xc = np.clip(kernel / xmax, F32(-1), F32(1)) * xmax
+      self.q = round_half_even(xc / scale)
+      self.L, self.m = F32(1), scale
+      w = self.q * scale
+    elif kind == "parametric_d":
+      s = F32(quant["step"])
+      qp = F32(2 ** (bits - 1) - 1)
+      self.q = round_half_even(np.clip(kernel / s, -qp, qp))
+      self.L, self.m = F32(1), s
+      w = self.q * s
+    elif kind == "parametric_d_xmax":
+      d = np.clip(F32(quant["d"]), F32(quant.get("d_min", 2 ** -12)),
+                  F32(quant.get("d_max", 1.0)))
+      xmax = np.clip(F32(quant["xmax"]), F32(quant.get("xmax_min", 2 ** -8)),
+                     F32(quant.get("xmax_max", 127.0)))
+      xc = np.clip(kernel / xmax, F32(-1), F32(1)) * xmax
+      self.q = round_half_even(xc / d)
+      self.L, self.m = F32(1), F32(d)
+      w = F32(d) * self.q
+    else:
+      raise ValueError(kind)
+    w = np.asarray(w, dtype=F32)
+    if mask is not None:
+      mask = np.asarray(mask, dtype=F32)
+      w = w * mask                       # quant.py:491, after quantisation
+      if self.q is not None:
+        assert np.all((mask == 0) | (mask == 1)), "int mode needs a 0/1 mask"
+        self.q = self.q * mask
+    self.w_fq = w.astype(F32)
+
+  @property
+  def quantised(self):
+    return self.q is not None
+
+  def dequant_acc(self, acc):
+    """y = fl(fl(acc / L) * m) on an exact integer accumulator."""
+    a = np.asarray(acc).astype(F32)       # round-to-nearest-even like v_cvt_f32_i32
+    return ((a / self.L) * self.m).astype(F32)
+
+
+# ---------------------------------------------------------------------------
+# Contractions
+# ---------------------------------------------------------------------------
+
+
+def _exact_int_matmul(x, q):
+  """Exact integer matmul using BLAS on floats (guards exactness)."""
+  x = np.asarray(x)
+  q = np.asarray(q)
+  bound = float(np.max(np.abs(x), initial=0)) * float(
+      np.max(np.abs(q), initial=0)) * x.shape[-1]
+  if bound < 2 ** 24:
+    acc = np.asarray(x, dtype=F32) @ np.asarray(q, dtype=F32)
+  else:
+    assert bound < 2 ** 53
+    acc = np.asarray(x, dtype=np.float64) @ np.asarray(q, dtype=np.float64)
+  return np.rint(acc).astype(np.int64)
+
+
+def _is_integer_valued(x):
+  x = np.asarray(x)
+  return np.issubdtype(x.dtype, np.integer) or x.dtype == np.bool_ or bool(
+      np.all(x == np.rint(x)))
+
+
+def dense_acc(x, qw: QWeight):
+  """Integer accumulator of QuantDense in 'int' mode ([..., N] int64)."""
+  x = np.asarray(x)
+  lead = x.shape[:-1]
+  acc = _exact_int_matmul(x.reshape(-1, x.shape[-1]), qw.q)
+  return acc.reshape(lead + (qw.q.shape[-1],))
+
+
+def quant_dense(x, qw: QWeight, mode: str = "int"):
+  """QuantDense.__call__ without bias, flax_qdense.py:58-89."""
+  x = np.asarray(x)
+  lead = x.shape[:-1]
+  x2 = x.reshape(-1, x.shape[-1])
+  if mode == "int":
+    assert qw.quantised and _is_integer_valued(x2)
+    y = qw.dequant_acc(_exact_int_matmul(x2, qw.q))
+  elif mode == "fseq":
+    y = fseq_matmul(x2.astype(F32), qw.w_fq)
+  elif mode == "float":
+    y = x2.astype(F32) @ qw.w_fq
+  else:
+    raise ValueError(mode)
+  return y.reshape(lead + (qw.w_fq.shape[-1],)).astype(F32)
+
+
+def resolve_padding(in_spatial, k_spatial, strides, padding, rhs_dilation=None):
+  """String padding -> explicit pads, flax_qconv.py:131-144 (padtype_to_pads).
+
+  SAME: out = ceil(in / stride); total = max((out-1)*stride + k_eff - in, 0);
+  lo = total // 2, hi = total - lo.  VALID: zeros."""
+  n = len(in_spatial)
+  rhs_dilation = rhs_dilation or (1,) * n
+  if isinstance(padding, str):
+    pads = []
+    for i in range(n):
+      k_eff = (k_spatial[i] - 1) * rhs_dilation[i] + 1
+      if padding.upper() == "SAME":
+        out = -(-in_spatial[i] // strides[i])
+        total = max((out - 1) * strides[i] + k_eff - in_spatial[i], 0)
+        pads.append((total // 2, total - total // 2))
+      elif padding.upper() == "VALID":
+        pads.append((0, 0))
+      else:
+        raise ValueError(padding)
+    return tuple(pads)
+  return tuple((int(lo), int(hi)) for lo, hi in padding)
+
+
+def conv_out_spatial(in_spatial, k_spatial, strides, pads, lhs_dilation=None,
+                     rhs_dilation=None):
+  n = len(in_spatial)
+  lhs_dilation = lhs_dilation or (1,) * n
+  rhs_dilation = rhs_dilation or (1,) * n
+  out = []
+  for i in range(n):
+    in_d = (in_spatial[i] - 1) * lhs_dilation[i] + 1 if in_spatial[i] > 0 else 0
+    k_eff = (k_spatial[i] - 1) * rhs_dilation[i] + 1
+    tot = in_d + pads[i][0] + pads[i][1]
+    out.append(0 if tot < k_eff else (tot - k_eff) // strides[i] + 1)
+  return tuple(out)
+
+
+def im2col(x, k_spatial, strides, pads, lhs_dilation=None, rhs_dilation=None):
+  """NHWC (or NWC) -> [B, *out_spatial, prod(k)*Cin] in (k..., cin) order."""
+  x = np.asarray(x)
+  n = x.ndim - 2
+  lhs_dilation = tuple(lhs_dilation or (1,) * n)
+  rhs_dilation = tuple(rhs_dilation or (1,) * n)
+  if n == 1:                      # treat 1-D as 2-D with H = 1
+    cols = im2col(x[:, None], (1,) + tuple(k_spatial), (1,) + tuple(strides),
+                  ((0, 0),) + tuple(pads), (1,) + lhs_dilation,
+                  (1,) + rhs_dilation)
+    return cols[:, 0]
+  assert n == 2, "oracle supports 1-D and 2-D convolutions"
+  B, H, W, C = x.shape
+  if lhs_dilation != (1, 1):
+    hd = (H - 1) * lhs_dilation[0] + 1
+    wd = (W - 1) * lhs_dilation[1] + 1
+    xd = np.zeros((B, hd, wd, C), dtype=x.dtype)
+    xd[:, ::lhs_dilation[0], ::lhs_dilation[1]] = x
+    x, H, W = xd, hd, wd
+  xp = np.pad(x, ((0, 0), pads[0], pads[1], (0, 0)))
+  OH, OW = conv_out_spatial((H, W), k_spatial, strides, pads, None, rhs_dilation)
+  KH, KW = k_spatial
+  cols = np.empty((B, OH, OW, KH, KW, C), dtype=x.dtype)
+  for kh in range(KH):
+    for kw in range(KW):
+      y0, x0 = kh * rhs_dilation[0], kw * rhs_dilation[1]
+      cols[:, :, :, kh, kw, :] = xp[
+          :, y0:y0 + (OH - 1) * strides[0] + 1:strides[0],
+          x0:x0 + (OW - 1) * strides[1] + 1:strides[1], :]
+  return cols.reshape(B, OH, OW, KH * KW * C)
+
+
+def quant_conv(x, qw: QWeight, strides=None, padding="SAME", input_dilation=None,
+               kernel_dilation=None, feature_group_count=1, mode="int",
+               return_acc=False):
+  """QuantConv.__call__ without bias, flax_qconv.py:93-171.
+
+  x NHWC ([B, H, W, Cin] or [B, W, Cin]); kernel HWIO in qw."""
+  x = np.asarray(x)
+  kshape = qw.kernel.shape
+  nsp = len(kshape) - 2
+  single = False
+  if x.ndim == nsp + 1:                              # flax_qconv.py:109-112
+    single, x = True, x[None]
+  k_spatial = tuple(kshape[:nsp])
+  strides = tuple(strides or (1,) * nsp)
+  cin_g, cout = kshape[-2], kshape[-1]
+  G = feature_group_count
+  assert x.shape[-1] % G == 0                        # flax_qconv.py:117
+  assert x.shape[-1] // G == cin_g and cout % G == 0
+  # flax_qconv.py:128-144 uses rhs_dilation = 1 to resolve string padding
+  pads = resolve_padding(x.shape[1:-1], k_spatial, strides, padding, None)
+  outs = []
+  for g in range(G):
+    xg = x[..., g * cin_g:(g + 1) * cin_g]
+    cols = im2col(xg, k_spatial, strides, pads, input_dilation, kernel_dilation)
+    lead = cols.shape[:-1]
+    c2 = cols.reshape(-1, cols.shape[-1])
+    og = cout // G
+    sl = slice(g * og, (g + 1) * og)
+    if mode == "int":
+      assert qw.quantised and _is_integer_valued(c2)
+      acc = _exact_int_matmul(c2, qw.q.reshape(-1, cout)[:, sl])
+      yg = acc if return_acc else qw.dequant_acc(acc)
+    elif mode == "fseq":
+      yg = fseq_matmul(c2.astype(F32), qw.w_fq.reshape(-1, cout)[:, sl])
+    elif mode == "float":
+      yg = c2.astype(F32) @ qw.w_fq.reshape(-1, cout)[:, sl]
+    else:
+      raise ValueError(mode)
+    outs.append(yg.reshape(lead + (og,)))
+  y = np.concatenate(outs, axis=-1) if G > 1 else outs[0]
+  if not (mode == "int" and return_acc):
+    y = y.astype(F32)
+  return y[0] if single else y
+
+
+# ---------------------------------------------------------------------------
+# Neurons, norm, SpikingBlock   (spiking_learning.py)
+# ---------------------------------------------------------------------------
+
+
+def heaviside(x):
+  """Forward of atan / fast_sigmoid / ... (spiking_learning.py:139-241): x >= 0."""
+  return (np.asarray(x, dtype=F32) >= F32(0)).astype(F32)
+
+
+def sigmoid_f32(x):
+  """Host-side sigmoid used for PLIF / LIF decay: float64 expit rounded once."""
+  return (1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))).astype(F32)
+
+
+def multi_step_lif(u, s_in, tau=2.0, v_threshold=1.0, v_reset=0.0):
+  """multi_step_LIF.__call__, spiking_learning.py:403-416."""
+  u = np.asarray(u, dtype=F32)
+  s_in = np.asarray(s_in, dtype=F32)
+  tau, vth, vr = F32(tau), F32(v_threshold), F32(v_reset)
+  u = u + (s_in - (u - vr)) / tau          # :410
+  s = heaviside(u - vth)                   # :412
+  u = np.where(s != 0, vr, u)              # :414
+  return u.astype(F32), s
+
+
+def parametric_leaky_if(u, s_in, tau_param, v_threshold=1.0, v_reset=0.0):
+  """parametric_leaky_IF.__call__, spiking_learning.py:370-387 (tau_param shape (1,))."""
+  u = np.asarray(u, dtype=F32)
+  s_in = np.asarray(s_in, dtype=F32)
+  k = sigmoid_f32(np.asarray(tau_param).reshape(-1)[0])
+  vth, vr = F32(v_threshold), F32(v_reset)
+  u = u + (s_in - (u - vr)) * k            # :381
+  s = heaviside(u - vth)
+  u = np.where(s != 0, vr, u)
+  return u.astype(F32), s
+
+
+def lif(u, s_in, tau_vec, v_threshold=1.0, v_reset=0.0):
+  """LIF.__call__, spiking_learning.py:426-438 (tau_vec shape (N,))."""
+  u = np.asarray(u, dtype=F32)
+  s_in = np.asarray(s_in, dtype=F32)
+  k = sigmoid_f32(tau_vec)
+  vth, vr = F32(v_threshold), F32(v_reset)
+  u = u * k + s_in                         # :432
+  s = heaviside(u - vth)
+  u = np.where(s > F32(0.5), vr, u)        # :436
+  return u.astype(F32), s
+
+
+def bn_coeffs(mean, var, scale=None, bias=None, eps=1e-5):
+  """Eval-mode flax 0.4.0 BatchNorm folded to (mean, mul, bias):
+  mul = fl(fl(1 / sqrt(var + eps)) * scale)  (models.py:101-107)."""
+  mean = np.asarray(mean, dtype=F32)
+  var = np.asarray(var, dtype=F32)
+  mul = F32(1) / np.sqrt(var + F32(eps))
+  if scale is not None:
+    mul = mul * np.asarray(scale, dtype=F32)
+  b = np.zeros_like(mean) if bias is None else np.asarray(bias, dtype=F32)
+  return mean, mul.astype(F32), b
+
+
+def batchnorm_eval(x, mean, var, scale=None, bias=None, eps=1e-5):
+  """y = fl(fl(fl(x - mean) * mul) + bias) over the last axis."""
+  mean, mul, b = bn_coeffs(mean, var, scale, bias, eps)
+  y = (np.asarray(x, dtype=F32) - mean) * mul
+  return (y + b).astype(F32)
+
+
+def spiking_block(u0, inputs, connection_fn: Callable, neuron_fn: Callable,
+                  norm_fn: Optional[Callable] = None):
+  """SpikingBlock.__call__, spiking_learning.py:446-462: scan over axis 0."""
+  u = None if u0 is None else np.asarray(u0, dtype=F32)
+  out = []
+  for t in range(inputs.shape[0]):
+    x = connection_fn(inputs[t])
+    if norm_fn is not None:
+      x = norm_fn(x)
+    if u is None:                         # initialize_carry, :464-472
+      u = np.zeros_like(x, dtype=F32)
+    u, s = neuron_fn(u, x)
+    out.append(s)
+  return u, np.stack(out, axis=0)
+
+
+def max_pool_2x2(x):
+  """reduce_window max (1,1,2,2,1), models.py:145-147, on [T, B, H, W, C]."""
+  T, B, H, W, C = x.shape
+  x = x[:, :, :H // 2 * 2, :W // 2 * 2]
+  return x.reshape(T, B, H // 2, 2, W // 2, 2, C).max(axis=(3, 5))
+
+
+def flatten_channel_major(x):
+  """models.py:189-190: transpose (T,B,C,H,W) then reshape [T, B, C*H*W]."""
+  x = np.transpose(x, (0, 1, 4, 2, 3))
+  return x.reshape(x.shape[:2] + (-1,))
+
+
+def vote(spikes, group=10):
+  """models.py:253-255: mean over T, then mean over groups of `group`.
+
+  Both means are sequential float32 sums divided by the count."""
+  s = np.asarray(spikes, dtype=F32)
+  T = s.shape[0]
+  acc = np.zeros(s.shape[1:], dtype=F32)
+  for t in range(T):
+    acc = acc + s[t]
+  r = acc / F32(T)
+  r = r.reshape(r.shape[0], -1, group)
+  acc2 = np.zeros(r.shape[:2], dtype=F32)
+  for j in range(group):
+    acc2 = acc2 + r[:, :, j]
+  return (acc2 / F32(group)).astype(F32)
+
+
+def onehot(labels, num_classes):
+  return (np.asarray(labels)[:, None] == np.arange(num_classes)[None]).astype(F32)
+
+
+def mse_loss(logits, labels, smoothing=0.0, T=1):
+  """examples/train_utils.py:210-217."""
+  oh = onehot(labels, logits.shape[1])
+  oh = oh * F32(1 - smoothing) + F32(smoothing / oh.shape[1])
+  return F32(np.mean(np.square(np.asarray(logits, dtype=F32) / F32(T) - oh),
+                     dtype=F32))
+
+
+def compute_metrics(logits, labels, smoothing=0.0):
+  """examples/train_utils.py:220-225."""
+  return {"loss": mse_loss(logits, labels, smoothing),
+          "accuracy": np.argmax(logits, -1) == np.asarray(labels)}
+
+
+# ---------------------------------------------------------------------------
+# Model-level restatements for the BASELINE.json configs
+# ---------------------------------------------------------------------------
+
+
+def _neuron(cfg):
+  kind = cfg.get("kind", "multi_step_LIF")
+  vth, vr = cfg.get("v_threshold", 1.0), cfg.get("v_reset", 0.0)
+  if kind == "multi_step_LIF":
+    return lambda u, x: multi_step_lif(u, x, cfg.get("tau", 2.0), vth, vr)
+  if kind == "parametric_leaky_IF":
+    return lambda u, x: parametric_leaky_if(u, x, cfg["tau_param"], vth, vr)
+  if kind == "LIF":
+    return lambda u, x: lif(u, x, cfg["tau_vec"], vth, vr)
+  raise ValueError(kind)
+
+
+def dense_block(inputs, qw: QWeight, neuron_cfg=None, mode="int", u0=None):
+  """SpikingBlock(QuantDense, neuron) on [T, B, K] -> (u_T, spikes [T, B, N])."""
+  return spiking_block(u0, inputs, lambda x: quant_dense(x, qw, mode),
+                       _neuron(neuron_cfg or {}))
+
+
+def conv_block(inputs, qw: QWeight, bn: Optional[dict], neuron_cfg=None,
+               mode="int", padding=((1, 1), (1, 1)), strides=None, u0=None):
+  """SpikingBlock(QuantConv, neuron, BatchNorm) on [T, B, H, W, C]."""
+  norm = None
+  if bn is not None:
+    norm = lambda x: batchnorm_eval(x, bn["mean"], bn["var"], bn.get("scale"),
+                                    bn.get("bias"), bn.get("eps", 1e-5))
+  return spiking_block(
+      u0, inputs,
+      lambda x: quant_conv(x, qw, strides=strides, padding=padding, mode=mode),
+      _neuron(neuron_cfg or {}), norm)
+
+
+def dense2_forward(inputs, qw1: QWeight, qw2: QWeight, neuron_cfg=None,
+                   mode="int", group=10):
+  """Configs C1/C2: [T, B, 2048] -> QuantDense(512)+LIF -> QuantDense(110)+LIF -> vote.
+
+  Head of CextNet, models.py:200-255.  Returns dict of intermediates."""
+  u1, s1 = dense_block(inputs, qw1, neuron_cfg, mode)
+  u2, s2 = dense_block(s1, qw2, neuron_cfg, mode)
+  return {"u1": u1, "s1": s1, "u2": u2, "s2": s2, "logits": vote(s2, group)}
+
+
+def conv3_dense_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
+                        dense_qw: QWeight, neuron_cfg=None, mode="int",
+                        group=10, keep=False):
+  """Config C3: three (QuantConv3x3 + BN + LIF + 2x2 max-pool) blocks
+  (models.py:109-147), channel-major flatten (:189-190), QuantDense + LIF
+  (:231-246), vote (:253-255).  inputs [B, T, H, W, Cin]."""
+  x = np.swapaxes(np.asarray(inputs), 0, 1)          # models.py:109
+  out = {}
+  for i, (qw, bn) in enumerate(zip(conv_qw, bns)):
+    u, s = conv_block(x, qw, bn, neuron_cfg, mode)
+    x = max_pool_2x2(s)
+    if keep:
+      out["conv%d_u" % i], out["conv%d_s" % i] = u, s
+    out["pool%d" % i] = x
+  xf = flatten_channel_major(x)
+  u, s = dense_block(xf, dense_qw, neuron_cfg, mode)
+  out["dense_u"], out["dense_s"] = u, s
+  out["logits"] = vote(s, group)
+  return out
+
+
+# ---------------------------------------------------------------------------
+# Synthetic inputs shared by tests and bench
+# ---------------------------------------------------------------------------
+
+WEIGHT_SEED = 203853699      # examples/tcja/configs/prune_quant_joint.py:21
+DATA_SEED = 8627169          # quant_test.py:149
+
+
+def poisson_spikes(shape, lam=0.1, seed=DATA_SEED):
+  rng = np.random.Generator(np.random.PCG64(seed))
+  return (rng.poisson(lam, size=shape) > 0).astype(np.uint8)
+
+
+def synth_kernel(shape, gain=1.0, seed=WEIGHT_SEED):
+  """N(0, 1/fan_in) * gain (stand-in for lecun_normal, flax_qdense.py:26)."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  fan_in = int(np.prod(shape[:-1]))
+  return (rng.standard_normal(shape) * (gain / np.sqrt(fan_in))).astype(F32)

@@ -1,0 +1,70 @@
+// Entry points of the fused SpikingBlock (spiking_learning.py:446-462) and the
+// dispatch between the direct-form kernel and the int8 MFMA kernels.
+#include "common.h"
+#include "kernels.h"
+
+using namespace snnqp;
+
+extern "C" {
+
+int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
+                           int64_t x_stride_b, int32_t T, int32_t B,
+                           const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                           const int8_t *wt, const snnqp_bn_t *bn,
+                           const snnqp_neuron_t *nrn,
+                           const float *u0, float *u_out, void *s_out,
+                           int s_type, int pool, int impl,
+                           snnqp_stream_t stream) {
+  SNNQP_REQUIRE(g && w && nrn, SNNQP_EINVAL, "conv_lif_forward: null descriptor");
+  SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
+                    nrn->kind <= SNNQP_NEURON_LIF,
+                SNNQP_EINVAL, "conv_lif_forward: unknown neuron kind %d", nrn->kind);
+  SNNQP_REQUIRE(pool == 1 || pool == 2, SNNQP_EINVAL,
+                "conv_lif_forward: pool must be 1 or 2");
+  SNNQP_REQUIRE(impl >= SNNQP_IMPL_AUTO && impl <= SNNQP_IMPL_MFMA, SNNQP_EINVAL,
+                "conv_lif_forward: unknown impl %d", impl);
+  const char *why = conv3x3_mfma_unsupported(in_type, g, w, wt, nrn, s_type);
+  if (impl == SNNQP_IMPL_MFMA)
+    SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "conv_lif_forward: MFMA kernel: %s", why);
+  if (!why && impl != SNNQP_IMPL_GENERIC)
+    return run_conv3x3_mfma(x, in_type, x_stride_t, x_stride_b, T, B, g, w, wt, bn,
+                            nrn, u0, u_out, (uint32_t *)s_out, pool,
+                            (hipStream_t)stream);
+  SNNQP_REQUIRE(pool == 1, SNNQP_EUNSUPPORTED,
+                "conv_lif_forward: the direct-form kernel does not fuse the "
+                "max-pool; call snnqp_maxpool2x2 after it");
+  return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, g, w, bn, nrn, u0,
+                     u_out, s_out, s_type, nullptr, (hipStream_t)stream);
+}
+
+int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
+                            int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
+                            int32_t N, const snnqp_weight_t *w,
+                            const int8_t *wt, const snnqp_bn_t *bn,
+                            const snnqp_neuron_t *nrn, const float *u0,
+                            float *u_out, void *s_out, int s_type, int impl,
+                            snnqp_stream_t stream) {
+  SNNQP_REQUIRE(w && nrn, SNNQP_EINVAL, "dense_lif_forward: null descriptor");
+  SNNQP_REQUIRE(K > 0 && N > 0, SNNQP_EINVAL, "dense_lif_forward: bad K/N");
+  SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
+                    nrn->kind <= SNNQP_NEURON_LIF,
+                SNNQP_EINVAL, "dense_lif_forward: unknown neuron kind %d", nrn->kind);
+  SNNQP_REQUIRE(impl >= SNNQP_IMPL_AUTO && impl <= SNNQP_IMPL_MFMA, SNNQP_EINVAL,
+                "dense_lif_forward: unknown impl %d", impl);
+  const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
+  if (impl == SNNQP_IMPL_MFMA)
+    SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "dense_lif_forward: MFMA kernel: %s", why);
+  if (!why && impl != SNNQP_IMPL_GENERIC)
+    return run_dense_mfma(x, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn,
+                          u0, u_out, (uint32_t *)s_out, (hipStream_t)stream);
+  snnqp_conv_geom_t g;
+  g.H = 1; g.W = 1; g.Cin = K; g.Cout = N; g.KH = 1; g.KW = 1;
+  g.stride_h = g.stride_w = 1;
+  g.pad_h_lo = g.pad_h_hi = g.pad_w_lo = g.pad_w_hi = 0;
+  g.in_dil_h = g.in_dil_w = g.k_dil_h = g.k_dil_w = 1;
+  g.groups = 1;
+  return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, &g, w, bn, nrn, u0,
+                     u_out, s_out, s_type, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"

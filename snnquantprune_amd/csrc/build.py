@@ -1,0 +1,52 @@
+"""Builds libsnnqp.so (the C-ABI HIP library) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numeric
+contract: every float op of the reference keeps its own rounding.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["api.hip", "quantize.hip", "spikes.hip", "elementwise.hip",
+           "generic_block.hip", "blocks.hip", "conv3x3_mfma.hip", "dense_mfma.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+LIB = os.path.join(HERE, "libsnnqp.so")
+
+
+def _stale(out, deps):
+  if not os.path.exists(out):
+    return True
+  t = os.path.getmtime(out)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, extra_flags=()):
+  hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+  headers = [os.path.join(HERE, h) for h in ("common.h", "kernels.h")]
+  headers.append(os.path.join(HERE, "..", "..", "include", "snnqp.h"))
+  headers.append(os.path.abspath(__file__))
+  objs, jobs = [], []
+  for s in SOURCES:
+    src = os.path.join(HERE, s)
+    obj = os.path.join(HERE, s.replace(".hip", ".o"))
+    objs.append(obj)
+    if force or _stale(obj, [src] + headers):
+      jobs.append([hipcc, *FLAGS, *extra_flags, "-c", src, "-o", obj])
+
+  def run(cmd):
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+  with ThreadPoolExecutor(max_workers=4) as ex:
+    list(ex.map(run, jobs))
+  if jobs or force or _stale(LIB, objs):
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+  return LIB
+
+
+if __name__ == "__main__":
+  build(force="--force" in sys.argv)

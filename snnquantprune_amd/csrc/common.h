@@ -1,0 +1,137 @@
+// Shared host/device helpers for libsnnqp (gfx950 only).
+// Build flags matter: -ffp-contract=off keeps every float op of the reference
+// as its own rounding (fmaf appears only where it is written).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/snnqp.h"
+
+namespace snnqp {
+
+void set_error(const char *fmt, ...);
+
+#define SNNQP_REQUIRE(cond, code, ...)  \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::snnqp::set_error(__VA_ARGS__);  \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+#define SNNQP_CHECK_LAUNCH(name)                                         \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      ::snnqp::set_error("%s: %s", (name), hipGetErrorString(e__));      \
+      return SNNQP_EHIP;                                                 \
+    }                                                                    \
+  } while (0)
+
+#define SNNQP_HIP(call)                                                  \
+  do {                                                                   \
+    hipError_t e__ = (call);                                             \
+    if (e__ != hipSuccess) {                                             \
+      ::snnqp::set_error("%s: %s", #call, hipGetErrorString(e__));       \
+      return SNNQP_EHIP;                                                 \
+    }                                                                    \
+  } while (0)
+
+// ---- dequantisation:  x = fl(fl(acc / L) * m) -----------------------------
+// The division is done as q = a*r; e = fma(-q, L, a); q' = fma(e, r, q) with
+// r = fl(1/L); oracle/oracle_c.c:oracle_check_div proves it equal to the IEEE
+// quotient for every integer |a| <= 2^24 and every L = 2^(b-1) - 1.
+struct Dequant {
+  float L, rL, m;
+  int has_div;
+};
+
+inline Dequant make_dequant(float L, float m) {
+  Dequant d;
+  d.L = L;
+  d.rL = 1.0f / L;
+  d.m = m;
+  d.has_div = (L != 1.0f);
+  return d;
+}
+
+__device__ __forceinline__ float dequant_acc(int acc, const Dequant &d) {
+  float a = (float)acc;
+  if (d.has_div) {
+    float q = a * d.rL;
+    float e = __builtin_fmaf(-q, d.L, a);
+    a = __builtin_fmaf(e, d.rL, q);
+  }
+  return a * d.m;
+}
+
+// ---- neuron update, spiking_learning.py:357-438 ----------------------------
+struct NeuronP {
+  int kind;
+  float k;       // tau (MULTI_STEP_LIF) or sigmoid(tau_param) (PLIF)
+  float inv_k;   // 1/tau when tau is a power of two (exact), else 0
+  float vth, vr;
+  const float *decay;
+};
+
+inline NeuronP make_neuron(const snnqp_neuron_t *n) {
+  NeuronP p;
+  p.kind = n ? n->kind : SNNQP_NEURON_NONE;
+  p.k = n ? n->k : 1.0f;
+  p.vth = n ? n->v_threshold : 1.0f;
+  p.vr = n ? n->v_reset : 0.0f;
+  p.decay = n ? n->decay : nullptr;
+  p.inv_k = 0.0f;
+  if (p.kind == SNNQP_NEURON_MULTI_STEP_LIF) {
+    int e;
+    float mant = frexpf(p.k, &e);
+    // x / 2^j == x * 2^-j exactly (same real value, one rounding)
+    if (mant == 0.5f && e > -100 && e < 100) p.inv_k = 1.0f / p.k;
+  }
+  return p;
+}
+
+// Returns the spike; updates u.  `dec` is the per-feature decay (LIF only).
+__device__ __forceinline__ bool neuron_step(float &u, float x, const NeuronP &p,
+                                            float dec) {
+  if (p.kind == SNNQP_NEURON_MULTI_STEP_LIF) {
+    float d = x - (u - p.vr);                       // :410
+    u = u + (p.inv_k != 0.0f ? d * p.inv_k : d / p.k);
+  } else if (p.kind == SNNQP_NEURON_PARAMETRIC_LEAKY_IF) {
+    float d = x - (u - p.vr);                       // :381
+    u = u + d * p.k;
+  } else {
+    u = u * dec + x;                                // :432
+  }
+  bool s = (u - p.vth) >= 0.0f;                     // :412 / :224 Heaviside
+  u = s ? p.vr : u;                                 // :414
+  return s;
+}
+
+struct BnP {
+  const float *mean, *mul, *bias;
+};
+
+inline BnP make_bn(const snnqp_bn_t *b) {
+  BnP p;
+  p.mean = b ? b->mean : nullptr;
+  p.mul = b ? b->mul : nullptr;
+  p.bias = b ? b->bias : nullptr;
+  return p;
+}
+
+__device__ __forceinline__ float bn_apply(float x, float mean, float mul,
+                                          float bias) {
+  x = x - mean;
+  x = x * mul;
+  return x + bias;
+}
+
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace snnqp

@@ -1,0 +1,226 @@
+// Direct-form SpikingBlock: one thread owns one output neuron for all T steps
+// (membrane potential in a register), computing its convolution / dense sum
+// from the input each step.  Serves every geometry and element type of
+// QuantConv (flax_qconv.py:93-171) and QuantDense (flax_qdense.py:58-89, the
+// 1x1 convolution on a 1x1 image); the MFMA kernels take over the shapes the
+// BASELINE configs use.  Two arithmetic paths:
+//   INT   int8 codes x integer input (u8 counts or spike bits): exact int32
+//         accumulator, current = fl(fl(acc / L) * m)
+//   FSEQ  float32 weights x any input: fmaf chain over (kh, kw, cin) ascending
+#include "common.h"
+
+namespace snnqp {
+
+struct GenericArgs {
+  const void *x;
+  int64_t xs_t, xs_b;        // element (word for BITS) strides of t and b
+  int32_t T, B;
+  snnqp_conv_geom_t g;
+  int32_t OH, OW, Hd, Wd, CinG, CoutG, CWin;
+  const void *w;
+  Dequant dq;
+  BnP bn;
+  NeuronP nrn;
+  const float *u0;
+  float *u_out;
+  void *s_out;               // spikes (neuron) or float32 currents (no neuron)
+  int32_t s_type;
+  int32_t *acc_out;          // optional int32 accumulators (no-neuron mode)
+  int64_t total;             // B * OH * OW * Cout
+};
+
+template <int IN>
+__device__ __forceinline__ int load_int(const void *x, int64_t pix_off, int32_t c) {
+  if (IN == SNNQP_U8) return (int)((const uint8_t *)x)[pix_off + c];
+  // BITS: pix_off is in words
+  return (int)((((const uint32_t *)x)[pix_off + (c >> 5)] >> (c & 31)) & 1u);
+}
+
+template <int IN>
+__device__ __forceinline__ float load_float(const void *x, int64_t pix_off,
+                                            int32_t c) {
+  if (IN == SNNQP_F32) return ((const float *)x)[pix_off + c];
+  return (float)load_int<IN == SNNQP_F32 ? SNNQP_U8 : IN>(x, pix_off, c);
+}
+
+template <int IN, bool INTPATH>
+__global__ void __launch_bounds__(256)
+generic_block_kernel(GenericArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < a.total;
+  const snnqp_conv_geom_t &g = a.g;
+  int64_t r = live ? idx : 0;
+  const int32_t co = (int32_t)(r % g.Cout); r /= g.Cout;
+  const int32_t ox = (int32_t)(r % a.OW); r /= a.OW;
+  const int32_t oy = (int32_t)(r % a.OH); r /= a.OH;
+  const int32_t b = (int32_t)r;
+  const int32_t grp = co / a.CoutG;
+  const int32_t cin0 = grp * a.CinG;
+  const int64_t pix_elems = (IN == SNNQP_BITS) ? a.CWin : g.Cin;
+
+  float bmean = 0.f, bmul = 1.f, bbias = 0.f, dec = 0.f;
+  const bool has_bn = a.bn.mean != nullptr;
+  if (has_bn) { bmean = a.bn.mean[co]; bmul = a.bn.mul[co]; bbias = a.bn.bias[co]; }
+  if (a.nrn.kind == SNNQP_NEURON_LIF) dec = a.nrn.decay[co];
+  float u = 0.0f;
+  if (live && a.u0 && a.nrn.kind != SNNQP_NEURON_NONE) u = a.u0[idx];
+  const bool word_aligned = (g.Cout & 31) == 0;
+  const int32_t CWout = (g.Cout + 31) / 32;
+
+  for (int32_t t = 0; t < a.T; ++t) {
+    const int64_t img_off = (int64_t)t * a.xs_t + (int64_t)b * a.xs_b;
+    int iacc = 0;
+    float facc = 0.0f;
+    if (live) {
+      for (int32_t kh = 0; kh < g.KH; ++kh) {
+        const int32_t yd = oy * g.stride_h - g.pad_h_lo + kh * g.k_dil_h;
+        if (yd < 0 || yd >= a.Hd || (yd % g.in_dil_h) != 0) continue;
+        const int32_t iy = yd / g.in_dil_h;
+        for (int32_t kw = 0; kw < g.KW; ++kw) {
+          const int32_t xd = ox * g.stride_w - g.pad_w_lo + kw * g.k_dil_w;
+          if (xd < 0 || xd >= a.Wd || (xd % g.in_dil_w) != 0) continue;
+          const int32_t ix = xd / g.in_dil_w;
+          const int64_t pix_off = img_off + ((int64_t)iy * g.W + ix) * pix_elems;
+          const int64_t wbase = ((int64_t)(kh * g.KW + kw) * a.CinG) * g.Cout + co;
+          if (INTPATH) {
+            const int8_t *w = (const int8_t *)a.w;
+            for (int32_t ci = 0; ci < a.CinG; ++ci)
+              iacc += load_int<IN>(a.x, pix_off, cin0 + ci) *
+                      (int)w[wbase + (int64_t)ci * g.Cout];
+          } else {
+            const float *w = (const float *)a.w;
+            for (int32_t ci = 0; ci < a.CinG; ++ci)
+              facc = __builtin_fmaf(load_float<IN>(a.x, pix_off, cin0 + ci),
+                                    w[wbase + (int64_t)ci * g.Cout], facc);
+          }
+        }
+      }
+    }
+    float cur = INTPATH ? dequant_acc(iacc, a.dq) : facc;
+    if (has_bn) cur = bn_apply(cur, bmean, bmul, bbias);
+    const int64_t o = (int64_t)t * a.total + idx;
+    if (a.nrn.kind == SNNQP_NEURON_NONE) {
+      if (live) {
+        ((float *)a.s_out)[o] = cur;
+        if (INTPATH && a.acc_out) a.acc_out[o] = iacc;
+      }
+      continue;
+    }
+    bool s = false;
+    if (live) s = neuron_step(u, cur, a.nrn, dec);
+    if (a.s_type == SNNQP_F32) {
+      if (live) ((float *)a.s_out)[o] = s ? 1.0f : 0.0f;
+    } else if (word_aligned) {
+      // Cout % 32 == 0: the packed layout is the linear bit index idx.
+      const unsigned long long m = __ballot(s);
+      const int lane = threadIdx.x & 63;
+      if (live && (lane & 31) == 0)
+        ((uint32_t *)a.s_out)[o >> 5] = (uint32_t)(lane ? (m >> 32) : m);
+    } else if (live && s) {
+      const int64_t row = idx / g.Cout;
+      const int64_t rows = a.total / g.Cout;
+      atomicOr(&((uint32_t *)a.s_out)[((int64_t)t * rows + row) * CWout + (co >> 5)],
+               1u << (co & 31));
+    }
+  }
+  if (live && a.u_out && a.nrn.kind != SNNQP_NEURON_NONE) a.u_out[idx] = u;
+}
+
+template <int IN, bool INTPATH>
+static int launch_generic(const GenericArgs &a, hipStream_t st) {
+  const int64_t blocks = ceil_div64(a.total, 256);
+  SNNQP_REQUIRE(blocks < (1ll << 31), SNNQP_EINVAL, "generic block: grid too large");
+  hipLaunchKernelGGL((generic_block_kernel<IN, INTPATH>), dim3((unsigned)blocks),
+                     dim3(256), 0, st, a);
+  SNNQP_CHECK_LAUNCH("generic_block_kernel");
+  return SNNQP_OK;
+}
+
+int check_geom(const snnqp_conv_geom_t *g, int32_t *OH, int32_t *OW) {
+  SNNQP_REQUIRE(g, SNNQP_EINVAL, "null geometry");
+  SNNQP_REQUIRE(g->H >= 0 && g->W >= 0 && g->Cin > 0 && g->Cout > 0, SNNQP_EINVAL,
+                "bad geometry H=%d W=%d Cin=%d Cout=%d", g->H, g->W, g->Cin, g->Cout);
+  SNNQP_REQUIRE(g->groups > 0 && g->Cin % g->groups == 0 && g->Cout % g->groups == 0,
+                SNNQP_EINVAL,  // flax_qconv.py:117 assert
+                "in_features %d / features %d not divisible by feature_group_count %d",
+                g->Cin, g->Cout, g->groups);
+  int rc = snnqp_conv_out_shape(g, OH, OW);
+  return rc;
+}
+
+// Shared by snnqp_conv_forward / snnqp_conv_lif_forward / snnqp_dense_lif_forward.
+int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T,
+                int32_t B, const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                float *u_out, void *s_out, int s_type, int32_t *acc_out,
+                hipStream_t st) {
+  int32_t OH, OW;
+  int rc = check_geom(g, &OH, &OW);
+  if (rc) return rc;
+  SNNQP_REQUIRE(x && w && w->w && s_out, SNNQP_EINVAL, "generic block: null pointer");
+  SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "generic block: negative T/B");
+  GenericArgs a;
+  a.x = x; a.xs_t = xs_t; a.xs_b = xs_b; a.T = T; a.B = B; a.g = *g;
+  a.OH = OH; a.OW = OW;
+  a.Hd = g->H > 0 ? (g->H - 1) * g->in_dil_h + 1 : 0;
+  a.Wd = g->W > 0 ? (g->W - 1) * g->in_dil_w + 1 : 0;
+  a.CinG = g->Cin / g->groups; a.CoutG = g->Cout / g->groups;
+  a.CWin = (g->Cin + 31) / 32;
+  a.w = w->w;
+  a.dq = make_dequant(w->wtype == SNNQP_W_I8 ? w->L : 1.0f,
+                      w->wtype == SNNQP_W_I8 ? w->m : 1.0f);
+  a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
+  a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.s_type = s_type;
+  a.acc_out = acc_out;
+  a.total = (int64_t)B * OH * OW * g->Cout;
+  if (a.total == 0 || T == 0) return SNNQP_OK;
+  if (a.nrn.kind == SNNQP_NEURON_LIF)
+    SNNQP_REQUIRE(a.nrn.decay, SNNQP_EINVAL, "LIF neuron needs a decay vector");
+  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
+                        "batch-norm descriptor with null arrays");
+  if (a.nrn.kind != SNNQP_NEURON_NONE) {
+    SNNQP_REQUIRE(s_type == SNNQP_F32 || s_type == SNNQP_BITS, SNNQP_EINVAL,
+                  "spike output type must be F32 or BITS");
+    if (s_type == SNNQP_BITS && (g->Cout & 31) != 0) {
+      const int64_t words = (int64_t)T * B * OH * OW * ((g->Cout + 31) / 32);
+      SNNQP_HIP(hipMemsetAsync(s_out, 0, words * 4, st));
+    }
+  }
+  const bool intpath = (w->wtype == SNNQP_W_I8);
+  if (intpath) {
+    SNNQP_REQUIRE(in_type == SNNQP_U8 || in_type == SNNQP_BITS, SNNQP_EUNSUPPORTED,
+                  "int8 codes need integer-typed input (U8/BITS); pass the "
+                  "fake-quantised float kernel for float32 input");
+    SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
+    // int32 accumulator cannot overflow: |acc| <= 255 * 127 * K
+    const int64_t kk = (int64_t)g->KH * g->KW * a.CinG;
+    SNNQP_REQUIRE(kk * 255 * 127 < (1ll << 31), SNNQP_EUNSUPPORTED,
+                  "contraction length %lld overflows int32", (long long)kk);
+    return in_type == SNNQP_U8 ? launch_generic<SNNQP_U8, true>(a, st)
+                               : launch_generic<SNNQP_BITS, true>(a, st);
+  }
+  SNNQP_REQUIRE(w->wtype == SNNQP_W_F32, SNNQP_EINVAL, "unknown weight type");
+  switch (in_type) {
+    case SNNQP_F32: return launch_generic<SNNQP_F32, false>(a, st);
+    case SNNQP_U8: return launch_generic<SNNQP_U8, false>(a, st);
+    case SNNQP_BITS: return launch_generic<SNNQP_BITS, false>(a, st);
+  }
+  set_error("unknown input type %d", in_type);
+  return SNNQP_EINVAL;
+}
+
+}  // namespace snnqp
+
+extern "C" int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
+                                  const snnqp_conv_geom_t *g,
+                                  const snnqp_weight_t *w, float *y,
+                                  int32_t *acc, snnqp_stream_t stream) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(g, SNNQP_EINVAL, "conv_forward: null geometry");
+  SNNQP_REQUIRE(NB >= 0 && NB < (1ll << 31), SNNQP_EINVAL, "conv_forward: bad NB");
+  const int64_t pix = (in_type == SNNQP_BITS) ? (g->Cin + 31) / 32 : g->Cin;
+  const int64_t img = (int64_t)g->H * g->W * pix;
+  // the NB images are the "batch"; T = 1
+  return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr,
+                     nullptr, nullptr, y, SNNQP_F32, acc, (hipStream_t)stream);
+}

@@ -1,0 +1,32 @@
+// Internal declarations shared by the .hip translation units of libsnnqp.
+#pragma once
+#include "common.h"
+
+namespace snnqp {
+
+int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T,
+                int32_t B, const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                float *u_out, void *s_out, int s_type, int32_t *acc_out,
+                hipStream_t st);
+
+// nullptr when the MFMA kernel can serve the request, else the reason.
+const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
+                                     const snnqp_weight_t *w, const int8_t *wt,
+                                     const snnqp_neuron_t *nrn, int s_type);
+int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
+                     int32_t T, int32_t B, const snnqp_conv_geom_t *g,
+                     const snnqp_weight_t *w, const int8_t *wt,
+                     const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
+                     const float *u0, float *u_out, uint32_t *s_out, int pool,
+                     hipStream_t st);
+
+const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
+                                   const snnqp_weight_t *w, const int8_t *wt,
+                                   const snnqp_neuron_t *nrn, int s_type);
+int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
+                   int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
+                   const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                   float *u_out, uint32_t *s_out, hipStream_t st);
+
+}  // namespace snnqp

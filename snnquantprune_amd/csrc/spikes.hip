@@ -1,0 +1,236 @@
+// Activation-format helpers and the small element-wise ops around the blocks:
+// float32 <-> u8 / bit-packed spikes, 2x2 max-pool (models.py:145-147), rate
+// vote (models.py:253-255).  All HBM-bound single-pass kernels.
+#include "common.h"
+
+namespace snnqp {
+
+__global__ void __launch_bounds__(256)
+inspect_f32_kernel(const float *__restrict__ x, int64_t n,
+                   int32_t *__restrict__ flags) {
+  int32_t f = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (!(v >= 0.0f && v <= 255.0f) || v != rintf(v)) f |= SNNQP_FLAG_NOT_INTEGER;
+    if (v > 1.0f) f |= SNNQP_FLAG_GT_ONE;
+    if (v > 127.0f) f |= SNNQP_FLAG_GT_127;
+  }
+  if (f) atomicOr(flags, f);
+}
+
+__global__ void __launch_bounds__(256)
+f32_to_u8_kernel(const float *__restrict__ x, uint8_t *__restrict__ y,
+                 int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (uint8_t)x[i];
+}
+
+// One wave packs 64 consecutive channels of one row with a ballot.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_bits_kernel(const T *__restrict__ x, int64_t rows, int32_t C, int32_t CW,
+                 uint32_t *__restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cpr = (C + 63) / 64;  // chunks per row
+  const int64_t nchunks = rows * cpr;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t ch = wave0; ch < nchunks; ch += nwaves) {
+    const int64_t row = ch / cpr;
+    const int32_t c0 = (int32_t)(ch % cpr) * 64;
+    const int32_t c = c0 + lane;
+    bool v = false;
+    if (c < C) v = x[row * C + c] != (T)0;
+    const unsigned long long m = __ballot(v);
+    const int32_t w0 = c0 >> 5;
+    if (lane == 0) bits[row * CW + w0] = (uint32_t)m;
+    if (lane == 1 && w0 + 1 < CW) bits[row * CW + w0 + 1] = (uint32_t)(m >> 32);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+unpack_bits_kernel(const uint32_t *__restrict__ bits, int64_t rows, int32_t C,
+                   int32_t CW, float *__restrict__ y) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C;
+    const int32_t c = (int32_t)(i - row * C);
+    y[i] = (float)((bits[row * CW + (c >> 5)] >> (c & 31)) & 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+maxpool_f32_kernel(const float *__restrict__ x, int64_t NB, int32_t H, int32_t W,
+                   int32_t C, float *__restrict__ y) {
+  const int32_t OH = H / 2, OW = W / 2;
+  const int64_t n = NB * OH * OW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int32_t c = (int32_t)(r % C); r /= C;
+    const int32_t ox = (int32_t)(r % OW); r /= OW;
+    const int32_t oy = (int32_t)(r % OH); r /= OH;
+    const float *p = x + ((r * H + 2 * oy) * W + 2 * ox) * C + c;
+    const float a = fmaxf(p[0], p[C]);
+    const float b = fmaxf(p[(int64_t)W * C], p[(int64_t)W * C + C]);
+    y[i] = fmaxf(a, b);
+  }
+}
+
+// max over {0,1} is OR: one thread per output word.
+__global__ void __launch_bounds__(256)
+maxpool_bits_kernel(const uint32_t *__restrict__ x, int64_t NB, int32_t H,
+                    int32_t W, int32_t CW, uint32_t *__restrict__ y) {
+  const int32_t OH = H / 2, OW = W / 2;
+  const int64_t n = NB * OH * OW * CW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int32_t c = (int32_t)(r % CW); r /= CW;
+    const int32_t ox = (int32_t)(r % OW); r /= OW;
+    const int32_t oy = (int32_t)(r % OH); r /= OH;
+    const uint32_t *p = x + ((r * H + 2 * oy) * W + 2 * ox) * CW + c;
+    y[i] = p[0] | p[CW] | p[(int64_t)W * CW] | p[(int64_t)W * CW + CW];
+  }
+}
+
+template <bool BITS>
+__global__ void __launch_bounds__(256)
+vote_kernel(const void *__restrict__ s, int32_t T, int32_t B, int32_t N,
+            int32_t group, float *__restrict__ logits) {
+  const int32_t NC = N / group;
+  const int32_t CW = (N + 31) / 32;
+  const int64_t n = (int64_t)B * NC;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t b = (int32_t)(i / NC);
+    const int32_t k = (int32_t)(i % NC);
+    float acc2 = 0.0f;
+    for (int32_t j = 0; j < group; ++j) {
+      const int32_t nn = k * group + j;
+      float acc = 0.0f;
+      for (int32_t t = 0; t < T; ++t) {
+        float v;
+        if (BITS) {
+          const uint32_t w =
+              ((const uint32_t *)s)[((int64_t)t * B + b) * CW + (nn >> 5)];
+          v = (float)((w >> (nn & 31)) & 1u);
+        } else {
+          v = ((const float *)s)[((int64_t)t * B + b) * N + nn];
+        }
+        acc = acc + v;                       // jnp.mean(x, 0): sum ...
+      }
+      acc2 = acc2 + acc / (float)T;          // ... / T, then sum over group
+    }
+    logits[i] = acc2 / (float)group;
+  }
+}
+
+static inline int grid_for(int64_t n) {
+  const int64_t b = ceil_div64(n, 256);
+  return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
+}
+
+}  // namespace snnqp
+
+using namespace snnqp;
+
+extern "C" {
+
+int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
+                      snnqp_stream_t stream) {
+  SNNQP_REQUIRE(x && flags && n >= 0, SNNQP_EINVAL, "inspect_f32: null argument");
+  if (n == 0) return SNNQP_OK;
+  hipLaunchKernelGGL(inspect_f32_kernel, dim3(grid_for(n)), dim3(256), 0,
+                     (hipStream_t)stream, x, n, flags);
+  SNNQP_CHECK_LAUNCH("inspect_f32_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
+                    snnqp_stream_t stream) {
+  SNNQP_REQUIRE(x && y && n >= 0, SNNQP_EINVAL, "f32_to_u8: null argument");
+  if (n == 0) return SNNQP_OK;
+  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for(n)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, n);
+  SNNQP_CHECK_LAUNCH("f32_to_u8_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
+                    uint32_t *bits, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(x && bits && rows >= 0 && C > 0, SNNQP_EINVAL,
+                "pack_bits: bad argument");
+  SNNQP_REQUIRE(in_type == SNNQP_F32 || in_type == SNNQP_U8, SNNQP_EINVAL,
+                "pack_bits: input must be F32 or U8");
+  if (rows == 0) return SNNQP_OK;
+  const int32_t CW = (C + 31) / 32;
+  const int64_t nchunks = rows * ((C + 63) / 64);
+  const int grid = grid_for(nchunks * 64);
+  if (in_type == SNNQP_F32)
+    hipLaunchKernelGGL(pack_bits_kernel<float>, dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, (const float *)x, rows, C, CW, bits);
+  else
+    hipLaunchKernelGGL(pack_bits_kernel<uint8_t>, dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, (const uint8_t *)x, rows, C, CW, bits);
+  SNNQP_CHECK_LAUNCH("pack_bits_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
+                      snnqp_stream_t stream) {
+  SNNQP_REQUIRE(bits && y && rows >= 0 && C > 0, SNNQP_EINVAL,
+                "unpack_bits: bad argument");
+  if (rows == 0) return SNNQP_OK;
+  hipLaunchKernelGGL(unpack_bits_kernel, dim3(grid_for(rows * C)), dim3(256), 0,
+                     (hipStream_t)stream, bits, rows, C, (C + 31) / 32, y);
+  SNNQP_CHECK_LAUNCH("unpack_bits_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_maxpool2x2(const void *x, int type, int64_t NB, int32_t H, int32_t W,
+                     int32_t C, void *y, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(x && y && NB >= 0 && H >= 0 && W >= 0 && C > 0, SNNQP_EINVAL,
+                "maxpool2x2: bad argument");
+  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
+                "maxpool2x2: type must be F32 or BITS");
+  const int64_t opix = NB * (H / 2) * (W / 2);
+  if (opix == 0) return SNNQP_OK;
+  if (type == SNNQP_F32) {
+    hipLaunchKernelGGL(maxpool_f32_kernel, dim3(grid_for(opix * C)), dim3(256),
+                       0, (hipStream_t)stream, (const float *)x, NB, H, W, C,
+                       (float *)y);
+  } else {
+    const int32_t CW = (C + 31) / 32;
+    hipLaunchKernelGGL(maxpool_bits_kernel, dim3(grid_for(opix * CW)),
+                       dim3(256), 0, (hipStream_t)stream, (const uint32_t *)x,
+                       NB, H, W, CW, (uint32_t *)y);
+  }
+  SNNQP_CHECK_LAUNCH("maxpool kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_vote(const void *s, int type, int32_t T, int32_t B, int32_t N,
+               int32_t group, float *logits, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(s && logits && T > 0 && B >= 0 && N > 0 && group > 0,
+                SNNQP_EINVAL, "vote: bad argument");
+  SNNQP_REQUIRE(N % group == 0, SNNQP_EINVAL,
+                "vote: N=%d not divisible by group=%d", N, group);
+  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
+                "vote: type must be F32 or BITS");
+  if (B == 0) return SNNQP_OK;
+  const int64_t n = (int64_t)B * (N / group);
+  if (type == SNNQP_BITS)
+    hipLaunchKernelGGL(vote_kernel<true>, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, s, T, B, N, group, logits);
+  else
+    hipLaunchKernelGGL(vote_kernel<false>, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, s, T, B, N, group, logits);
+  SNNQP_CHECK_LAUNCH("vote_kernel");
+  return SNNQP_OK;
+}
+
+}  // extern "C"
