@@ -1,0 +1,114 @@
+"""ctypes binding of libsnnqp.so (include/snnqp.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to
+load, importing an op raises.  Build it with ``python __graft_entry__.py`` or
+``python snnquantprune_amd/csrc/build.py``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int8,
+                    c_int32, c_int64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
+
+# enums of include/snnqp.h
+F32, U8, BITS = 0, 1, 2
+W_F32, W_I8 = 0, 1
+NEURON_NONE, NEURON_MULTI_STEP_LIF, NEURON_PARAMETRIC_LEAKY_IF, NEURON_LIF = 0, 1, 2, 3
+Q_DUQ, Q_UNIFORM_STATIC, Q_PARAMETRIC_D, Q_PARAMETRIC_D_XMAX = 0, 1, 2, 3
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA = 0, 1, 2
+FLAG_CODE_OVERFLOW, FLAG_MASK_NOT_BINARY = 1, 2
+FLAG_NOT_INTEGER, FLAG_GT_ONE, FLAG_GT_127 = 4, 8, 16
+OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
+
+
+class WeightT(Structure):
+  _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float)]
+
+
+class BnT(Structure):
+  _fields_ = [("mean", c_void_p), ("mul", c_void_p), ("bias", c_void_p)]
+
+
+class NeuronT(Structure):
+  _fields_ = [("kind", c_int32), ("k", c_float), ("v_threshold", c_float),
+              ("v_reset", c_float), ("decay", c_void_p)]
+
+
+class ConvGeomT(Structure):
+  _fields_ = [(n, c_int32) for n in (
+      "H", "W", "Cin", "Cout", "KH", "KW", "stride_h", "stride_w",
+      "pad_h_lo", "pad_h_hi", "pad_w_lo", "pad_w_hi",
+      "in_dil_h", "in_dil_w", "k_dil_h", "k_dil_w", "groups")]
+
+
+_PROTOTYPES = {
+    "snnqp_version": (c_int, []),
+    "snnqp_last_error": (c_char_p, []),
+    "snnqp_conv_out_shape": (c_int, [POINTER(ConvGeomT), POINTER(c_int32),
+                                     POINTER(c_int32)]),
+    "snnqp_quantize": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_float,
+                               c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snnqp_transpose_codes": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                      c_void_p]),
+    "snnqp_inspect_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "snnqp_f32_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "snnqp_pack_bits": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p,
+                                c_void_p]),
+    "snnqp_unpack_bits": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "snnqp_conv_forward": (c_int, [c_void_p, c_int, c_int64, POINTER(ConvGeomT),
+                                   POINTER(WeightT), c_void_p, c_void_p, c_void_p]),
+    "snnqp_conv_lif_forward": (c_int, [
+        c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
+        POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
+        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "snnqp_dense_lif_forward": (c_int, [
+        c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
+        POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
+        c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "snnqp_lif_forward": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(BnT),
+                                  POINTER(NeuronT), c_void_p, c_void_p, c_void_p,
+                                  c_int, c_void_p]),
+    "snnqp_batchnorm_forward": (c_int, [c_void_p, c_int64, c_int32, POINTER(BnT),
+                                        c_void_p, c_void_p]),
+    "snnqp_maxpool2x2": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_int32,
+                                 c_void_p, c_void_p]),
+    "snnqp_vote": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int32, c_int32,
+                           c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+class SnnqpError(RuntimeError):
+  def __init__(self, code, msg):
+    super().__init__("libsnnqp error %d: %s" % (code, msg))
+    self.code = code
+
+
+def lib():
+  """Loads libsnnqp.so once; raises if it is missing (no CPU fallback)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise ImportError(
+          "HIP extension %s not found: build it with `python __graft_entry__.py` "
+          "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOTYPES.items():
+      fn = getattr(handle, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = handle
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    raise SnnqpError(rc, lib().snnqp_last_error().decode("utf-8", "replace"))

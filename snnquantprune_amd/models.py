@@ -1,0 +1,130 @@
+"""Models for the BASELINE.json configurations, built from the same blocks and
+with the same call signature as the reference's CextNet
+(examples/tcja/models.py:31-257):
+
+  DenseSNN      configs C1 / C2: the two-layer head of CextNet,
+                QuantDense(hidden)+LIF -> QuantDense(num_classes*10)+LIF -> vote
+                (models.py:200-255)
+  ConvDenseSNN  config C3: the three `for i in range(3)` conv blocks
+                (QuantConv 3x3 + BatchNorm + LIF + 2x2 max-pool, models.py:111-147)
+                -> channel-major flatten (:189-190) -> QuantDense + LIF (:231-246)
+                -> vote (:253-255)
+
+Variable names follow Flax auto-naming in construction order (QuantConv_i,
+BatchNorm_i, QuantDense_i; tcja_load_pretrained_weights.py:19-36).
+"""
+
+from __future__ import annotations
+
+from typing import Any, Callable
+
+import torch
+
+from . import linen as nn
+from . import ops
+from .flax_qconv import QuantConv
+from .flax_qdense import QuantDense
+from .spiking_learning import SpikingBlock
+
+
+def flatten_channel_major(x):
+  """transpose (T,B,C,H,W) + reshape [T, B, C*H*W]  (models.py:189-190).
+
+  Packed spikes are not moved: the NHWC words are re-labelled and the consumer
+  re-orders its weight rows (an exact re-indexing of an integer sum)."""
+  if isinstance(x, ops.PackedSpikes):
+    T, B, H, W, C = x.shape
+    if C % 32:
+      d = x.to_dense().permute(0, 1, 4, 2, 3).reshape(T, B, -1)
+      return ops.pack_bits(d.contiguous())
+    out = ops.PackedSpikes(x.bits.reshape(T, B, H * W * (C // 32)), H * W * C)
+    out.flat_perm = (C, H, W)
+    return out
+  x = x.permute(0, 1, 4, 2, 3)
+  return x.reshape(x.shape[0], x.shape[1], -1).contiguous()
+
+
+def _require_eval(train):
+  if train:
+    raise NotImplementedError(
+        "training (dropout, batch statistics, gradients) is out of scope: this "
+        "package implements the eval forward pass (train=False)")
+
+
+def _as_input(inputs):
+  if isinstance(inputs, ops.PackedSpikes):
+    return inputs
+  x = torch.as_tensor(inputs)
+  if x.dtype not in (torch.uint8, torch.float32):
+    x = x.to(torch.float32)
+  return x
+
+
+class DenseSNN(nn.Module):
+  """inputs [B, T, K] -> logits [B, num_classes] (configs C1 / C2)."""
+  num_classes: int = 11
+  dtype: Any = torch.float32
+  config: dict = nn.FrozenConfigDict({})
+
+  def __call__(self, inputs, trgt=None, train: bool = False, rng: Any = None,
+               u_state=None, online=False):
+    _require_eval(train)
+    cfg = self.config
+    x = _as_input(inputs)
+    hidden = cfg.hidden if "hidden" in cfg else cfg.channels * 2 * 2
+    layer = SpikingBlock(
+        connection_fn=QuantDense(hidden, use_bias=False, dtype=self.dtype,
+                                 config=cfg.quant, bits=cfg.quant.bits,
+                                 g_scale=cfg.quant.g_scale),
+        neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
+        return_state=False, batch_major_input=True)
+    _, x = layer(None, x)
+    layer = SpikingBlock(
+        connection_fn=QuantDense(self.num_classes * 10, use_bias=False,
+                                 dtype=self.dtype, config=cfg.quant,
+                                 bits=cfg.quant.bits, g_scale=cfg.quant.g_scale),
+        neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
+        return_state=False)
+    _, x = layer(None, x)
+    self.sow("intermediates", "dense2_out", x)
+    return ops.vote(x, 10), None                       # models.py:253-255
+
+
+class ConvDenseSNN(nn.Module):
+  """inputs [B, T, H, W, 2] -> logits [B, num_classes] (config C3)."""
+  num_classes: int = 11
+  dtype: Any = torch.float32
+  config: dict = nn.FrozenConfigDict({})
+
+  def __call__(self, inputs, trgt=None, train: bool = False, rng: Any = None,
+               u_state=None, online=False):
+    _require_eval(train)
+    cfg = self.config
+    x = _as_input(inputs)
+    nblocks = cfg.num_conv_blocks if "num_conv_blocks" in cfg else 3
+    norm = lambda: nn.BatchNorm(use_running_average=not train, momentum=0.9,  # noqa: E731
+                                epsilon=1e-5, use_bias=True, use_scale=True,
+                                dtype=self.dtype)
+    for i in range(nblocks):
+      layer = SpikingBlock(
+          connection_fn=QuantConv(features=cfg.channels, kernel_size=(3, 3),
+                                  padding=((1, 1), (1, 1)), use_bias=False,
+                                  dtype=self.dtype, config=cfg.quant,
+                                  bits=cfg.quant.bits, g_scale=cfg.quant.g_scale),
+          neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
+          norm_fn=norm(),
+          pool=2,                       # the reduce_window max of models.py:145-147
+          return_state=False,
+          batch_major_input=(i == 0))   # models.py:109 swapaxes, done by strides
+      _, x = layer(None, x)
+      self.sow("intermediates", "pool%d" % i, x)
+    x = flatten_channel_major(x)
+    layer = SpikingBlock(
+        connection_fn=QuantDense(self.num_classes * 10, use_bias=False,
+                                 dtype=self.dtype, config=cfg.quant,
+                                 bits=cfg.quant.bits, g_scale=cfg.quant.g_scale),
+        neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
+        return_state=False)
+    _, x = layer(None, x)
+    self.sow("intermediates", "dense_out", x)
+    return ops.vote(x, 10), None

@@ -1,0 +1,487 @@
+"""Thin functional layer: torch-ROCm tensors in, C-ABI calls (include/snnqp.h) out.
+
+torch is plumbing here (device memory + the current HIP stream); every op below
+is one call into libsnnqp.so.  Tensors must live on the GPU: there is no CPU
+fallback and nothing in this package imports the oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+# ---------------------------------------------------------------------------
+# Packed spike tensors
+# ---------------------------------------------------------------------------
+
+
+class PackedSpikes:
+  """Binary activations, channel-packed: `bits` is int32 [..., ceil(C/32)],
+  channel c of a row in bit (c & 31) of word (c >> 5); `shape` is the logical
+  shape [..., C] (time-major [T, B, ..., C] inside the model)."""
+
+  def __init__(self, bits: torch.Tensor, channels: int):
+    assert bits.dtype == torch.int32 and bits.is_contiguous()
+    assert bits.shape[-1] == (channels + 31) // 32
+    self.bits = bits
+    self.channels = int(channels)
+    # (C, H, W) when this is a [T, B, H*W*C] NHWC-ordered flattening of a
+    # [T, B, H, W, C] block whose logical order is channel-major
+    # (examples/tcja/models.py:189-190); consumers permute weight rows instead.
+    self.flat_perm = None
+
+  @property
+  def shape(self):
+    return tuple(self.bits.shape[:-1]) + (self.channels,)
+
+  @property
+  def device(self):
+    return self.bits.device
+
+  @property
+  def ndim(self):
+    return self.bits.ndim
+
+  def __getitem__(self, idx):
+    """Indexing over leading (non-channel) axes only."""
+    if not isinstance(idx, tuple):
+      idx = (idx,)
+    assert len(idx) < self.bits.ndim, "cannot index the packed channel axis"
+    return PackedSpikes(self.bits[idx].contiguous(), self.channels)
+
+  def reshape_leading(self, *lead):
+    return PackedSpikes(self.bits.reshape(*lead, self.bits.shape[-1]), self.channels)
+
+  def to_dense(self) -> torch.Tensor:
+    return unpack_bits(self)
+
+  def __repr__(self):
+    return "PackedSpikes(shape=%s, device=%s)" % (self.shape, self.device)
+
+
+# ---------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+  return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_gpu(*ts):
+  for t in ts:
+    if t is None:
+      continue
+    if not t.is_cuda:
+      raise RuntimeError(
+          "snnquantprune_amd ops run on the GPU only (tensor on %s); there is no "
+          "CPU fallback" % t.device)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+  if t.dtype != torch.float32:
+    t = t.to(torch.float32)
+  return t.contiguous()
+
+
+def is_pow2(x: float) -> bool:
+  import math
+  if not (x > 0) or math.isinf(x):
+    return False
+  m, _ = math.frexp(x)
+  return m == 0.5
+
+
+@dataclass
+class Weight:
+  """Kernel after the weight transforms (flax_qdense.py:74-85).
+
+  wtype W_I8: `w` = int8 codes * mask in the reference's layout, current =
+  fl(fl(acc / L) * m); `wt` = optional [Npad][K] transposed codes for MFMA.
+  wtype W_F32: `w` = float32 fake-quantised * mask kernel."""
+  wtype: int
+  w: torch.Tensor
+  L: float = 1.0
+  m: float = 1.0
+  wt: Optional[torch.Tensor] = None
+
+  def struct(self) -> L.WeightT:
+    return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m))
+
+  @property
+  def is_int(self):
+    return self.wtype == L.W_I8
+
+
+@dataclass
+class Neuron:
+  kind: int
+  k: float = 2.0
+  v_threshold: float = 1.0
+  v_reset: float = 0.0
+  decay: Optional[torch.Tensor] = None   # LIF: sigmoid(tau) per feature (device)
+
+  def struct(self) -> L.NeuronT:
+    return L.NeuronT(self.kind, float(self.k), float(self.v_threshold),
+                     float(self.v_reset),
+                     None if self.decay is None else self.decay.data_ptr())
+
+
+@dataclass
+class BnCoeffs:
+  mean: torch.Tensor
+  mul: torch.Tensor
+  bias: torch.Tensor
+
+  def struct(self) -> L.BnT:
+    return L.BnT(self.mean.data_ptr(), self.mul.data_ptr(), self.bias.data_ptr())
+
+
+@dataclass
+class ConvGeom:
+  H: int
+  W: int
+  Cin: int
+  Cout: int
+  KH: int
+  KW: int
+  stride: Tuple[int, int] = (1, 1)
+  pad: Tuple[Tuple[int, int], Tuple[int, int]] = ((0, 0), (0, 0))
+  in_dil: Tuple[int, int] = (1, 1)
+  k_dil: Tuple[int, int] = (1, 1)
+  groups: int = 1
+
+  def struct(self) -> L.ConvGeomT:
+    return L.ConvGeomT(self.H, self.W, self.Cin, self.Cout, self.KH, self.KW,
+                       self.stride[0], self.stride[1], self.pad[0][0],
+                       self.pad[0][1], self.pad[1][0], self.pad[1][1],
+                       self.in_dil[0], self.in_dil[1], self.k_dil[0],
+                       self.k_dil[1], self.groups)
+
+  def out_hw(self) -> Tuple[int, int]:
+    oh, ow = ctypes.c_int32(), ctypes.c_int32()
+    g = self.struct()
+    L.check(L.lib().snnqp_conv_out_shape(ctypes.byref(g), ctypes.byref(oh),
+                                         ctypes.byref(ow)))
+    return oh.value, ow.value
+
+
+def _in_desc(x):
+  """(pointer tensor, in_type, words/elements per pixel-row unit)."""
+  if isinstance(x, PackedSpikes):
+    return x.bits, L.BITS
+  if x.dtype == torch.uint8:
+    return x, L.U8
+  if x.dtype == torch.float32:
+    return x, L.F32
+  raise TypeError("activation dtype %s not supported (float32, uint8 or "
+                  "PackedSpikes)" % x.dtype)
+
+
+# ---------------------------------------------------------------------------
+# weight transforms
+# ---------------------------------------------------------------------------
+
+
+def quantize(kind: int, w: torch.Tensor, mask: Optional[torch.Tensor], bits: int,
+             p0: float, p1: float = 0.0, want_fq: bool = True,
+             want_codes: bool = False):
+  """snnqp_quantize: returns (fq | None, codes | None, flags tensor | None)."""
+  w = _f32c(w)
+  _require_gpu(w, mask)
+  if mask is not None:
+    mask = _f32c(mask)
+    assert mask.shape == w.shape
+  fq = torch.empty_like(w) if want_fq else None
+  codes = torch.empty(w.shape, dtype=torch.int8, device=w.device) if want_codes else None
+  flags = torch.zeros(1, dtype=torch.int32, device=w.device) if (
+      want_codes or mask is not None) else None
+  L.check(L.lib().snnqp_quantize(kind, _ptr(w), _ptr(mask), w.numel(), int(bits),
+                                 float(p0), float(p1), _ptr(fq), _ptr(codes),
+                                 _ptr(flags), _stream()))
+  return fq, codes, flags
+
+
+def transpose_codes(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
+  """[K, N] int8 -> [Npad, K] (k contiguous), zero rows beyond N."""
+  _require_gpu(codes)
+  assert codes.dtype == torch.int8
+  c2 = codes.reshape(-1, codes.shape[-1]).contiguous()
+  K, N = c2.shape
+  n_pad = N if n_pad is None else n_pad
+  wt = torch.empty((n_pad, K), dtype=torch.int8, device=codes.device)
+  L.check(L.lib().snnqp_transpose_codes(_ptr(c2), K, N, n_pad, _ptr(wt), _stream()))
+  return wt
+
+
+# ---------------------------------------------------------------------------
+# activation formats
+# ---------------------------------------------------------------------------
+
+
+def inspect_f32(x: torch.Tensor) -> int:
+  """Flags of a float32 activation tensor (one device pass + a 4-byte readback)."""
+  x = _f32c(x)
+  _require_gpu(x)
+  flags = torch.zeros(1, dtype=torch.int32, device=x.device)
+  L.check(L.lib().snnqp_inspect_f32(_ptr(x), x.numel(), _ptr(flags), _stream()))
+  return int(flags.item())
+
+
+def f32_to_u8(x: torch.Tensor) -> torch.Tensor:
+  x = _f32c(x)
+  _require_gpu(x)
+  y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+  L.check(L.lib().snnqp_f32_to_u8(_ptr(x), _ptr(y), x.numel(), _stream()))
+  return y
+
+
+def pack_bits(x: torch.Tensor) -> PackedSpikes:
+  """float32 / uint8 [..., C] (nonzero = spike) -> PackedSpikes."""
+  _require_gpu(x)
+  if x.dtype not in (torch.float32, torch.uint8):
+    x = x.to(torch.float32)
+  x = x.contiguous()
+  C = x.shape[-1]
+  rows = x.numel() // C if C else 0
+  bits = torch.empty(tuple(x.shape[:-1]) + ((C + 31) // 32,), dtype=torch.int32,
+                     device=x.device)
+  L.check(L.lib().snnqp_pack_bits(_ptr(x), L.F32 if x.dtype == torch.float32 else L.U8,
+                                  rows, C, _ptr(bits), _stream()))
+  return PackedSpikes(bits, C)
+
+
+def unpack_bits(s: PackedSpikes) -> torch.Tensor:
+  _require_gpu(s.bits)
+  y = torch.empty(s.shape, dtype=torch.float32, device=s.device)
+  rows = y.numel() // s.channels
+  L.check(L.lib().snnqp_unpack_bits(_ptr(s.bits), rows, s.channels, _ptr(y), _stream()))
+  return y
+
+
+# ---------------------------------------------------------------------------
+# connection only
+# ---------------------------------------------------------------------------
+
+
+def conv_forward(x, geom: ConvGeom, weight: Weight, want_acc: bool = False):
+  """x [NB, H, W, Cin] -> float32 [NB, OH, OW, Cout] (+ int32 accumulators)."""
+  xt, in_type = _in_desc(x)
+  xt = xt.contiguous()
+  _require_gpu(xt, weight.w)
+  NB = xt.shape[0]
+  OH, OW = geom.out_hw()
+  y = torch.empty((NB, OH, OW, geom.Cout), dtype=torch.float32, device=xt.device)
+  acc = torch.empty(y.shape, dtype=torch.int32, device=xt.device) if want_acc else None
+  g, w = geom.struct(), weight.struct()
+  L.check(L.lib().snnqp_conv_forward(_ptr(xt), in_type, NB, ctypes.byref(g),
+                                     ctypes.byref(w), _ptr(y), _ptr(acc), _stream()))
+  return (y, acc) if want_acc else y
+
+
+# ---------------------------------------------------------------------------
+# per-launch timing with HIP events on the launch stream (bench.py roofline)
+# ---------------------------------------------------------------------------
+
+_PROFILE = None
+
+
+def profile_start():
+  global _PROFILE
+  _PROFILE = {}
+
+
+def profile_stop():
+  """{tag: (launches, total milliseconds)} since profile_start()."""
+  global _PROFILE
+  prof, _PROFILE = _PROFILE or {}, None
+  torch.cuda.synchronize()
+  return {tag: (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+          for tag, evs in prof.items()}
+
+
+class _timed:
+  def __init__(self, tag):
+    self.tag = tag
+
+  def __enter__(self):
+    if _PROFILE is not None:
+      self.a = torch.cuda.Event(enable_timing=True)
+      self.b = torch.cuda.Event(enable_timing=True)
+      self.a.record()
+
+  def __exit__(self, *exc):
+    if _PROFILE is not None and exc[0] is None:
+      self.b.record()
+      _PROFILE.setdefault(self.tag, []).append((self.a, self.b))
+    return False
+
+
+# ---------------------------------------------------------------------------
+# fused SpikingBlock
+# ---------------------------------------------------------------------------
+
+
+def _tb_strides(x, T, B, time_major: bool, unit: int):
+  """Element (word) strides of t and b for a contiguous tensor."""
+  if time_major:
+    return B * unit, unit
+  return unit, T * unit
+
+
+def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
+                     bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
+                     want_u: bool = True, packed_out: bool = False, pool: int = 1,
+                     impl: int = L.IMPL_AUTO, time_major: bool = True):
+  """x [T, B, H, W, Cin] (or [B, T, ...] with time_major=False) ->
+  (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout])."""
+  xt, in_type = _in_desc(x)
+  xt = xt.contiguous()
+  _require_gpu(xt, weight.w, u0)
+  T, B = (xt.shape[0], xt.shape[1]) if time_major else (xt.shape[1], xt.shape[0])
+  unit = geom.H * geom.W * (xt.shape[-1])
+  xs_t, xs_b = _tb_strides(xt, T, B, time_major, unit)
+  OH, OW = geom.out_hw()
+  dev = xt.device
+  u_out = torch.empty((B, OH, OW, geom.Cout), dtype=torch.float32, device=dev) \
+      if want_u else None
+  if u0 is not None:
+    u0 = _f32c(u0)
+    assert tuple(u0.shape) == (B, OH, OW, geom.Cout), (u0.shape, (B, OH, OW, geom.Cout))
+  oshape = (T, B, OH // pool, OW // pool)
+  if packed_out:
+    s = torch.empty(oshape + ((geom.Cout + 31) // 32,), dtype=torch.int32, device=dev)
+  else:
+    s = torch.empty(oshape + (geom.Cout,), dtype=torch.float32, device=dev)
+  g, w, n = geom.struct(), weight.struct(), neuron.struct()
+  b = bn.struct() if bn is not None else None
+  with _timed("conv%dx%d[%dx%dx%d->%d]" % (geom.KH, geom.KW, geom.H, geom.W, geom.Cin,
+                                          geom.Cout)):
+    L.check(L.lib().snnqp_conv_lif_forward(
+        _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
+        _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
+        _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
+        _stream()))
+  return u_out, (PackedSpikes(s, geom.Cout) if packed_out else s)
+
+
+def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
+                      bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
+                      want_u: bool = True, packed_out: bool = False,
+                      impl: int = L.IMPL_AUTO, time_major: bool = True):
+  """x [T, B, K] -> (u_T [B, N] | None, spikes [T, B, N])."""
+  xt, in_type = _in_desc(x)
+  xt = xt.contiguous()
+  _require_gpu(xt, weight.w, u0)
+  T, B = (xt.shape[0], xt.shape[1]) if time_major else (xt.shape[1], xt.shape[0])
+  xs_t, xs_b = _tb_strides(xt, T, B, time_major, xt.shape[-1])
+  dev = xt.device
+  u_out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_u else None
+  if u0 is not None:
+    u0 = _f32c(u0)
+    assert tuple(u0.shape) == (B, N)
+  if packed_out:
+    s = torch.empty((T, B, (N + 31) // 32), dtype=torch.int32, device=dev)
+  else:
+    s = torch.empty((T, B, N), dtype=torch.float32, device=dev)
+  w, n = weight.struct(), neuron.struct()
+  b = bn.struct() if bn is not None else None
+  with _timed("dense[%d->%d]" % (K, N)):
+    L.check(L.lib().snnqp_dense_lif_forward(
+        _ptr(xt), in_type, xs_t, xs_b, T, B, K, N, ctypes.byref(w), _ptr(weight.wt),
+        ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0),
+        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl, _stream()))
+  return u_out, (PackedSpikes(s, N) if packed_out else s)
+
+
+# ---------------------------------------------------------------------------
+# element-wise pieces
+# ---------------------------------------------------------------------------
+
+
+def lif_forward(x: torch.Tensor, neuron: Neuron, bn: Optional[BnCoeffs] = None,
+                u0: Optional[torch.Tensor] = None, want_u: bool = True,
+                packed_out: bool = False):
+  """x float32 [T, ..., C] currents -> (u_T [..., C] | None, spikes [T, ..., C])."""
+  x = _f32c(x)
+  _require_gpu(x, u0)
+  T, C = x.shape[0], x.shape[-1]
+  R = (x.numel() // (T * C)) if T * C else 0
+  u_out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device) if want_u else None
+  if u0 is not None:
+    u0 = _f32c(u0)
+    assert tuple(u0.shape) == tuple(x.shape[1:])
+  if packed_out:
+    s = torch.empty(tuple(x.shape[:-1]) + ((C + 31) // 32,), dtype=torch.int32,
+                    device=x.device)
+  else:
+    s = torch.empty_like(x)
+  n = neuron.struct()
+  b = bn.struct() if bn is not None else None
+  L.check(L.lib().snnqp_lif_forward(
+      _ptr(x), T, R, C, ctypes.byref(b) if b is not None else None, ctypes.byref(n),
+      _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, _stream()))
+  return u_out, (PackedSpikes(s, C) if packed_out else s)
+
+
+def batchnorm_forward(x: torch.Tensor, bn: BnCoeffs) -> torch.Tensor:
+  x = _f32c(x)
+  _require_gpu(x)
+  C = x.shape[-1]
+  y = torch.empty_like(x)
+  b = bn.struct()
+  L.check(L.lib().snnqp_batchnorm_forward(_ptr(x), x.numel() // C if C else 0, C,
+                                          ctypes.byref(b), _ptr(y), _stream()))
+  return y
+
+
+def maxpool2x2(x):
+  """[..., H, W, C] -> [..., H/2, W/2, C] for float32 tensors or PackedSpikes."""
+  if isinstance(x, PackedSpikes):
+    bits = x.bits
+    _require_gpu(bits)
+    H, W = bits.shape[-3], bits.shape[-2]
+    lead = tuple(bits.shape[:-3])
+    NB = 1
+    for d in lead:
+      NB *= d
+    y = torch.empty(lead + (H // 2, W // 2, bits.shape[-1]), dtype=torch.int32,
+                    device=bits.device)
+    L.check(L.lib().snnqp_maxpool2x2(_ptr(bits), L.BITS, NB, H, W, x.channels, _ptr(y),
+                                     _stream()))
+    return PackedSpikes(y, x.channels)
+  x = _f32c(x)
+  _require_gpu(x)
+  H, W, C = x.shape[-3:]
+  lead = tuple(x.shape[:-3])
+  NB = 1
+  for d in lead:
+    NB *= d
+  y = torch.empty(lead + (H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+  L.check(L.lib().snnqp_maxpool2x2(_ptr(x), L.F32, NB, H, W, C, _ptr(y), _stream()))
+  return y
+
+
+def vote(s, group: int = 10) -> torch.Tensor:
+  """spikes [T, B, N] -> logits float32 [B, N // group] (models.py:253-255)."""
+  if isinstance(s, PackedSpikes):
+    t, typ, N = s.bits, L.BITS, s.channels
+  else:
+    t, typ, N = _f32c(s), L.F32, s.shape[-1]
+  _require_gpu(t)
+  T, B = t.shape[0], t.shape[1]
+  if N % group:
+    raise ValueError("vote: %d features not divisible by group %d" % (N, group))
+  out = torch.empty((B, N // group), dtype=torch.float32, device=t.device)
+  L.check(L.lib().snnqp_vote(_ptr(t), typ, T, B, N, group, _ptr(out), _stream()))
+  return out

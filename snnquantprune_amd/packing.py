@@ -1,0 +1,142 @@
+"""The pack step: reference parameter leaves -> what the kernels load.
+
+`{'kernel', 'DuQ_0': {a, c}, 'prune_0': {mask}}` becomes either
+int8 codes * mask with the dequantisation (L, m) -- the exact-integer path --
+or the float32 fake-quantised * mask kernel (unquantised layers, real-valued
+inputs).  This replaces the reference's per-timestep fake-quant inside the scan
+body (spiking_learning.py:455 -> flax_qdense.py:74-85): it runs once per weight
+version and is cached.
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .quant import QuantDesc
+
+# When True a float32 activation tensor is inspected on the device (one pass +
+# a 4-byte readback) and, if every value is a small non-negative integer, is
+# routed through the exact-integer kernels, like typed uint8 / PackedSpikes.
+AUTO_INTEGER_INPUTS = True
+
+
+class PackedKernel:
+  def __init__(self, kernel: torch.Tensor, desc: Optional[QuantDesc],
+               mask: Optional[torch.Tensor]):
+    self.kernel = kernel
+    self.desc = desc
+    self.mask = mask
+    self._int = None
+    self._int_done = False
+    self._float = None
+    self._wt = {}
+
+  def int_weight(self) -> Optional[ops.Weight]:
+    """int8 codes (None if unquantised, > 8 bits, or the mask is not 0/1)."""
+    if self._int_done:
+      return self._int
+    self._int_done = True
+    d = self.desc
+    if d is None or d.bits > 8:
+      return None
+    _, codes, flags = ops.quantize(d.kind, self.kernel, self.mask, d.bits, d.p0, d.p1,
+                                   want_fq=False, want_codes=True)
+    if int(flags.item()) & (L.FLAG_CODE_OVERFLOW | L.FLAG_MASK_NOT_BINARY):
+      return None
+    self._int = ops.Weight(L.W_I8, codes, d.L, d.m)
+    return self._int
+
+  def float_weight(self) -> ops.Weight:
+    """float32 kernel_fwd of flax_qdense.py:74-85 (fake-quant, then * mask)."""
+    if self._float is None:
+      d = self.desc
+      k = self.kernel.to(torch.float32).contiguous()
+      if d is not None:
+        fq, _, _ = ops.quantize(d.kind, k, self.mask, d.bits, d.p0, d.p1,
+                                want_fq=True, want_codes=False)
+      elif self.mask is not None:
+        fq = k * self.mask.to(k.device, torch.float32)   # quant.py:491
+      else:
+        fq = k
+      self._float = ops.Weight(L.W_F32, fq.contiguous())
+    return self._float
+
+  def int_weight_transposed(self, n_pad: int, row_perm: Optional[torch.Tensor] = None,
+                            perm_key=None) -> Optional[ops.Weight]:
+    """int weight with `wt` = [n_pad][K] codes for the MFMA kernels.  `row_perm`
+    re-orders the K rows first (an exact re-indexing of the integer sum, used
+    to absorb the channel-major flatten of models.py:189-190)."""
+    base = self.int_weight()
+    if base is None:
+      return None
+    key = (n_pad, perm_key)
+    w = self._wt.get(key)
+    if w is None:
+      codes = base.w.reshape(-1, base.w.shape[-1])
+      if row_perm is not None:
+        codes = codes.index_select(0, row_perm)
+      codes = codes.contiguous()
+      w = ops.Weight(L.W_I8, codes, base.L, base.m,
+                     wt=ops.transpose_codes(codes, n_pad))
+      self._wt[key] = w
+    return w
+
+
+_cache: "OrderedDict[tuple, PackedKernel]" = OrderedDict()
+_CACHE_MAX = 128
+
+
+def _tkey(t):
+  return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+def get_packed(kernel, desc, mask) -> PackedKernel:
+  key = (_tkey(kernel), desc, _tkey(mask))
+  pk = _cache.get(key)
+  if pk is None:
+    pk = PackedKernel(kernel, desc, mask)
+    _cache[key] = pk
+    while len(_cache) > _CACHE_MAX:
+      _cache.popitem(last=False)
+  else:
+    _cache.move_to_end(key)
+  return pk
+
+
+def clear_cache():
+  _cache.clear()
+
+
+def prepare_input(x, prefer_bits: Optional[bool] = None):
+  """Returns (tensor-or-PackedSpikes, integer_typed).
+
+  PackedSpikes and uint8 / bool / integer tensors are integer-typed as they are;
+  float32 tensors are inspected when AUTO_INTEGER_INPUTS is set."""
+  if isinstance(x, ops.PackedSpikes):
+    return x, True
+  if not isinstance(x, torch.Tensor):
+    x = torch.as_tensor(x)
+  if x.dtype == torch.uint8:
+    return x, True
+  if x.dtype in (torch.bool, torch.int8, torch.int16, torch.int32, torch.int64):
+    if x.dtype != torch.bool and (int(x.min()) < 0 or int(x.max()) > 255):
+      return x.to(torch.float32), False
+    return x.to(torch.uint8), True
+  if x.dtype != torch.float32:
+    x = x.to(torch.float32)
+  if not AUTO_INTEGER_INPUTS or x.numel() == 0:
+    return x, False
+  flags = ops.inspect_f32(x)
+  if flags & L.FLAG_NOT_INTEGER:
+    return x, False
+  binary = not (flags & L.FLAG_GT_ONE)
+  if prefer_bits is None:
+    prefer_bits = x.shape[-1] >= 32
+  if binary and prefer_bits:
+    return ops.pack_bits(x), True
+  return ops.f32_to_u8(x), True

@@ -1,0 +1,353 @@
+"""Neuron models and SpikingBlock -- host-side mirror of the reference's
+``spiking_learning.py`` (forward pass).
+
+The reference scans ``connection -> norm -> neuron`` over T with ``nn.scan``
+(spiking_learning.py:446-462).  Here one SpikingBlock call is ONE fused HIP
+launch (snnqp_conv_lif_forward / snnqp_dense_lif_forward): the connection is
+stateless across t, so only the neuron update is sequential and it runs inside
+the kernel with the membrane potential in registers.
+
+Out of scope (training / unused): surrogate-gradient backward rules
+(:139-241), gsis, debug, the DECOLLE neuron and block (:244-354).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Callable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import linen as nn
+from . import ops
+from . import packing
+from .flax_qconv import QuantConv
+from .flax_qdense import QuantDense
+
+Array = Any
+
+
+# ---------------------------------------------------------------------------
+# initialisers, spiking_learning.py:24-77 (host side)
+# ---------------------------------------------------------------------------
+
+
+def uniform(scale=1e-2, dtype=torch.float32):
+  def init(key, shape, dtype=dtype):
+    return (torch.rand(tuple(shape), generator=key) * scale * 2 - scale).to(
+        dtype).to(nn._default_device())
+  return init
+
+
+def static_init(val=1.0, dtype=torch.float32):
+  def init(key, shape, dtype=dtype):
+    return torch.full(tuple(shape), float(val), dtype=dtype, device=nn._default_device())
+  return init
+
+
+def normal_shift(bias=0, scale=1e-2, no_sign_flip=True, dtype=torch.float32):
+  def init(key, shape, dtype=dtype):
+    x = torch.randn(tuple(shape), generator=key) * scale + bias
+    if no_sign_flip:
+      x = x.abs()
+    return x.to(dtype).to(nn._default_device())
+  return init
+
+
+# ---------------------------------------------------------------------------
+# spike functions: forward = Heaviside(x >= 0), spiking_learning.py:139-241.
+# They differ only in their surrogate gradient; kept as config tokens.
+# ---------------------------------------------------------------------------
+
+
+def _make_spike_fn(name):
+  def fn(x):
+    return (x >= 0.0).to(x.dtype)
+  fn.__name__ = name
+  return fn
+
+
+fast_sigmoid = _make_spike_fn("fast_sigmoid")
+slayer = _make_spike_fn("slayer")
+smooth_step = _make_spike_fn("smooth_step")
+piecewise_linear = _make_spike_fn("piecewise_linear")
+atan = _make_spike_fn("atan")
+
+
+def _sigmoid_f32(x):
+  """float64 expit rounded once to float32 (PLIF / LIF decay factor)."""
+  x = np.asarray(x, dtype=np.float64)
+  return (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+
+
+_decay_cache = {}
+
+
+class _NeuronBase(nn.Module):
+
+  def _step(self, u, s_in):
+    """One time step (u, s_in) -> (u, s), via the T = 1 scan kernel."""
+    s_in = torch.as_tensor(s_in, dtype=torch.float32)
+    nrn = self.neuron(s_in.shape[-1])
+    u0 = None if u is None or isinstance(u, ZeroCarry) else u
+    x = s_in.unsqueeze(0)
+    if x.ndim == 2:                      # 1-D state: [T=1, C]
+      x = x.unsqueeze(1)
+      u0 = None if u0 is None else u0.unsqueeze(0)
+      u_out, s = ops.lif_forward(x, nrn, u0=u0)
+      return u_out[0], s[0, 0]
+    u_out, s = ops.lif_forward(x, nrn, u0=u0)
+    return u_out, s[0]
+
+
+class parametric_leaky_IF(_NeuronBase):
+  """spiking_learning.py:357-387: u += (s_in - (u - v_reset)) * sigmoid(tau)."""
+  init_tau: float
+  spike_fn: Callable
+  v_threshold: float = 1.0
+  v_reset: float = 0.0
+  pre_spike_fn: Callable = None
+  dtype: Any = torch.float32
+
+  @nn.compact_method
+  def neuron(self, features: int) -> ops.Neuron:
+    tau = self.param("tau", static_init(-math.log(self.init_tau - 1)), (1,))
+    k = float(_sigmoid_f32(tau.detach().cpu().numpy().reshape(-1)[0]))
+    return ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, k, self.v_threshold, self.v_reset)
+
+  def __call__(self, u, s_in):
+    return self._step(u, s_in)
+
+
+class multi_step_LIF(_NeuronBase):
+  """spiking_learning.py:390-416: u += (s_in - (u - v_reset)) / tau; s = u >= v_th;
+  hard reset.  No parameters."""
+  tau: float
+  spike_fn: Callable
+  v_threshold: float = 1.0
+  v_reset: float = 0.0
+  pre_spike_fn: Callable = None
+  dtype: Any = torch.float32
+
+  @nn.compact_method
+  def neuron(self, features: int) -> ops.Neuron:
+    return ops.Neuron(L.NEURON_MULTI_STEP_LIF, float(np.float32(self.tau)),
+                      self.v_threshold, self.v_reset)
+
+  def __call__(self, u, s_in):
+    return self._step(u, s_in)
+
+
+class LIF(_NeuronBase):
+  """spiking_learning.py:419-438: u = u * sigmoid(tau[N]) + s_in; reset where s > .5."""
+  init_tau: float
+  spike_fn: Callable
+  v_threshold: float = 1.0
+  v_reset: float = 0.0
+  dtype: Any = torch.float32
+
+  @nn.compact_method
+  def neuron(self, features: int) -> ops.Neuron:
+    tau = self.param("tau", uniform(self.init_tau), (int(features),))
+    key = (tau.data_ptr(), tau._version, str(tau.device))
+    dec = _decay_cache.get(key)
+    if dec is None:
+      if len(_decay_cache) > 256:
+        _decay_cache.clear()
+      dec = torch.from_numpy(_sigmoid_f32(tau.detach().cpu().numpy())).to(tau.device)
+      _decay_cache[key] = dec
+    return ops.Neuron(L.NEURON_LIF, 0.0, self.v_threshold, self.v_reset, decay=dec)
+
+  def __call__(self, u, s_in):
+    return self._step(u, s_in)
+
+
+class ZeroCarry:
+  """The all-zero initial membrane state of initialize_carry
+  (spiking_learning.py:464-472) without allocating it: the kernels start from
+  zero registers when given no u0."""
+
+  def __init__(self, shape, dtype=torch.float32):
+    self.shape = tuple(shape)
+    self.dtype = dtype
+
+  def materialize(self, device=None):
+    return torch.zeros(self.shape, dtype=self.dtype, device=device or nn._default_device())
+
+  def __repr__(self):
+    return "ZeroCarry(shape=%s)" % (self.shape,)
+
+
+def _flat_perm(c, h, w, device):
+  """row_perm[k_nhwc] = k_channel_major for a [h, w, c] block flattened NHWC."""
+  idx = torch.arange(c * h * w, device=device).reshape(c, h, w)   # value = k_cm
+  return idx.permute(1, 2, 0).reshape(-1).contiguous()           # position = k_nhwc
+
+
+class SpikingBlock(nn.Module):
+  """connection -> [norm] -> neuron over the leading (time) axis.
+
+  Reference surface (spiking_learning.py:441-472):
+    SpikingBlock(connection_fn, neural_dynamics, norm_fn=None)(u, inputs[T, B, ...])
+      -> (u_T, spikes[T, B, ...])
+  Extensions used by this package's models (defaults keep the reference's
+  behaviour):
+    pool          2 fuses the 2x2 max-pool that follows the block in
+                  examples/tcja/models.py:145-147 (spikes come back pooled)
+    return_state  False skips materialising u_T (the models discard it)
+    packed        True / False forces bit-packed / float32 spikes; None: packed
+                  iff the input was integer-typed (uint8 or PackedSpikes)
+    impl          kernel choice, _lib.IMPL_*
+    batch_major_input  inputs are [B, T, ...] (the model's input layout,
+                  models.py:109 swaps axes first); the kernels read it by strides
+  """
+  connection_fn: Callable
+  neural_dynamics: Callable
+  norm_fn: Callable = None
+  pool: int = 1
+  return_state: bool = True
+  packed: Optional[bool] = None
+  impl: int = L.IMPL_AUTO
+  batch_major_input: bool = False
+
+  def _fusable(self):
+    conn, nrn, norm = self.connection_fn, self.neural_dynamics, self.norm_fn
+    if not isinstance(conn, (QuantDense, QuantConv)) or conn.use_bias:
+      return False
+    if not isinstance(nrn, _NeuronBase):
+      return False
+    if norm is not None:
+      if not isinstance(norm, nn.BatchNorm) or not norm.use_running_average:
+        return False
+    return True
+
+  def __call__(self, u, inputs):
+    if self.pool not in (1, 2):
+      raise ValueError("pool must be 1 or 2")
+    if self._fusable():
+      return self._fused(u, inputs)
+    return self._composed(u, inputs)
+
+  # -- one launch ---------------------------------------------------------------
+  def _fused(self, u, inputs):
+    conn, norm = self.connection_fn, self.norm_fn
+    flat = getattr(inputs, "flat_perm", None)
+    x, integer = packing.prepare_input(inputs)
+    if flat is not None:
+      x.flat_perm = flat
+    u0 = None if (u is None or isinstance(u, ZeroCarry)) else u
+    tm = not self.batch_major_input
+    cin = x.shape[-1]
+    pk = conn.packed_kernel(cin)
+    packed_out = integer if self.packed is None else bool(self.packed)
+    is_dense = isinstance(conn, QuantDense)
+    w = None
+    if integer:
+      if is_dense:
+        n_pad = (conn.features + 31) // 32 * 32
+        perm = None
+        if flat is not None:
+          perm = _flat_perm(*flat, device=pk.kernel.device)
+        w = pk.int_weight_transposed(n_pad, perm, perm_key=flat)
+        flat = None if w is not None else flat
+      else:
+        w = pk.int_weight_transposed(conn.features)
+    if w is None:
+      w = pk.float_weight()
+    if flat is not None:
+      # float path: the fmaf order is the channel-major one -> reorder the data
+      c, h, ww = flat
+      d = x.to_dense() if isinstance(x, ops.PackedSpikes) else x.to(torch.float32)
+      d = d.reshape(d.shape[0], d.shape[1], h, ww, c).permute(0, 1, 4, 2, 3)
+      x = d.reshape(d.shape[0], d.shape[1], -1).contiguous()
+    nrn = self.neural_dynamics.neuron(conn.features)
+    bn = norm.coeffs(conn.features) if norm is not None else None
+
+    if is_dense:
+      if x.ndim != 3:
+        raise ValueError("QuantDense block expects [T, B, K] inputs, got %s" % (x.shape,))
+      u_out, s = ops.dense_lif_forward(x, w, cin, conn.features, nrn, bn=bn, u0=u0,
+                                       want_u=self.return_state, packed_out=packed_out,
+                                       impl=self.impl, time_major=tm)
+      if self.pool == 2:
+        raise ValueError("pool=2 needs a convolutional block")
+      return u_out, s
+
+    nsp = len(conn._ksize())
+    if x.ndim != nsp + 3:
+      raise ValueError("QuantConv block expects [T, B, spatial..., C] inputs, got %s"
+                       % (x.shape,))
+    geom = conn.geometry(tuple(x.shape[2:-1]), cin)
+    T, B = (x.shape[0], x.shape[1]) if tm else (x.shape[1], x.shape[0])
+    if nsp == 1 and not tm:
+      raise NotImplementedError("batch-major input for 1-D convolution blocks")
+    if nsp == 1:     # 1-D: H = 1
+      if isinstance(x, ops.PackedSpikes):
+        x = x.reshape_leading(T, B, 1, geom.W)
+      else:
+        x = x.reshape(T, B, 1, geom.W, cin)
+      if u0 is not None:
+        u0 = u0.unsqueeze(1)
+    try:
+      u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
+                                      want_u=self.return_state, packed_out=packed_out,
+                                      pool=self.pool, impl=self.impl, time_major=tm)
+    except L.SnnqpError as e:
+      if e.code != L.EUNSUPPORTED or self.pool != 2 or self.impl == L.IMPL_MFMA:
+        raise
+      u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
+                                      want_u=self.return_state, packed_out=packed_out,
+                                      pool=1, impl=self.impl, time_major=tm)
+      s = ops.maxpool2x2(s)
+    if nsp == 1:
+      if isinstance(s, ops.PackedSpikes):
+        s = s.reshape_leading(T, B, s.shape[3])
+      else:
+        s = s.reshape(T, B, s.shape[3], s.shape[4])
+      if u_out is not None:
+        u_out = u_out.squeeze(1)
+    return u_out, s
+
+  # -- arbitrary connection / norm / neuron: compose the stand-alone ops -----------
+  def _composed(self, u, inputs):
+    conn, norm, nrn_mod = self.connection_fn, self.norm_fn, self.neural_dynamics
+    if self.batch_major_input:
+      inputs = inputs.transpose(0, 1)
+    T = inputs.shape[0]
+    xs = []
+    for t in range(T):
+      x = conn(inputs[t])
+      if norm is not None:
+        x = norm(x)
+      xs.append(x)
+    x = torch.stack(xs, 0)
+    if isinstance(nrn_mod, _NeuronBase):
+      u0 = None if (u is None or isinstance(u, ZeroCarry)) else u
+      packed_out = bool(self.packed)
+      u_out, s = ops.lif_forward(x, nrn_mod.neuron(x.shape[-1]), u0=u0,
+                                 want_u=self.return_state, packed_out=packed_out)
+    else:                       # foreign neuron callable: explicit time loop
+      if isinstance(u, ZeroCarry) or u is None:
+        u = torch.zeros_like(x[0])
+      out = []
+      for t in range(T):
+        u, st = nrn_mod(u, x[t])
+        out.append(st)
+      u_out, s = u, torch.stack(out, 0)
+    if self.pool == 2:
+      s = ops.maxpool2x2(s)
+    return u_out, s
+
+  @staticmethod
+  def initialize_carry(inputs, connection_fn, norm_fn=None, dtype=torch.float32):
+    """Zero state shaped like norm(conn(inputs[0])) (spiking_learning.py:464-472);
+    returned lazily, the connection is not run for its shape."""
+    shape = tuple(inputs.shape[1:])
+    if hasattr(connection_fn, "out_shape"):
+      return ZeroCarry(connection_fn.out_shape(shape), dtype)
+    x = connection_fn(inputs[0])
+    if norm_fn is not None:
+      x = norm_fn(x)
+    return ZeroCarry(tuple(x.shape), dtype)

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+  from oracle import snn_oracle
+  snn_oracle.clib()          # builds liboracle_c.so if missing
+  return snn_oracle
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+  return os.path.join(ROOT, "tests", "golden")

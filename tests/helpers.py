@@ -1,0 +1,35 @@
+"""Shared by the CPU and GPU tests: oracle-side views of the synthetic trees."""
+import numpy as np
+
+
+def qweight_of(o, leaf, bits, quantized=True):
+  """oracle.QWeight from a reference-style parameter leaf."""
+  a = float(leaf["DuQ_0"]["a"][0])
+  quant = None
+  if quantized and a != -1.0:
+    quant = {"kind": "duq", "bits": bits, "a": a, "c": float(leaf["DuQ_0"]["c"][0])}
+  mask = leaf.get("prune_0", {}).get("mask")
+  return o.QWeight(leaf["kernel"], quant, mask)
+
+
+def bn_of(variables, i):
+  p = variables["params"]["BatchNorm_%d" % i]
+  s = variables["batch_stats"]["BatchNorm_%d" % i]
+  return dict(mean=s["mean"], var=s["var"], scale=p["scale"], bias=p["bias"])
+
+
+def packbits_lastaxis(s):
+  """uint8/float 0-1 array [..., C] -> uint32 words [..., ceil(C/32)] in the
+  library's bit order (channel c -> bit c & 31 of word c >> 5)."""
+  s = (np.asarray(s) != 0)
+  C = s.shape[-1]
+  CW = (C + 31) // 32
+  pad = CW * 32 - C
+  if pad:
+    s = np.concatenate([s, np.zeros(s.shape[:-1] + (pad,), bool)], -1)
+  b = np.packbits(s.reshape(s.shape[:-1] + (CW, 32)), axis=-1, bitorder="little")
+  return b.view(np.uint32).reshape(s.shape[:-1] + (CW,))
+
+
+def rate(s):
+  return float(np.mean(np.asarray(s, dtype=np.float64)))

@@ -1,0 +1,207 @@
+"""CPU suite, part 2: host logic -- the C-ABI library loads and exports every
+symbol include/snnqp.h declares (no compute without a GPU), the module
+protocol produces the reference's variable tree, argument errors surface as the
+reference's exceptions, and the data-parallel path works on gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+  from snnquantprune_amd import _lib as L
+  if not os.path.exists(L.LIB_PATH):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
+  return L
+
+
+def test_library_exports_every_declared_symbol():
+  L = _lib()
+  hdr = open(os.path.join(ROOT, "include", "snnqp.h")).read()
+  hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+  declared = set(re.findall(r"\b(snnqp_[a-z0-9_]+)\s*\(", hdr))
+  assert declared, "no declarations parsed"
+  lib = L.lib()
+  for name in sorted(declared):
+    assert hasattr(lib, name), "libsnnqp.so does not export %s" % name
+  assert declared == set(L.EXPORTED_SYMBOLS)
+  assert lib.snnqp_version() >= 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+  L = _lib()
+  lib = L.lib()
+  # quant.py:332-336: bit widths below 2 are rejected
+  rc = lib.snnqp_quantize(L.Q_UNIFORM_STATIC, ctypes.c_void_p(8), None, 4, 1, 1.0, 0.0,
+                          None, None, None, None)
+  assert rc == L.EINVAL and b"bits" in lib.snnqp_last_error()
+  with pytest.raises(L.SnnqpError):
+    L.check(rc)
+  g = L.ConvGeomT(28, 28, 3, 8, 2, 2, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 2)
+  w = L.WeightT(L.W_F32, 8, 1.0, 1.0)
+  rc = lib.snnqp_conv_forward(ctypes.c_void_p(8), L.F32, 1, ctypes.byref(g), ctypes.byref(w),
+                              ctypes.c_void_p(8), None, None)
+  assert rc == L.EINVAL and b"feature_group_count" in lib.snnqp_last_error()  # flax_qconv.py:117
+  rc = lib.snnqp_vote(ctypes.c_void_p(8), L.F32, 4, 2, 110, 7, ctypes.c_void_p(8), None)
+  assert rc == L.EINVAL
+
+
+def test_conv_out_shape_matches_reference_table():
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  from tests import cases
+  _lib()
+  for name, H, W, ks, st, pad, OH, OW in cases.REF_CONV_GEOMS:
+    conv = QuantConv(features=10, kernel_size=ks, strides=st, padding=pad,
+                     config=nn.ConfigDict({"prune_percentage": -1.0}))
+    assert conv.geometry((H, W), 1).out_hw() == (OH, OW), name
+    conv2 = QuantConv(features=20, kernel_size=ks, strides=st, padding=pad,
+                      config=nn.ConfigDict({"prune_percentage": -1.0}))
+    assert conv2.geometry((OH, OW), 10).out_hw() == cases.REF_CONV_TWICE[name], name
+  c1 = QuantConv(features=8, kernel_size=[4], padding="SAME",
+                 config=nn.ConfigDict({"prune_percentage": -1.0}))
+  g = c1.geometry((20,), 128)
+  assert g.pad == ((0, 0), (1, 2)) and g.out_hw() == (1, 20)      # TCJA convs, k = 4
+
+
+def test_ops_refuse_cpu_tensors():
+  from snnquantprune_amd import ops
+  _lib()
+  with pytest.raises(RuntimeError, match="GPU only"):
+    ops.pack_bits(torch.zeros(4, 32))
+  with pytest.raises(RuntimeError, match="GPU only"):
+    ops.vote(torch.zeros(2, 2, 20))
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+  from snnquantprune_amd import _lib as L
+  monkeypatch.setattr(L, "_lib", None)
+  monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+  with pytest.raises(ImportError, match="no CPU fallback"):
+    L.lib()
+
+
+def test_product_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, "snnquantprune_amd")
+  for dp, _, fs in os.walk(pkg):
+    for f in fs:
+      if f.endswith((".py", ".hip", ".h", ".cpp")):
+        src = open(os.path.join(dp, f)).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+        assert "snn_oracle" not in src, f
+
+
+# ---- module protocol ---------------------------------------------------------------
+
+def test_module_protocol_names_and_mutability():
+  from snnquantprune_amd import linen as nn
+
+  class Leaf(nn.Module):
+    feats: int
+
+    def __call__(self, x):
+      w = self.param("kernel", nn.lecun_normal(), (x.shape[-1], self.feats))
+      cnt = self.variable("batch_stats", "count", lambda: torch.zeros(()))
+      if self.is_mutable_collection("batch_stats"):
+        cnt.value = cnt.value + 1
+      return x @ w.cpu()
+
+  class Holder(nn.Module):
+    inner: object
+
+    def __call__(self, x):
+      return self.inner(x)
+
+  class Top(nn.Module):
+    config: dict = nn.FrozenConfigDict({})
+
+    def __call__(self, x, train=False):
+      a, b = Leaf(4), Leaf(3)
+      y = Holder(inner=a)(x)      # `a` keeps the name it got in Top's scope
+      y = a(x) + y                # second call shares the same parameters
+      return b(y)
+
+  top = Top()
+  v = top.init({"params": 1}, torch.ones(2, 5))
+  assert sorted(v["params"]) == ["Leaf_0", "Leaf_1"]
+  assert v["params"]["Leaf_0"]["kernel"].shape == (5, 4)
+  out = top.apply(v, torch.ones(2, 5))
+  out2, mut = top.apply(v, torch.ones(2, 5), mutable=["batch_stats"])
+  assert torch.equal(out, out2)
+  assert float(mut["batch_stats"]["Leaf_0"]["count"]) == float(
+      v["batch_stats"]["Leaf_0"]["count"]) + 2
+  assert float(v["batch_stats"]["Leaf_0"]["count"]) == 2      # input tree untouched
+  with pytest.raises(KeyError):
+    top.apply({"params": {}}, torch.ones(2, 5))
+  with pytest.raises(RuntimeError):
+    Leaf(3)(torch.ones(2, 5))                                  # unbound call
+
+
+def test_config_dict_behaves_like_the_reference_expects():
+  from snnquantprune_amd import linen as nn
+  cfg = nn.ConfigDict({"quant": {"bits": 4}})
+  assert cfg.quant.bits == 4 and "weight" not in cfg.quant
+  with pytest.raises(AttributeError):          # flax_qdense.py:84 on stale configs
+    cfg.quant.prune_percentage
+  cfg.quant.prune_percentage = 0.9
+  assert cfg.quant["prune_percentage"] == 0.9
+
+
+def test_synthetic_trees_use_reference_names():
+  from snnquantprune_amd import synthetic as syn
+  v = syn.conv_net_variables(hw=16)
+  assert sorted(v["params"]) == ["BatchNorm_0", "BatchNorm_1", "BatchNorm_2", "QuantConv_0",
+                                 "QuantConv_1", "QuantConv_2", "QuantDense_0"]
+  leaf = v["params"]["QuantConv_1"]
+  assert sorted(leaf) == ["DuQ_0", "kernel", "prune_0"]
+  assert leaf["kernel"].shape == (3, 3, 128, 128) and leaf["DuQ_0"]["a"].shape == (1,)
+  assert abs(1 - leaf["prune_0"]["mask"].mean() - 0.9) < 1e-3
+  assert sorted(v["batch_stats"]["BatchNorm_0"]) == ["mean", "var"]
+
+
+def test_shard_bounds_error_matches_eval_py():
+  from snnquantprune_amd import parallel
+  assert parallel.shard_bounds(16, 3, 8) == (6, 8)
+  with pytest.raises(ValueError, match="divisible"):
+    parallel.shard_bounds(10, 0, 8)
+
+
+_GLOO_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from snnquantprune_amd import parallel
+rank, world, _ = parallel.init_from_env("gloo")
+assert world == 2
+x = torch.arange(8 * 3, dtype=torch.float32).reshape(8, 3)
+def apply_fn(variables, inp, **kw):        # stand-in for model.apply
+  return (inp.sum(-1, keepdim=True) * variables["s"], None), {}
+full = parallel.sharded_logits(apply_fn, {"s": 2.0}, x, rank, world)
+assert full.shape == (8, 1)
+assert torch.equal(full, x.sum(-1, keepdim=True) * 2.0), full
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_eval_on_gloo_world_size_2(tmp_path):
+  script = tmp_path / "worker.py"
+  script.write_text(_GLOO_WORKER % ROOT)
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+           for r in range(2)]
+  outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+  for p, o in zip(procs, outs):
+    assert p.returncode == 0, o
+    assert "ok" in o

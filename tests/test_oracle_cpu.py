@@ -1,0 +1,224 @@
+"""CPU suite, part 1: the oracle against its pins -- the reference tests'
+invariants, source-derived known answers, and the committed
+golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+F32 = np.float32
+
+
+# ---- golden fixtures ---------------------------------------------------------
+
+@pytest.mark.parametrize("name", sorted(cases.GOLDEN))
+def test_oracle_reproduces_golden(oracle, golden_dir, name):
+  exp = cases.GOLDEN[name](oracle)
+  with np.load(os.path.join(golden_dir, name + ".npz")) as g:
+    assert sorted(g.files) == sorted(exp)
+    for k in exp:
+      np.testing.assert_array_equal(np.asarray(exp[k]), g[k], err_msg=k)
+
+
+def test_fixture_firing_rates_are_not_vacuous(golden_dir):
+  """All-zero rasters would make parity vacuous."""
+  for name in ("conv_block_c128", "conv_block_c2"):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as g:
+      assert 0.02 <= float(g["rate"][0]) <= 0.30, (name, g["rate"])
+  with np.load(os.path.join(golden_dir, "conv_net_c3_tiny.npz")) as g:
+    assert np.all(g["rates"] > 0.02) and np.all(g["rates"] < 0.5), g["rates"]
+  for name in ("dense_net_c1", "dense_net_c2"):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as g:
+      assert 0.01 < g["s1"].mean() < 0.3 and 0.005 < g["s2"].mean() < 0.3
+
+
+# ---- known answers derived from the reference source ----------------------------
+
+def _drive(o, I, n=9):
+  u = np.zeros(1, F32)
+  out = []
+  for _ in range(n):
+    u, s = o.multi_step_lif(u, F32([I]))
+    out.append((float(u[0]), int(s[0])))
+  return out
+
+
+def test_lif_constant_drive_known_answers(oracle):
+  """multi_step_LIF(tau=2, v_th=1, v_reset=0) from u = 0, hand-evaluated from
+  spiking_learning.py:410-414."""
+  assert [u for u, s in _drive(oracle, 1.0, 4)] == [0.5, 0.75, 0.875, 0.9375]
+  # exact arithmetic never reaches 1; float32 does: u = 1 - 2^-24 after 24 steps,
+  # and u + 2^-25 ties to even = 1.0 -> the first spike is at step 25
+  assert [s for _, s in _drive(oracle, 1.0, 26)] == [0] * 24 + [1, 0]
+  assert _drive(oracle, 1.5, 4) == [(0.75, 0), (0.0, 1), (0.75, 0), (0.0, 1)]
+  assert all(s == 1 for _, s in _drive(oracle, 2.0, 5))             # threshold is >=
+  assert [s for _, s in _drive(oracle, 1.2, 9)] == [0, 0, 1] * 3    # period 3
+
+
+def test_round_is_half_to_even(oracle):
+  np.testing.assert_array_equal(oracle.round_half_even([0.5, 1.5, 2.5, -0.5, -1.5, 3.5]),
+                                F32([0, 2, 2, -0, -2, 4]))
+
+
+@pytest.mark.parametrize("bits,lim,levels", [(2, 1, 3), (3, 3, 7), (4, 7, 15), (8, 127, 255)])
+def test_duq_code_range_and_levels(oracle, bits, lim, levels):
+  w = np.linspace(-2, 2, 20001, dtype=F32)
+  q = oracle.duq_codes(w, 1.0, bits)
+  assert q.min() == -lim and q.max() == lim
+  assert len(np.unique(q)) == levels
+  fq = oracle.duq_forward(w, 1.0, 0.5, bits)
+  assert len(np.unique(fq)) == levels
+  np.testing.assert_array_equal(oracle.duq_forward(w, -1.0, -1.0, bits), w)  # a == -1
+  np.testing.assert_array_equal(oracle.duq_forward(w, 1.0, 1.0, -1), w)      # bits == -1
+
+
+def test_prune_is_applied_after_quantisation(oracle):
+  w = F32([[0.3, -0.8], [0.05, 0.6]])
+  mask = F32([[1, 0], [1, 1]])
+  qw = oracle.QWeight(w, {"kind": "duq", "bits": 4, "a": 1.0, "c": 1.0}, mask)
+  np.testing.assert_array_equal(qw.w_fq, oracle.duq_forward(w, 1.0, 1.0, 4) * mask)
+  np.testing.assert_array_equal(qw.q, oracle.duq_codes(w, 1.0, 4) * mask)
+
+
+# ---- invariants asserted by the reference's own tests --------------------------------
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16])
+@pytest.mark.parametrize("quantizer", ["uniform_static", "parametric_d", "parametric_d_xmax"])
+def test_equality_native_dtypes(oracle, dtype, quantizer):
+  """quant_test.py:141-185: integer data within the code range passes through."""
+  rng = np.random.Generator(np.random.PCG64(8627169))
+  info = np.iinfo(dtype)
+  data = rng.integers(info.min, info.max, size=(60, 50)).astype(np.float64)
+  data[0, 0] = info.min
+  data = np.clip(data, info.min + 1, info.max).astype(F32)
+  bits = info.bits
+  if quantizer == "uniform_static":
+    xmax = oracle.uniform_static_init(data, bits)
+    dq = oracle.uniform_static_forward(data, xmax, bits)
+  elif quantizer == "parametric_d":
+    step = oracle.parametric_d_init(data, bits)
+    dq = oracle.parametric_d_forward(data * step, step, bits) / step
+  else:
+    d, xmax = oracle.parametric_d_xmax_init(data, bits)
+    dq = oracle.parametric_d_xmax_forward(data, d, xmax, xmax_max=info.max)
+  np.testing.assert_allclose(data, dq)
+
+
+@pytest.mark.parametrize("bits", list(range(2, 13)))
+def test_unique_values(oracle, bits):
+  """quant_test.py:187-250: a signed b-bit quantiser emits 2**b - 1 values."""
+  rng = np.random.Generator(np.random.PCG64(8627169))
+  scale = 23.0
+  data = (rng.uniform(-1, 1, size=(700, 300)) * scale).astype(F32)
+  data[0, 0] = scale
+  assert len(np.unique(oracle.uniform_static_forward(data, scale, bits))) == 2 ** bits - 1
+  step = scale / (2 ** (bits - 1) - 1)
+  assert len(np.unique(oracle.parametric_d_forward(data, step, bits))) == 2 ** bits - 1
+  assert len(np.unique(oracle.duq_forward(data, scale, scale, bits))) == 2 ** bits - 1
+
+
+def test_qdense_without_quant_is_plain_matmul(oracle):
+  """flax_qdense_test.py:153-250: empty config == nn.Dense."""
+  rng = np.random.Generator(np.random.PCG64(3))
+  for (m, k, n) in ((512, 100, 20), (1024, 1, 1), (256, 1, 200)):
+    x = rng.standard_normal((m, k)).astype(F32)
+    w = rng.standard_normal((k, n)).astype(F32)
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    for mode in ("fseq", "float"):
+      y = oracle.quant_dense(x, oracle.QWeight(w), mode)
+      np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)
+    xi = rng.integers(-4, 5, size=(m, k)).astype(F32)
+    wi = rng.integers(-4, 5, size=(k, n)).astype(F32)
+    np.testing.assert_array_equal(oracle.quant_dense(xi, oracle.QWeight(wi), "fseq"), xi @ wi)
+
+
+@pytest.mark.parametrize("geom", cases.REF_CONV_GEOMS, ids=[g[0] for g in cases.REF_CONV_GEOMS])
+def test_qconv_without_quant_is_standard_conv(oracle, geom):
+  """flax_qconv_test.py:148-285, tolerance 0.0: checked against torch's CPU
+  conv2d on integer-valued data (exact in any summation order), including the
+  output sizes the reference's table lists."""
+  name, H, W, ks, st, pad, OH, OW = geom
+  c = cases.conv_geom_case(name)
+  e = cases.conv_geom_expected(oracle, c)
+  assert e["y1"].shape == (2, OH, OW, 10)
+  assert e["y2"].shape[1:3] == cases.REF_CONV_TWICE[name]
+
+  def torch_conv(x, k):
+    pads = oracle.resolve_padding(x.shape[1:3], ks, st, pad)
+    xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2).double()
+    xt = torch.nn.functional.pad(xt, (pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    kt = torch.from_numpy(np.ascontiguousarray(k)).permute(3, 2, 0, 1).double()
+    return torch.nn.functional.conv2d(xt, kt, stride=st).permute(0, 2, 3, 1).numpy()
+
+  y1 = torch_conv(c["x"], c["k1"])
+  np.testing.assert_array_equal(e["y1"], y1.astype(F32))
+  np.testing.assert_array_equal(e["y2"], torch_conv(y1.astype(F32), c["k2"]).astype(F32))
+
+
+def test_conv_dilation_groups_1d_against_torch(oracle):
+  rng = np.random.Generator(np.random.PCG64(5))
+  x = rng.integers(-3, 4, size=(2, 9, 11, 4)).astype(F32)
+  k = rng.integers(-2, 3, size=(3, 2, 2, 6)).astype(F32)     # groups = 2
+  y = oracle.quant_conv(x, oracle.QWeight(k), (2, 1), ((1, 2), (0, 1)), (1, 2), (2, 1), 2,
+                        mode="fseq")
+  xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()
+  xd = torch.zeros(2, 4, 9, 21, dtype=torch.double)
+  xd[:, :, :, ::2] = xt                                      # input dilation (1, 2)
+  xd = torch.nn.functional.pad(xd, (0, 1, 1, 2))
+  kt = torch.from_numpy(k).permute(3, 2, 0, 1).double()
+  ref = torch.nn.functional.conv2d(xd, kt, stride=(2, 1), dilation=(2, 1), groups=2)
+  np.testing.assert_array_equal(y, ref.permute(0, 2, 3, 1).numpy().astype(F32))
+  # 1-D with SAME and k = 4 -> pad (1, 2) (the TCJA convolutions, models.py:52-59)
+  x1 = rng.integers(-3, 4, size=(3, 10, 5)).astype(F32)
+  k1 = rng.integers(-2, 3, size=(4, 5, 7)).astype(F32)
+  assert oracle.resolve_padding((10,), (4,), (1,), "SAME") == ((1, 2),)
+  y1 = oracle.quant_conv(x1, oracle.QWeight(k1), None, "SAME", mode="fseq")
+  ref1 = torch.nn.functional.conv1d(
+      torch.nn.functional.pad(torch.from_numpy(x1).permute(0, 2, 1).double(), (1, 2)),
+      torch.from_numpy(k1).permute(2, 1, 0).double())
+  np.testing.assert_array_equal(y1, ref1.permute(0, 2, 1).numpy().astype(F32))
+
+
+# ---- internal consistency of the three contraction modes ---------------------------
+
+def test_int_and_float_modes_agree_away_from_ties(oracle):
+  c = cases.dense_block_case(T=8, B=16, K=512, N=128)
+  qw = cases.qweight_of(oracle, c["leaf"], c["bits"])
+  yi = oracle.quant_dense(c["x"], qw, "int")
+  for mode in ("fseq", "float"):
+    yf = oracle.quant_dense(c["x"].astype(F32), qw, mode)
+    np.testing.assert_allclose(yi, yf, rtol=1e-5, atol=2e-6)
+  _, si = oracle.dense_block(c["x"], qw, None, "int")
+  _, sf = oracle.dense_block(c["x"].astype(F32), qw, None, "float")
+  assert (si != sf).mean() < 1e-3
+
+
+def test_three_instruction_division_is_exact(oracle):
+  """The HIP epilogues divide by L = n_lv - 1 with mul + 2 fma; exhaustive."""
+  for L in (1, 3, 7, 15, 31, 63, 127):
+    assert oracle.clib().oracle_check_div(L, 1 << 22) == 0
+
+
+def test_vote_and_metrics(oracle):
+  s = np.zeros((4, 2, 20), F32)
+  s[:, 0, :10] = 1            # class 0 of sample 0 fires always
+  s[::2, 1, 10:] = 1          # class 1 of sample 1 fires every other step
+  lg = oracle.vote(s)
+  np.testing.assert_array_equal(lg, F32([[1, 0], [0, 0.5]]))
+  m = oracle.compute_metrics(lg, np.array([0, 1]))
+  assert m["accuracy"].tolist() == [True, True]
+  assert abs(float(m["loss"]) - np.mean([0, 0, 0, 0.25])) < 1e-7
+
+
+def test_masks(oracle):
+  rng = np.random.Generator(np.random.PCG64(9))
+  ks = [rng.standard_normal((3, 3, 4, 8)).astype(F32), rng.standard_normal((32, 10)).astype(F32)]
+  m = oracle.local_prune_mask(ks[0], 0.75)
+  assert m.sum() == ks[0].size - int(ks[0].size * 0.75)
+  assert np.abs(ks[0][m == 0]).max() <= np.abs(ks[0][m == 1]).min()
+  gm = oracle.global_prune_masks(ks, 0.5)
+  tot = sum(k.size for k in ks)
+  assert sum(x.sum() for x in gm) == tot - int(tot * 0.5)

@@ -1,0 +1,569 @@
+"""GPU suite: the HIP path (through the C ABI) against the oracle on the same
+seeded inputs and against the committed golden fixtures.  Bit-exact for spike
+rasters, integer accumulators and -- because the float paths are defined as
+fmaf chains in a fixed order -- float membrane potentials too; where a looser
+bound applies (any-order float reference) the tolerance is written in the test.
+"""
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from tests.helpers import packbits_lastaxis, qweight_of
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "GPU tests need a GPU"
+  from snnquantprune_amd import _lib
+  _lib.lib()                      # fails loudly if the HIP extension is missing
+  return torch.device("cuda:0")
+
+
+def _t(a, dev):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _np(x):
+  from snnquantprune_amd import ops
+  if isinstance(x, ops.PackedSpikes):
+    return x.bits.cpu().numpy().view(np.uint32)
+  return x.cpu().numpy()
+
+
+def _golden(golden_dir, name):
+  with np.load(os.path.join(golden_dir, name + ".npz")) as g:
+    return {k: g[k] for k in g.files}
+
+
+def _weight(leaf, bits, dev, quantized=True, transposed=False):
+  """Product-side packing of a reference-style leaf."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import packing
+  from snnquantprune_amd.quant import QuantDesc
+  a, c = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
+  desc = None
+  if quantized and a != -1.0:
+    desc = QuantDesc(L.Q_DUQ, bits, a, c, float(2 ** (bits - 1) - 1), c)
+  mask = leaf.get("prune_0", {}).get("mask")
+  pk = packing.PackedKernel(_t(leaf["kernel"], dev), desc,
+                            None if mask is None else _t(mask, dev))
+  if desc is None:
+    return pk.float_weight()
+  if transposed:
+    n = leaf["kernel"].shape[-1]
+    return pk.int_weight_transposed((n + 31) // 32 * 32)
+  return pk.int_weight()
+
+
+def _mslif():
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  return ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, 1.0, 0.0)
+
+
+def _bn(bn, dev):
+  from snnquantprune_amd import ops
+  mul = (F32(1) / np.sqrt(bn["var"] + F32(1e-5))) * bn["scale"]
+  return ops.BnCoeffs(_t(bn["mean"], dev), _t(mul.astype(F32), dev), _t(bn["bias"], dev))
+
+
+# ---------------------------------------------------------------------------
+# weight transforms
+# ---------------------------------------------------------------------------
+
+def test_quantizers_bit_exact(dev, oracle, golden_dir):
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.quant_case()
+  g = _golden(golden_dir, "quant")
+  live = cases.quant_expected(oracle)
+  w, mask = _t(c["w"], dev), _t(c["mask"], dev)
+  for bits in (2, 3, 4, 8):
+    for a, cc in ((1.0, 1.0), (0.73, 0.41)):
+      key = "duq_b%d_a%g" % (bits, a)
+      fq, codes, flags = ops.quantize(L.Q_DUQ, w, None, bits, a, cc, True, True)
+      assert int(flags.item()) == 0
+      for ref in (g, live):
+        np.testing.assert_array_equal(_np(fq), ref[key + "_fq"])
+        np.testing.assert_array_equal(_np(codes), ref[key + "_codes"])
+      fqm, codes_m, _ = ops.quantize(L.Q_DUQ, w, mask, bits, a, cc, True, True)
+      np.testing.assert_array_equal(_np(fqm), g[key + "_fq_masked"])
+      np.testing.assert_array_equal(_np(codes_m), g[key + "_codes"] * c["mask"].astype(np.int8))
+    fq, _, _ = ops.quantize(L.Q_UNIFORM_STATIC, w, None, bits, 0.9)
+    np.testing.assert_array_equal(_np(fq), g["us_b%d" % bits])
+    fq, _, _ = ops.quantize(L.Q_PARAMETRIC_D, w, None, bits, 0.05)
+    np.testing.assert_array_equal(_np(fq), g["pd_b%d" % bits])
+    fq, _, _ = ops.quantize(L.Q_PARAMETRIC_D_XMAX, w, None, bits, 2 ** -4, 0.8)
+    np.testing.assert_array_equal(_np(fq), g["pdx_b%d" % bits])
+  # flags: non-binary mask, code overflow (parametric_d with a tiny step)
+  _, _, fl = ops.quantize(L.Q_DUQ, w, mask * 0.5, 4, 1.0, 1.0, False, True)
+  assert int(fl.item()) & L.FLAG_MASK_NOT_BINARY
+  _, _, fl = ops.quantize(L.Q_PARAMETRIC_D, w, None, 12, 1e-3, 0.0, False, True)
+  assert int(fl.item()) & L.FLAG_CODE_OVERFLOW
+
+
+def test_quantizer_modules_match_reference_tests(dev, oracle):
+  """quant_test.py invariants through the module surface (init + apply)."""
+  from snnquantprune_amd import quant
+  rng = np.random.Generator(np.random.PCG64(8627169))
+  data8 = np.clip(rng.integers(-128, 127, size=(60, 50)), -127, 127).astype(F32)
+  for q in (quant.uniform_static, quant.parametric_d):
+    m = q(8)
+    x = _t(data8, dev)
+    variables = m.init(0, x)
+    scale = 1.0
+    if "step_size" in variables["quant_params"]:
+      scale = float(variables["quant_params"]["step_size"])
+    out = m.apply(variables, x * scale)
+    np.testing.assert_allclose(_np(out) / scale, data8, rtol=1e-6)
+  m = quant.parametric_d_xmax(8, xmax_max=127)
+  variables = m.init(0, _t(data8, dev))
+  np.testing.assert_allclose(_np(m.apply(variables, _t(data8, dev))), data8)
+  # unique values
+  data = (rng.uniform(-1, 1, size=(300, 200)) * 23).astype(F32)
+  data[0, 0] = 23
+  for bits in (2, 3, 5, 8, 11):
+    m = quant.uniform_static(bits)
+    v = m.init(0, _t(data, dev))
+    assert len(np.unique(_np(m.apply(v, _t(data, dev))))) == 2 ** bits - 1
+    d = quant.DuQ(bits)
+    v = d.init(0, _t(data, dev))
+    np.testing.assert_array_equal(_np(d.apply(v, _t(data, dev))), data)   # a == -1
+    v["params"]["a"] = torch.full((1,), 23.0, device=dev)
+    v["params"]["c"] = torch.full((1,), 23.0, device=dev)
+    out = _np(d.apply(v, _t(data, dev)))
+    assert len(np.unique(out)) == 2 ** bits - 1
+    np.testing.assert_array_equal(out, oracle.duq_forward(data, 23.0, 23.0, bits))
+  with pytest.raises(AssertionError):
+    quant.uniform_static(1).init(0, _t(data, dev))
+
+
+# ---------------------------------------------------------------------------
+# formats and element-wise pieces
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("C", [1, 31, 32, 33, 64, 110, 130])
+def test_pack_unpack_roundtrip(dev, C):
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(C))
+  x = (rng.random((5, 7, C)) < 0.3)
+  for arr in (x.astype(F32), x.astype(np.uint8)):
+    p = ops.pack_bits(_t(arr, dev))
+    assert p.shape == (5, 7, C)
+    np.testing.assert_array_equal(_np(p), packbits_lastaxis(x))
+    np.testing.assert_array_equal(_np(p.to_dense()), x.astype(F32))
+  e = ops.pack_bits(torch.zeros((0, C), device=dev))
+  assert e.bits.shape[0] == 0
+
+
+def test_inspect_and_u8(dev):
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  x = torch.tensor([0., 1., 3., 127.], device=dev)
+  assert ops.inspect_f32(x) == L.FLAG_GT_ONE
+  assert ops.inspect_f32(torch.tensor([0., 1.], device=dev)) == 0
+  assert ops.inspect_f32(torch.tensor([0.5], device=dev)) & L.FLAG_NOT_INTEGER
+  assert ops.inspect_f32(torch.tensor([-1.0], device=dev)) & L.FLAG_NOT_INTEGER
+  assert ops.inspect_f32(torch.tensor([200.0], device=dev)) & L.FLAG_GT_127
+  np.testing.assert_array_equal(_np(ops.f32_to_u8(x)), [0, 1, 3, 127])
+
+
+def test_neurons_bit_exact(dev, oracle, golden_dir):
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.neuron_case()
+  g = _golden(golden_dir, "neurons")
+  x, u0 = _t(c["x"], dev), _t(c["u0"], dev)
+  dec = _t(oracle.sigmoid_f32(c["tau_vec"]), dev)
+  k_plif = float(oracle.sigmoid_f32(c["tau_param"]))
+  kinds = {
+      "mslif_tau2": ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, 1.0, 0.0),
+      "mslif_tau3_vr": ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, 0.8, 0.1),
+      "plif": ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, k_plif, 1.0, 0.0),
+      "lif": ops.Neuron(L.NEURON_LIF, 0.0, 1.0, 0.0, decay=dec),
+  }
+  for name, nrn in kinds.items():
+    u, s = ops.lif_forward(x, nrn, u0=u0)
+    np.testing.assert_array_equal(_np(s).astype(np.uint8), g[name + "_s"], err_msg=name)
+    np.testing.assert_array_equal(_np(u), g[name + "_u"], err_msg=name)
+    _, sp = ops.lif_forward(x, nrn, u0=u0, packed_out=True, want_u=False)
+    np.testing.assert_array_equal(_np(sp), packbits_lastaxis(g[name + "_s"]))
+    assert 0.02 < g[name + "_s"].mean() < 0.6
+
+
+def test_neuron_modules_single_step(dev, oracle):
+  from snnquantprune_amd.spiking_learning import LIF, atan, multi_step_LIF, parametric_leaky_IF
+  c = cases.neuron_case()
+  x0, u0 = c["x"][0], c["u0"]
+  m = multi_step_LIF(tau=2.0, spike_fn=atan)
+  (u, s) = m.apply({}, _t(u0, dev), _t(x0, dev))
+  eu, es = oracle.multi_step_lif(u0, x0, 2.0)
+  np.testing.assert_array_equal(_np(u), eu)
+  np.testing.assert_array_equal(_np(s), es)
+  p = parametric_leaky_IF(init_tau=3.0, spike_fn=atan)
+  v = p.init(0, _t(u0, dev), _t(x0, dev))
+  assert v["params"]["tau"].shape == (1,)
+  (u, s) = p.apply(v, _t(u0, dev), _t(x0, dev))
+  eu, es = oracle.parametric_leaky_if(u0, x0, _np(v["params"]["tau"]))
+  np.testing.assert_array_equal(_np(u), eu)
+  l = LIF(init_tau=0.5, spike_fn=atan)
+  v = l.init(0, _t(u0, dev), _t(x0, dev))
+  assert v["params"]["tau"].shape == (x0.shape[-1],)
+  (u, s) = l.apply(v, _t(u0, dev), _t(x0, dev))
+  eu, es = oracle.lif(u0, x0, _np(v["params"]["tau"]))
+  np.testing.assert_array_equal(_np(u), eu)
+  np.testing.assert_array_equal(_np(s), es)
+
+
+def test_bn_pool_vote(dev, oracle):
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(4))
+  x = rng.standard_normal((3, 2, 6, 8, 40)).astype(F32)
+  bn = dict(mean=rng.standard_normal(40).astype(F32), var=(rng.random(40) + 0.5).astype(F32),
+            scale=rng.standard_normal(40).astype(F32), bias=rng.standard_normal(40).astype(F32))
+  y = ops.batchnorm_forward(_t(x, dev), _bn(bn, dev))
+  np.testing.assert_array_equal(_np(y), oracle.batchnorm_eval(x, **bn))
+  np.testing.assert_array_equal(_np(ops.maxpool2x2(_t(x, dev))), oracle.max_pool_2x2(x))
+  s = (rng.random((3, 2, 6, 8, 40)) < 0.2).astype(F32)
+  ps = ops.pack_bits(_t(s, dev))
+  np.testing.assert_array_equal(_np(ops.maxpool2x2(ps)),
+                                packbits_lastaxis(oracle.max_pool_2x2(s)))
+  sp = (rng.random((9, 5, 110)) < 0.3).astype(F32)
+  np.testing.assert_array_equal(_np(ops.vote(_t(sp, dev))), oracle.vote(sp))
+  np.testing.assert_array_equal(_np(ops.vote(ops.pack_bits(_t(sp, dev)))), oracle.vote(sp))
+  with pytest.raises(ValueError):
+    ops.vote(_t(sp, dev), group=7)
+
+
+# ---------------------------------------------------------------------------
+# dense blocks
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("counts", [False, True])
+def test_dense_block_int_path(dev, oracle, golden_dir, counts):
+  """Ragged K = 200, N = 70; integer accumulators, rasters and u bit-exact."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.dense_block_case(counts=counts)
+  g = _golden(golden_dir, "dense_block_counts" if counts else "dense_block")
+  live = cases.dense_block_expected(oracle, c)
+  T, B, K = c["x"].shape
+  N = c["leaf"]["kernel"].shape[1]
+  w = _weight(c["leaf"], c["bits"], dev)
+  x = _t(c["x"], dev)
+  inputs = [x] if counts else [x, ops.pack_bits(x)]
+  for xin in inputs:
+    x4 = xin.reshape(T * B, 1, 1, K) if isinstance(xin, torch.Tensor) \
+        else xin.reshape_leading(T * B, 1, 1)
+    y, acc = ops.conv_forward(x4, ops.ConvGeom(1, 1, K, N, 1, 1), w, want_acc=True)
+    np.testing.assert_array_equal(_np(acc).reshape(T, B, N), g["acc"])
+    qw = qweight_of(oracle, c["leaf"], c["bits"])
+    np.testing.assert_array_equal(_np(y).reshape(T, B, N), qw.dequant_acc(g["acc"]))
+    for packed in (False, True):
+      u, s = ops.dense_lif_forward(xin, w, K, N, _mslif(), u0=_t(c["u0"], dev),
+                                   packed_out=packed, impl=L.IMPL_GENERIC)
+      for ref in (g, live):
+        np.testing.assert_array_equal(_np(u), ref["u"])
+        exp_s = packbits_lastaxis(ref["s"]) if packed else ref["s"].astype(F32)
+        np.testing.assert_array_equal(_np(s), exp_s)
+  assert 0.02 < g["s"].mean() < 0.4
+  # batch-major input read by strides gives the same result
+  xb = _t(np.ascontiguousarray(np.swapaxes(c["x"], 0, 1)), dev)
+  u, s = ops.dense_lif_forward(xb, w, K, N, _mslif(), u0=_t(c["u0"], dev),
+                               impl=L.IMPL_GENERIC, time_major=False)
+  np.testing.assert_array_equal(_np(s), g["s"].astype(F32))
+  # int8 codes with float32 input are refused (the caller passes the fake-quant kernel)
+  with pytest.raises(L.SnnqpError) as ei:
+    ops.dense_lif_forward(x.to(torch.float32), w, K, N, _mslif(), impl=L.IMPL_GENERIC)
+  assert ei.value.code == L.EUNSUPPORTED
+
+
+def test_dense_block_fseq_path(dev, oracle, golden_dir):
+  """Unquantised float32 weights, real-valued input: k-ascending fmaf chain,
+  bit-exact vs the oracle's fseq mode and within 1e-5 relative of float64."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.dense_fseq_case()
+  g = _golden(golden_dir, "dense_fseq")
+  T, B, K = c["x"].shape
+  N = c["leaf"]["kernel"].shape[1]
+  w = _weight(c["leaf"], 8, dev, quantized=False)
+  assert w.wtype == L.W_F32
+  y = ops.conv_forward(_t(c["x"], dev).reshape(T * B, 1, 1, K), ops.ConvGeom(1, 1, K, N, 1, 1), w)
+  np.testing.assert_array_equal(_np(y).reshape(T, B, N), g["y"])
+  ref64 = c["x"].astype(np.float64) @ c["leaf"]["kernel"].astype(np.float64)
+  np.testing.assert_allclose(_np(y).reshape(T, B, N), ref64, rtol=1e-5, atol=1e-6)
+  u, s = ops.dense_lif_forward(_t(c["x"], dev), w, K, N, _mslif())
+  np.testing.assert_array_equal(_np(u), g["u"])
+  np.testing.assert_array_equal(_np(s), g["s"].astype(F32))
+
+
+def test_quant_dense_module_matches_plain_matmul(dev, oracle):
+  """flax_qdense_test.py: QuantDense with an empty config == x @ W (+ bias)."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd.flax_qdense import QuantDense
+  rng = np.random.Generator(np.random.PCG64(12))
+  cfg = nn.ConfigDict({"prune_percentage": -1.0})
+  for (m, k, n) in ((512, 100, 20), (64, 1, 1), (256, 1, 200)):
+    x = rng.standard_normal((m, k)).astype(F32)
+    layer = QuantDense(n, config=cfg)
+    v = layer.init(3, _t(x, dev))
+    assert sorted(v["params"]) == ["bias", "kernel"]
+    v["params"]["bias"] = _t(rng.standard_normal(n).astype(F32), dev)
+    y = _np(layer.apply(v, _t(x, dev)))
+    wk, b = _np(v["params"]["kernel"]), _np(v["params"]["bias"])
+    np.testing.assert_array_equal(y, oracle.fseq_matmul(x, wk) + b)
+    np.testing.assert_allclose(y, x.astype(np.float64) @ wk + b, rtol=1e-5, atol=1e-5)
+  with pytest.raises(AttributeError):        # stale configs fail as in the reference
+    QuantDense(4, config=nn.ConfigDict({})).init(0, _t(x, dev))
+
+
+# ---------------------------------------------------------------------------
+# convolutions
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("geom", cases.REF_CONV_GEOMS, ids=[g[0] for g in cases.REF_CONV_GEOMS])
+def test_quant_conv_reference_geometries(dev, oracle, golden_dir, geom):
+  """flax_qconv_test.py:148-285 through the QuantConv module, tolerance 0.0."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  name, H, W, ks, st, pad, OH, OW = geom
+  c = cases.conv_geom_case(name)
+  g = _golden(golden_dir, "conv_geom_" + name)
+  cfg = nn.ConfigDict({"prune_percentage": -1.0})
+  c1 = QuantConv(features=10, kernel_size=ks, strides=st, padding=pad, use_bias=False, config=cfg)
+  c2 = QuantConv(features=20, kernel_size=ks, strides=st, padding=pad, use_bias=False, config=cfg)
+  y1 = c1.apply({"params": {"kernel": _t(c["k1"], dev)}}, _t(c["x"], dev))
+  assert tuple(y1.shape) == (2, OH, OW, 10)
+  y2 = c2.apply({"params": {"kernel": _t(c["k2"], dev)}}, y1)
+  np.testing.assert_array_equal(_np(y1), g["y1"])
+  np.testing.assert_array_equal(_np(y2), g["y2"])
+  # single (batch-less) input, flax_qconv.py:109-112
+  ys = c1.apply({"params": {"kernel": _t(c["k1"], dev)}}, _t(c["x"][0], dev))
+  np.testing.assert_array_equal(_np(ys), g["y1"][0])
+
+
+def test_conv_generic_dilation_groups_1d_and_int_paths(dev, oracle):
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import ops
+  from snnquantprune_amd.flax_qconv import QuantConv
+  rng = np.random.Generator(np.random.PCG64(5))
+  cfg = nn.ConfigDict({"prune_percentage": -1.0})
+  x = rng.standard_normal((2, 9, 11, 4)).astype(F32)
+  k = rng.standard_normal((3, 2, 2, 6)).astype(F32)
+  conv = QuantConv(features=6, kernel_size=(3, 2), strides=(2, 1), padding=((1, 2), (0, 1)),
+                   input_dilation=(1, 2), kernel_dilation=(2, 1), feature_group_count=2,
+                   use_bias=False, config=cfg)
+  y = conv.apply({"params": {"kernel": _t(k, dev)}}, _t(x, dev))
+  e = oracle.quant_conv(x, oracle.QWeight(k), (2, 1), ((1, 2), (0, 1)), (1, 2), (2, 1), 2, "fseq")
+  np.testing.assert_array_equal(_np(y), e)
+  with pytest.raises(AssertionError):          # flax_qconv.py:117
+    QuantConv(features=6, kernel_size=(3, 2), feature_group_count=3, config=cfg).init(
+        0, _t(x, dev))
+  # 1-D SAME k = 4 (the TCJA convolutions)
+  x1 = rng.standard_normal((3, 10, 5)).astype(F32)
+  k1 = rng.standard_normal((4, 5, 7)).astype(F32)
+  c1 = QuantConv(features=7, kernel_size=[4], padding="SAME", use_bias=False, config=cfg)
+  y1 = c1.apply({"params": {"kernel": _t(k1, dev)}}, _t(x1, dev))
+  np.testing.assert_array_equal(_np(y1), oracle.quant_conv(x1, oracle.QWeight(k1), None, "SAME",
+                                                            mode="fseq"))
+  # integer path of the direct-form kernel on a strided, padded, grouped conv
+  leaf = {"kernel": (rng.standard_normal((3, 3, 8, 24)) * 0.2).astype(F32),
+          "DuQ_0": {"a": F32([0.5]), "c": F32([0.45])},
+          "prune_0": {"mask": (rng.random((3, 3, 8, 24)) > 0.6).astype(F32)}}
+  xs = (rng.random((3, 13, 10, 16)) < 0.3).astype(np.uint8)
+  qw = qweight_of(oracle, leaf, 4)
+  w = _weight(leaf, 4, dev)
+  geom = ops.ConvGeom(13, 10, 16, 24, 3, 3, (2, 1), ((1, 1), (0, 2)), groups=2)
+  for xin in (_t(xs, dev), ops.pack_bits(_t(xs, dev))):
+    yy, acc = ops.conv_forward(xin, geom, w, want_acc=True)
+    eacc = oracle.quant_conv(xs, qw, (2, 1), ((1, 1), (0, 2)), feature_group_count=2,
+                             mode="int", return_acc=True)
+    np.testing.assert_array_equal(_np(acc), eacc)
+    np.testing.assert_array_equal(_np(yy), qw.dequant_acc(eacc))
+
+
+@pytest.mark.parametrize("which", ["conv_block_c128", "conv_block_c2"])
+def test_conv_block_mfma_and_generic(dev, oracle, golden_dir, which):
+  """The fused conv + BN + LIF (+ pool) block: MFMA kernel and direct-form
+  kernel both bit-exact vs the oracle (rasters, pooled rasters, final u)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case() if which.endswith("c128") else \
+      cases.conv_block_case(hw=16, cin=2, seed=961, gain=4.0)
+  g = _golden(golden_dir, which)
+  live = cases.conv_block_expected(oracle, c)
+  T, B, H, W, Cin = c["x"].shape
+  Cout = c["leaf"]["kernel"].shape[-1]
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  bn = _bn(c["bn"], dev)
+  geom = ops.ConvGeom(H, W, Cin, Cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  x = _t(c["x"], dev)
+  xin = x if Cin == 2 else ops.pack_bits(x)
+  for impl in (L.IMPL_GENERIC, L.IMPL_MFMA):
+    u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=bn, packed_out=True, pool=1, impl=impl)
+    for ref in (g, live):
+      np.testing.assert_array_equal(_np(s), ref["s_bits"], err_msg="impl %d" % impl)
+      np.testing.assert_array_equal(_np(u), ref["u"], err_msg="impl %d" % impl)
+  _, sp = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=bn, packed_out=True, pool=2,
+                               impl=L.IMPL_MFMA, want_u=False)
+  np.testing.assert_array_equal(_np(sp), g["pooled_bits"])
+  # continuing from a non-zero carry: run T in two halves
+  u1, s1 = ops.conv_lif_forward(xin[:2], geom, w, _mslif(), bn=bn, packed_out=True,
+                                impl=L.IMPL_MFMA)
+  u2, s2 = ops.conv_lif_forward(xin[2:], geom, w, _mslif(), bn=bn, u0=u1, packed_out=True,
+                                impl=L.IMPL_MFMA)
+  np.testing.assert_array_equal(np.concatenate([_np(s1), _np(s2)]), g["s_bits"])
+  np.testing.assert_array_equal(_np(u2), g["u"])
+  # batch-major input (the model's [B, T, ...] layout) read by strides
+  xb = _t(np.ascontiguousarray(np.swapaxes(c["x"], 0, 1)), dev)
+  xbin = xb if Cin == 2 else ops.pack_bits(xb)
+  _, sb = ops.conv_lif_forward(xbin, geom, w, _mslif(), bn=bn, packed_out=True, pool=2,
+                               impl=L.IMPL_MFMA, want_u=False, time_major=False)
+  np.testing.assert_array_equal(_np(sb), g["pooled_bits"])
+  # other neuron kinds take the general epilogue
+  nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, 0.8, 0.1)
+  ua, sa = ops.conv_lif_forward(xin, geom, w, nrn, bn=bn, packed_out=True, impl=L.IMPL_MFMA)
+  ub, sb = ops.conv_lif_forward(xin, geom, w, nrn, bn=bn, packed_out=True, impl=L.IMPL_GENERIC)
+  np.testing.assert_array_equal(_np(sa), _np(sb))
+  np.testing.assert_array_equal(_np(ua), _np(ub))
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  eu, es = oracle.conv_block(c["x"], qw, c["bn"],
+                             {"tau": 3.0, "v_threshold": 0.8, "v_reset": 0.1}, "int")
+  np.testing.assert_array_equal(_np(sa), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(ua), eu)
+
+
+def test_mfma_kernel_refuses_unsupported_shapes(dev):
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(hw=8)
+  w = _weight(c["leaf"], 4, dev, transposed=True)
+  x = ops.pack_bits(_t(c["x"], dev))
+  geom = ops.ConvGeom(8, 8, 128, 128, 3, 3, (2, 2), ((1, 1), (1, 1)))
+  with pytest.raises(L.SnnqpError) as ei:
+    ops.conv_lif_forward(x, geom, w, _mslif(), packed_out=True, impl=L.IMPL_MFMA)
+  assert ei.value.code == L.EUNSUPPORTED and "stride" in str(ei.value)
+
+
+# ---------------------------------------------------------------------------
+# whole models through the Module.init / Module.apply surface
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("quantized", [False, True], ids=["c1_fp32", "c2_8bit_50pct"])
+def test_dense_snn_model(dev, oracle, golden_dir, quantized):
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.dense_net_case(quantized)
+  g = _golden(golden_dir, "dense_net_c2" if quantized else "dense_net_c1")
+  cfg = syn.make_config(bits=8, prune_percentage=0.5 if quantized else -1.0,
+                        hidden=96)
+  model = models.DenseSNN(num_classes=11, config=cfg)
+  x = _t(c["x"], dev)
+  init_vars = model.init({"params": 0, "dropout": 1}, x, rng=None, trgt=None, train=False)
+  want = {"QuantDense_0": ["DuQ_0", "kernel"] + (["prune_0"] if quantized else []),
+          "QuantDense_1": ["DuQ_0", "kernel"] + (["prune_0"] if quantized else [])}
+  assert {k: sorted(v) for k, v in init_vars["params"].items()} == want
+  assert float(init_vars["params"]["QuantDense_0"]["DuQ_0"]["a"]) == -1.0
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  for inp in (x, x.to(torch.float32)):       # typed uint8 and the reference's float32
+    (logits, _), mut = model.apply(variables, inp, trgt=None, train=False, rng=None,
+                                   mutable=["intermediates"])
+    np.testing.assert_array_equal(_np(logits), g["logits"])
+    s2 = mut["intermediates"]["dense2_out"][0]
+    s2 = s2.to_dense() if hasattr(s2, "to_dense") else s2
+    np.testing.assert_array_equal(_np(s2).astype(np.uint8), g["s2"])
+  with pytest.raises(NotImplementedError):
+    model.apply(variables, x, trgt=None, train=True, rng=None)
+
+
+def test_conv_dense_snn_model_tiny(dev, oracle, golden_dir):
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.conv_net_case()
+  g = _golden(golden_dir, "conv_net_c3_tiny")
+  live = cases.conv_net_expected(oracle, c)
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  model = models.ConvDenseSNN(num_classes=11, config=cfg)
+  x = _t(c["x"], dev)
+  iv = model.init({"params": 0}, x, rng=None, trgt=None, train=False)
+  assert sorted(iv["params"]) == ["BatchNorm_0", "BatchNorm_1", "BatchNorm_2", "QuantConv_0",
+                                  "QuantConv_1", "QuantConv_2", "QuantDense_0"]
+  assert sorted(iv["batch_stats"]) == ["BatchNorm_0", "BatchNorm_1", "BatchNorm_2"]
+  assert sorted(iv["params"]["QuantConv_1"]) == ["DuQ_0", "kernel", "prune_0"]
+  assert tuple(iv["params"]["QuantConv_1"]["kernel"].shape) == (3, 3, 128, 128)
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  for inp in (x, x.to(torch.float32)):
+    (logits, _), mut = model.apply(variables, inp, trgt=None, train=False, rng=None,
+                                   mutable=["intermediates", "batch_stats"])
+    for ref in (g, live):
+      np.testing.assert_array_equal(_np(logits), ref["logits"])
+      for i in range(3):
+        np.testing.assert_array_equal(_np(mut["intermediates"]["pool%d" % i][0]),
+                                      ref["pool%d_bits" % i])
+      np.testing.assert_array_equal(
+          _np(mut["intermediates"]["dense_out"][0].to_dense()).astype(np.uint8), ref["dense_s"])
+
+
+def test_conv_dense_snn_with_event_counts(dev, oracle):
+  """Integer event counts (input_pipeline.py:195-218) into conv0."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.conv_net_case(counts=True)
+  assert c["x"].max() > 1
+  e = cases.conv_net_expected(oracle, c)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  (logits, _) = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None,
+                            train=False, rng=None)
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+
+
+def test_full_size_c3_layers_against_oracle(dev, oracle):
+  """BASELINE config 3 geometry (128x128x2 input, 128 channels, 32768 -> 110
+  read-out, 4-bit / 90 % pruned, T = 20) at B = 1: every pooled raster and the
+  logits bit-exact; plus the size-independent property that samples are
+  independent (a batch equals its samples run one by one)."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.conv_net_case(T=20, B=1, hw=128, random_bn=False, gains=(4.0, 5.0, 4.0, 4.0))
+  e = cases.conv_net_expected(oracle, c)
+  assert np.all(e["rates"] > 0.02) and np.all(e["rates"] < 0.5), e["rates"]
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  (logits, _), mut = model.apply(variables, _t(c["x"], dev), trgt=None, train=False, rng=None,
+                                 mutable=["intermediates"])
+  for i in range(3):
+    np.testing.assert_array_equal(_np(mut["intermediates"]["pool%d" % i][0]),
+                                  e["pool%d_bits" % i])
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+  xb = syn.poisson_spikes((3, 20, 128, 128, 2), 0.1, seed=77)
+  (lb, _) = model.apply(variables, _t(xb, dev), trgt=None, train=False, rng=None)
+  for i in range(3):
+    (li, _) = model.apply(variables, _t(xb[i:i + 1], dev), trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(lb)[i:i + 1], _np(li))
+
+
+def test_eval_step_metrics(dev, oracle):
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn, train_utils
+  c = cases.dense_net_case(True)
+  cfg = syn.make_config(bits=8, prune_percentage=0.5, hidden=96)
+  model = train_utils.create_model(model_cls=models.DenseSNN, num_classes=11, config=cfg)
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  state = train_utils.EvalState(model.apply, {"params": variables["params"]},
+                                variables["batch_stats"])
+  labels = np.array([3, 1, 0, 7])
+  m = train_utils.eval_step(state, {"dvs_matrix": _t(c["x"], dev), "label": _t(labels, dev)},
+                            None, 0.0, partial(train_utils.mse_loss, T=1))
+  e = cases.dense_net_expected(oracle, c)
+  em = oracle.compute_metrics(e["logits"], labels)
+  assert abs(float(m["loss"]) - float(em["loss"])) < 1e-7
+  np.testing.assert_array_equal(_np(m["accuracy"]), em["accuracy"])
