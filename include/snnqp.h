@@ -132,9 +132,12 @@ int snnqp_quantize(int kind, const float *w, const float *mask, int64_t n,
                    int8_t *codes_out, int32_t *flags, snnqp_stream_t stream);
 
 /* Layout step of the pack: int8 codes [K][N] (dense kernel / flattened HWIO
- * convolution kernel, as the reference stores them) -> [Npad][K], zero rows for
- * n >= N: the k-contiguous order the MFMA B operand is loaded in. */
-int snnqp_transpose_codes(const int8_t *w, int64_t K, int32_t N, int32_t Npad,
+ * convolution kernel, as the reference stores them) -> MFMA B-operand tiles
+ * wt[Npad/32][K/32][64][16]: for column block nb and k-step ks, lane
+ * l = (n & 31) + 32 h holds bytes k = 32 ks + 16 h + j (j < 16) of column
+ * n = 32 nb + (l & 31); columns >= N are zero.  One contiguous 1 KiB read per
+ * wave and k-step.  K and Npad must be multiples of 32. */
+int snnqp_pack_codes_mfma(const int8_t *w, int64_t K, int32_t N, int32_t Npad,
                           int8_t *wt, snnqp_stream_t stream);
 
 /* ---- activation format helpers ------------------------------------------
@@ -174,8 +177,8 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  * impl  SNNQP_IMPL_GENERIC: direct form, any geometry / types.
  *       SNNQP_IMPL_MFMA: int8 MFMA implicit GEMM; needs W_I8, 3x3 / stride 1 /
  *       pad 1 / no dilation / groups 1, H % 8 == W % 8 == 0, Cout % 32 == 0 and
- *       (BITS input with Cin == 128 and `wt` = the codes transposed to
- *       [Cout][9 * Cin] by snnqp_transpose_codes, or U8 input with Cin == 2 and
+ *       (BITS input with Cin == 128 and `wt` = the codes tiled by
+ *       snnqp_pack_codes_mfma (K = 9 * Cin), or U8 input with Cin == 2 and
  *       values <= 127), s_type BITS.  SNNQP_IMPL_AUTO picks MFMA when it can. */
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
@@ -186,8 +189,9 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int impl, snnqp_stream_t stream);
 
 /* Same for QuantDense: x [T][B][K], weights [K][N] (GENERIC) .
- * IMPL_MFMA additionally needs `wt`: the int8 codes transposed to [Npad][K]
- * (Npad = N rounded up to 32, zero rows), BITS input, K % 64 == 0, s_type BITS. */
+ * IMPL_MFMA additionally needs `wt`: the int8 codes tiled by
+ * snnqp_pack_codes_mfma (Npad = N rounded up to 32), BITS input, K % 32 == 0,
+ * T <= 160, s_type BITS. */
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,

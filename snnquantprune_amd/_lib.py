@@ -53,7 +53,7 @@ _PROTOTYPES = {
                                      POINTER(c_int32)]),
     "snnqp_quantize": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_float,
                                c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "snnqp_transpose_codes": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p,
+    "snnqp_pack_codes_mfma": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                       c_void_p]),
     "snnqp_inspect_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_f32_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
@@ -100,6 +100,7 @@ def lib():
       raise ImportError(
           "HIP extension %s not found: build it with `python __graft_entry__.py` "
           "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    import torch  # noqa: F401  (first: libsnnqp must share torch's HIP runtime)
     handle = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOTYPES.items():
       fn = getattr(handle, name)

@@ -32,7 +32,7 @@ struct ConvMfmaArgs {
   int64_t xs_t, xs_b;
   int32_t T, B, H, W, Cin, Cout;
   const int8_t *w;   // HWIO int8 codes
-  const int8_t *wt;  // the same codes as [Cout][KH*KW*Cin]
+  const int8_t *wt;  // the same codes, MFMA-tiled (snnqp_pack_codes_mfma)
   Dequant dq;
   BnP bn;
   NeuronP nrn;
@@ -158,15 +158,17 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const int cout = wave_on ? cout_base + n : n;
   const int cw = cout_base >> 5;
 
-  // B operand: lane (n, h) holds W[tap][cin = 32 kk + 16 h + j][cout], j < 16,
-  // one 16-byte load from the [Cout][9][Cin] transposed codes.
+  // B operand: lane (n, h) holds W[tap][cin = 32 kk + 16 h + j][cout], j < 16:
+  // k-step tap * KK + kk of this wave's 32-column block in the MFMA-tiled codes.
   v4i bf[9][KK];
+  {
+    const v4i *wtile = (const v4i *)a.wt + ((int64_t)(cout_base >> 5) * (9 * KK)) * 64 + lane;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-      bf[tap][kk] = *(const v4i *)(a.wt + (int64_t)cout * (9 * CIN) + tap * CIN +
-                                   kk * 32 + 16 * h);
+      for (int kk = 0; kk < KK; ++kk)
+        bf[tap][kk] = wave_on ? wtile[(tap * KK + kk) * 64] : v4i{0, 0, 0, 0};
+  }
 
   float bmean = 0.f, bmul = 1.f, bbias = 0.f, dec = 0.f;
   if (a.bn.mean) { bmean = a.bn.mean[cout]; bmul = a.bn.mul[cout]; bbias = a.bn.bias[cout]; }
@@ -380,7 +382,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                      const snnqp_weight_t *w, const int8_t *wt,
                                      const snnqp_neuron_t *nrn, int s_type) {
   if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
-  if (in_type == SNNQP_BITS && !wt) return "transposed codes `wt` not given";
+  if (in_type == SNNQP_BITS && !wt) return "MFMA-tiled codes `wt` not given";
   if (g->KH != 3 || g->KW != 3) return "kernel is not 3x3";
   if (g->stride_h != 1 || g->stride_w != 1) return "stride is not 1";
   if (g->pad_h_lo != 1 || g->pad_h_hi != 1 || g->pad_w_lo != 1 || g->pad_w_hi != 1)
@@ -424,7 +426,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      hipStream_t st) {
   SNNQP_REQUIRE(x && w->w && s_out, SNNQP_EINVAL, "conv3x3 mfma: null pointer");
   SNNQP_REQUIRE(in_type != SNNQP_BITS || wt, SNNQP_EINVAL,
-                "conv3x3 mfma: bit input needs the transposed codes `wt`");
+                "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "conv3x3 mfma: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,

@@ -1,20 +1,237 @@
-// Fused SpikingBlock(QuantDense, neuron) on int8 MFMA -- placeholder until the
-// kernel lands: every request is served by the direct-form kernel.
+// Fused SpikingBlock(QuantDense, neuron) (spiking_learning.py:446-462 with
+// flax_qdense.py:87 as the connection) on int8 MFMA: bit-packed spikes x int8
+// codes -> int32 -> dequantise -> [BatchNorm] -> neuron over T -> packed spikes.
+//
+// The connection is stateless across t, so the contraction is one GEMM over
+// rows m = (sample, t); only the neuron is sequential:
+//  * a workgroup (4 waves) owns SB samples x all T steps (<= RT*32 rows) and a
+//    block of 128 output features (32 per wave);
+//  * K is walked in chunks of 256: the rows' spike bits are expanded to {0,1}
+//    bytes in LDS (row stride 256 B, 16-byte chunks XOR-swizzled by row so the
+//    ds_read_b128 of an A fragment is conflict-free); the B fragments stream
+//    from the MFMA-tiled codes (snnqp_pack_codes_mfma: one contiguous 1 KiB
+//    read per wave and k-step) straight into registers and are reused by the
+//    RT row tiles;
+//  * after the K loop the int32 tile goes through LDS once so that each thread
+//    gets the T currents of one (sample, feature) pair in order, runs the
+//    neuron with u in a register and ballots the spikes into 32-bit words.
 #include "kernels.h"
 
 namespace snnqp {
 
-const char *dense_mfma_unsupported(int, int32_t, int32_t, const snnqp_weight_t *,
-                                   const int8_t *, const snnqp_neuron_t *, int) {
-  return "dense MFMA kernel not built into this library";
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 256;          // k per chunk (bytes per LDS row)
+constexpr int KSC = BK / 32;     // MFMA k-steps per chunk
+
+struct DenseMfmaArgs {
+  const uint32_t *x;
+  int64_t xs_t, xs_b;            // word strides
+  int32_t T, B, K, N, KS, SB;    // KS = K / 32, SB samples per workgroup
+  const int8_t *wt;              // MFMA-tiled codes [Npad/32][KS][64][16]
+  Dequant dq;
+  BnP bn;
+  NeuronP nrn;
+  const float *u0;
+  float *u_out;
+  uint32_t *s_out;
+};
+
+__device__ __forceinline__ v4i expand16b(uint32_t b) {
+  v4i o;
+  o.x = (int)((((b >> 0) & 0xFu) * 0x00204081u) & 0x01010101u);
+  o.y = (int)((((b >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+  o.z = (int)((((b >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+  o.w = (int)((((b >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+  return o;
 }
 
-int run_dense_mfma(const void *, int64_t, int64_t, int32_t, int32_t, int32_t,
-                   int32_t, const snnqp_weight_t *, const int8_t *,
-                   const snnqp_bn_t *, const snnqp_neuron_t *, const float *,
-                   float *, uint32_t *, hipStream_t) {
-  set_error("dense MFMA kernel not built into this library");
-  return SNNQP_EUNSUPPORTED;
+__device__ __forceinline__ int a_addr(int row, int c16) {
+  return row * BK + ((c16 ^ (row & 15)) << 4);
+}
+
+template <int RT>
+__global__ void __launch_bounds__(256)
+dense_mfma_kernel(DenseMfmaArgs a) {
+  constexpr int ROWS = RT * 32;
+  constexpr int WPR = BK / 32;                    // words per row per chunk
+  constexpr int NTASK = ROWS * WPR;
+  constexpr int TPT = (NTASK + 255) / 256;
+  // two A buffers; the epilogue tile (ROWS x 128 int32) overlays them
+  constexpr int ABYTES = ROWS * BK;
+  constexpr int EBYTES = ROWS * 128 * 4;
+  constexpr int LDSB = (2 * ABYTES > EBYTES) ? 2 * ABYTES : EBYTES;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[LDSB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int b0 = blockIdx.x * a.SB;
+  const int nsamp = min(a.SB, a.B - b0);
+  const int rows = nsamp * a.T;                   // live rows of this workgroup
+  const int nb = blockIdx.y * 4 + wave;           // 32-column block of this wave
+  const bool wave_on = nb * 32 < a.N;
+  const int nchunks = (a.KS + KSC - 1) / KSC;
+
+  v16i acc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+    acc[r] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  uint32_t stg[TPT];
+  auto stage_load = [&](int chunk) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int task = tid + k * 256;
+      const int row = task / WPR, wi = task % WPR;
+      uint32_t wv = 0;
+      const int kw = chunk * WPR + wi;
+      if (task < NTASK && row < rows && kw < a.KS) {
+        const int bl = row / a.T, t = row - bl * a.T;
+        wv = a.x[(int64_t)t * a.xs_t + (int64_t)(b0 + bl) * a.xs_b + kw];
+      }
+      stg[k] = wv;
+    }
+  };
+  auto stage_store = [&](int buf) {
+    uint8_t *base = lds + buf * ABYTES;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int task = tid + k * 256;
+      if (task < NTASK) {
+        const int row = task / WPR, wi = task % WPR;
+        *(v4i *)(base + a_addr(row, wi * 2)) = expand16b(stg[k] & 0xFFFFu);
+        *(v4i *)(base + a_addr(row, wi * 2 + 1)) = expand16b(stg[k] >> 16);
+      }
+    }
+  };
+
+  const v4i *wtile = (const v4i *)a.wt + ((int64_t)nb * a.KS) * 64 + lane;
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) stage_load(c + 1);
+    if (wave_on) {
+      const uint8_t *base = lds + (c & 1) * ABYTES;
+      const int ks_n = min(KSC, a.KS - c * KSC);
+      for (int ks = 0; ks < ks_n; ++ks) {
+        const v4i bf = wtile[(int64_t)(c * KSC + ks) * 64];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const v4i av = *(const v4i *)(base + a_addr(r * 32 + n, ks * 2 + h));
+          acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf, acc[r], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunks) stage_store((c + 1) & 1);
+    __syncthreads();
+  }
+
+  // int32 tile -> LDS [row][128]; C/D layout: col = lane & 31,
+  // row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+  int *et = (int *)lds;
+  if (wave_on) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = r * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        et[row * 128 + wave * 32 + n] = acc[r][i];
+      }
+  }
+  __syncthreads();
+
+  // one (sample, feature) pair per thread and pass; 64 consecutive features of
+  // one sample per wave, so a ballot is two output words
+  const int CW = (a.N + 31) >> 5;
+  for (int p = tid; p < a.SB * 128; p += 256) {
+    const int bl = p >> 7, col = p & 127;
+    const int feat = blockIdx.y * 128 + col;
+    const bool live = bl < nsamp && feat < a.N;
+    float bmean = 0.f, bmul = 1.f, bbias = 0.f, dec = 0.f, u = 0.0f;
+    if (live) {
+      if (a.bn.mean) { bmean = a.bn.mean[feat]; bmul = a.bn.mul[feat]; bbias = a.bn.bias[feat]; }
+      if (a.nrn.kind == SNNQP_NEURON_LIF) dec = a.nrn.decay[feat];
+      if (a.u0) u = a.u0[(int64_t)(b0 + bl) * a.N + feat];
+    }
+    for (int t = 0; t < a.T; ++t) {
+      bool s = false;
+      if (live) {
+        float cur = dequant_acc(et[(bl * a.T + t) * 128 + col], a.dq);
+        if (a.bn.mean) cur = bn_apply(cur, bmean, bmul, bbias);
+        s = neuron_step(u, cur, a.nrn, dec);
+      }
+      const unsigned long long m = __ballot(s);
+      const int word = (blockIdx.y * 128 + (col & 64)) >> 5;     // wave-uniform
+      if (bl < nsamp) {
+        uint32_t *o = a.s_out + ((int64_t)t * a.B + (b0 + bl)) * CW;
+        if (lane == 0 && word < CW) o[word] = (uint32_t)m;
+        if (lane == 32 && word + 1 < CW) o[word + 1] = (uint32_t)(m >> 32);
+      }
+    }
+    if (live && a.u_out) a.u_out[(int64_t)(b0 + bl) * a.N + feat] = u;
+  }
+}
+
+const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
+                                   const snnqp_weight_t *w, const int8_t *wt,
+                                   const snnqp_neuron_t *nrn, int s_type) {
+  if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
+  if (!wt) return "MFMA-tiled codes `wt` not given";
+  if (in_type != SNNQP_BITS) return "input must be bit-packed";
+  if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
+  if (K & 31) return "K must be a multiple of 32";
+  if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
+  return nullptr;
+}
+
+template <int RT>
+static void launch_dense(const DenseMfmaArgs &a, unsigned gx, unsigned gy, hipStream_t st) {
+  hipLaunchKernelGGL((dense_mfma_kernel<RT>), dim3(gx, gy), dim3(256), 0, st, a);
+}
+
+int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
+                   int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
+                   const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                   float *u_out, uint32_t *s_out, hipStream_t st) {
+  SNNQP_REQUIRE(x && s_out, SNNQP_EINVAL, "dense mfma: null pointer");
+  SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense mfma: negative T/B");
+  SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
+  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
+                        "batch-norm descriptor with null arrays");
+  if (T == 0 || B == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(T <= 160, SNNQP_EUNSUPPORTED, "dense mfma: T > 160");
+  DenseMfmaArgs a;
+  a.x = (const uint32_t *)x; a.xs_t = xs_t; a.xs_b = xs_b;
+  a.T = T; a.B = B; a.K = K; a.N = N; a.KS = K / 32;
+  a.wt = wt;
+  a.dq = make_dequant(w->L, w->m);
+  a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
+  a.u0 = u0; a.u_out = u_out; a.s_out = s_out;
+  const unsigned gy = (unsigned)((N + 127) / 128);
+  // largest row tile that still gives the chip enough workgroups, else the
+  // smallest one that holds a whole sample (most workgroups)
+  static const int rts[4] = {5, 3, 2, 1};
+  int rt = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int sb = rts[i] * 32 / T;
+    if (sb < 1) continue;
+    rt = rts[i];
+    if ((int64_t)((B + sb - 1) / sb) * gy >= 200) break;
+  }
+  SNNQP_REQUIRE(rt > 0, SNNQP_EUNSUPPORTED, "dense mfma: T too large");
+  a.SB = rt * 32 / T;
+  const unsigned gx = (unsigned)((B + a.SB - 1) / a.SB);
+  switch (rt) {
+    case 5: launch_dense<5>(a, gx, gy, st); break;
+    case 3: launch_dense<3>(a, gx, gy, st); break;
+    case 2: launch_dense<2>(a, gx, gy, st); break;
+    default: launch_dense<1>(a, gx, gy, st); break;
+  }
+  SNNQP_CHECK_LAUNCH("dense_mfma_kernel");
+  return SNNQP_OK;
 }
 
 }  // namespace snnqp

@@ -70,29 +70,39 @@ quantize_kernel(const float *__restrict__ w, const float *__restrict__ mask,
   if (flags && f) atomicOr(flags, f);
 }
 
+// MFMA B-operand tiles: for the 32-column block nb and the 32-deep k-step ks,
+// lane l = (n & 31) + 32 * h holds bytes k = 32 ks + 16 h + j (j < 16) of column
+// n = 32 nb + (l & 31): one contiguous 1 KiB read per wave and k-step.
 __global__ void __launch_bounds__(256)
-transpose_codes_kernel(const int8_t *__restrict__ w, int64_t K, int32_t N,
+pack_codes_mfma_kernel(const int8_t *__restrict__ w, int64_t K, int32_t N,
                        int32_t Npad, int8_t *__restrict__ wt) {
-  const int64_t n = (int64_t)Npad * K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  const int64_t total = (int64_t)Npad * K;
+  const int64_t KS = K / 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / K, k = i - row * K;
-    wt[i] = row < N ? w[k * N + row] : (int8_t)0;
+    const int j = (int)(i & 15);
+    const int lane = (int)((i >> 4) & 63);
+    const int64_t tile = i >> 10;
+    const int64_t ks = tile % KS, nb = tile / KS;
+    const int64_t n = nb * 32 + (lane & 31);
+    const int64_t k = ks * 32 + 16 * (lane >> 5) + j;
+    wt[i] = n < N ? w[k * N + n] : (int8_t)0;
   }
 }
 
 }  // namespace snnqp
 
-extern "C" int snnqp_transpose_codes(const int8_t *w, int64_t K, int32_t N,
+extern "C" int snnqp_pack_codes_mfma(const int8_t *w, int64_t K, int32_t N,
                                      int32_t Npad, int8_t *wt,
                                      snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(w && wt && K > 0 && N > 0 && Npad >= N, SNNQP_EINVAL,
-                "transpose_codes: bad argument");
+  SNNQP_REQUIRE(w && wt && K > 0 && N > 0, SNNQP_EINVAL, "pack_codes_mfma: bad argument");
+  SNNQP_REQUIRE((K & 31) == 0 && Npad >= N && (Npad & 31) == 0, SNNQP_EINVAL,
+                "pack_codes_mfma: K and Npad must be multiples of 32, Npad >= N");
   const int64_t blocks = ceil_div64((int64_t)Npad * K, 256);
-  hipLaunchKernelGGL(transpose_codes_kernel, dim3((int)(blocks < 4096 ? blocks : 4096)),
+  hipLaunchKernelGGL(pack_codes_mfma_kernel, dim3((int)(blocks < 4096 ? blocks : 4096)),
                      dim3(256), 0, (hipStream_t)stream, w, K, N, Npad, wt);
-  SNNQP_CHECK_LAUNCH("transpose_codes_kernel");
+  SNNQP_CHECK_LAUNCH("pack_codes_mfma_kernel");
   return SNNQP_OK;
 }
 
@@ -101,13 +111,14 @@ extern "C" int snnqp_quantize(int kind, const float *w, const float *mask,
                               float *fq_out, int8_t *codes_out, int32_t *flags,
                               snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(w && n >= 0, SNNQP_EINVAL, "quantize: null weights");
+  SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "quantize: negative size");
   SNNQP_REQUIRE(kind >= SNNQP_Q_DUQ && kind <= SNNQP_Q_PARAMETRIC_D_XMAX,
                 SNNQP_EINVAL, "quantize: unknown quantiser %d", kind);
   // quant.py:332-336 "Bit widths below 2 bits are not supported"
   SNNQP_REQUIRE(bits > 1 && bits <= 24, SNNQP_EINVAL,
                 "quantize: bits must be in [2, 24], got %d", bits);
   if (n == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(w, SNNQP_EINVAL, "quantize: null weights");
   QuantP p;
   p.kind = kind;
   p.p0 = p0;

@@ -142,8 +142,9 @@ extern "C" {
 
 int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
                       snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && flags && n >= 0, SNNQP_EINVAL, "inspect_f32: null argument");
+  SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "inspect_f32: negative size");
   if (n == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && flags, SNNQP_EINVAL, "inspect_f32: null argument");
   hipLaunchKernelGGL(inspect_f32_kernel, dim3(grid_for(n)), dim3(256), 0,
                      (hipStream_t)stream, x, n, flags);
   SNNQP_CHECK_LAUNCH("inspect_f32_kernel");
@@ -152,8 +153,9 @@ int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
 
 int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
                     snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && y && n >= 0, SNNQP_EINVAL, "f32_to_u8: null argument");
+  SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "f32_to_u8: negative size");
   if (n == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && y, SNNQP_EINVAL, "f32_to_u8: null argument");
   hipLaunchKernelGGL(f32_to_u8_kernel, dim3(grid_for(n)), dim3(256), 0,
                      (hipStream_t)stream, x, y, n);
   SNNQP_CHECK_LAUNCH("f32_to_u8_kernel");
@@ -162,11 +164,11 @@ int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
 
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
                     uint32_t *bits, snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && bits && rows >= 0 && C > 0, SNNQP_EINVAL,
-                "pack_bits: bad argument");
+  SNNQP_REQUIRE(rows >= 0 && C > 0, SNNQP_EINVAL, "pack_bits: bad shape");
   SNNQP_REQUIRE(in_type == SNNQP_F32 || in_type == SNNQP_U8, SNNQP_EINVAL,
                 "pack_bits: input must be F32 or U8");
   if (rows == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && bits, SNNQP_EINVAL, "pack_bits: null argument");
   const int32_t CW = (C + 31) / 32;
   const int64_t nchunks = rows * ((C + 63) / 64);
   const int grid = grid_for(nchunks * 64);
@@ -182,9 +184,9 @@ int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
 
 int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
                       snnqp_stream_t stream) {
-  SNNQP_REQUIRE(bits && y && rows >= 0 && C > 0, SNNQP_EINVAL,
-                "unpack_bits: bad argument");
+  SNNQP_REQUIRE(rows >= 0 && C > 0, SNNQP_EINVAL, "unpack_bits: bad shape");
   if (rows == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(bits && y, SNNQP_EINVAL, "unpack_bits: null argument");
   hipLaunchKernelGGL(unpack_bits_kernel, dim3(grid_for(rows * C)), dim3(256), 0,
                      (hipStream_t)stream, bits, rows, C, (C + 31) / 32, y);
   SNNQP_CHECK_LAUNCH("unpack_bits_kernel");

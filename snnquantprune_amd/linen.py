@@ -387,7 +387,9 @@ compact_method = _wrap_call
 # BatchNorm (flax.linen.BatchNorm, eval mode) -- examples/tcja/models.py:101-107
 # ---------------------------------------------------------------------------
 
-_bn_cache = {}
+from ._cache import TensorCache  # noqa: E402
+
+_bn_cache = TensorCache(256)
 
 
 class BatchNorm(Module):
@@ -414,9 +416,7 @@ class BatchNorm(Module):
     var = self.variable("batch_stats", "var", lambda: ones(None, feat)).value
     scale = self.param("scale", ones, feat) if self.use_scale else None
     bias = self.param("bias", zeros, feat) if self.use_bias else None
-    key = tuple((t.data_ptr(), t._version) if t is not None else None
-                for t in (mean, var, scale, bias)) + (float(self.epsilon),)
-    hit = _bn_cache.get(key)
+    hit = _bn_cache.get((mean, var, scale, bias), float(self.epsilon))
     if hit is not None:
       return hit
     dev = mean.device
@@ -430,10 +430,7 @@ class BatchNorm(Module):
     out = ops.BnCoeffs(torch.from_numpy(m).to(dev),
                        torch.from_numpy(mul.astype(np.float32)).to(dev),
                        torch.from_numpy(b).to(dev))
-    if len(_bn_cache) > 256:
-      _bn_cache.clear()
-    _bn_cache[key] = out
-    return out
+    return _bn_cache.put((mean, var, scale, bias), float(self.epsilon), out)
 
   def __call__(self, x, use_running_average: Optional[bool] = None):
     from . import ops

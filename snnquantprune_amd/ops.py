@@ -107,7 +107,7 @@ class Weight:
   """Kernel after the weight transforms (flax_qdense.py:74-85).
 
   wtype W_I8: `w` = int8 codes * mask in the reference's layout, current =
-  fl(fl(acc / L) * m); `wt` = optional [Npad][K] transposed codes for MFMA.
+  fl(fl(acc / L) * m); `wt` = optional MFMA-tiled codes (pack_codes_mfma).
   wtype W_F32: `w` = float32 fake-quantised * mask kernel."""
   wtype: int
   w: torch.Tensor
@@ -212,15 +212,17 @@ def quantize(kind: int, w: torch.Tensor, mask: Optional[torch.Tensor], bits: int
   return fq, codes, flags
 
 
-def transpose_codes(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
-  """[K, N] int8 -> [Npad, K] (k contiguous), zero rows beyond N."""
+def pack_codes_mfma(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
+  """[K, N] int8 codes -> MFMA B-operand tiles [Npad/32, K/32, 64, 16]."""
   _require_gpu(codes)
   assert codes.dtype == torch.int8
   c2 = codes.reshape(-1, codes.shape[-1]).contiguous()
   K, N = c2.shape
-  n_pad = N if n_pad is None else n_pad
-  wt = torch.empty((n_pad, K), dtype=torch.int8, device=codes.device)
-  L.check(L.lib().snnqp_transpose_codes(_ptr(c2), K, N, n_pad, _ptr(wt), _stream()))
+  n_pad = (N + 31) // 32 * 32 if n_pad is None else n_pad
+  if K % 32:
+    raise ValueError("MFMA tiling needs K % 32 == 0 (K = %d)" % K)
+  wt = torch.empty((n_pad // 32, K // 32, 64, 16), dtype=torch.int8, device=codes.device)
+  L.check(L.lib().snnqp_pack_codes_mfma(_ptr(c2), K, N, n_pad, _ptr(wt), _stream()))
   return wt
 
 

@@ -10,13 +10,13 @@ version and is cached.
 
 from __future__ import annotations
 
-from collections import OrderedDict
 from typing import Optional
 
 import torch
 
 from . import _lib as L
 from . import ops
+from ._cache import TensorCache
 from .quant import QuantDesc
 
 # When True a float32 activation tensor is inspected on the device (one pass +
@@ -66,9 +66,9 @@ class PackedKernel:
       self._float = ops.Weight(L.W_F32, fq.contiguous())
     return self._float
 
-  def int_weight_transposed(self, n_pad: int, row_perm: Optional[torch.Tensor] = None,
+  def int_weight_mfma(self, n_pad: int, row_perm: Optional[torch.Tensor] = None,
                             perm_key=None) -> Optional[ops.Weight]:
-    """int weight with `wt` = [n_pad][K] codes for the MFMA kernels.  `row_perm`
+    """int weight with `wt` = MFMA-tiled codes (None if K % 32 != 0).  `row_perm`
     re-orders the K rows first (an exact re-indexing of the integer sum, used
     to absorb the channel-major flatten of models.py:189-190)."""
     base = self.int_weight()
@@ -81,30 +81,19 @@ class PackedKernel:
       if row_perm is not None:
         codes = codes.index_select(0, row_perm)
       codes = codes.contiguous()
-      w = ops.Weight(L.W_I8, codes, base.L, base.m,
-                     wt=ops.transpose_codes(codes, n_pad))
+      wt = ops.pack_codes_mfma(codes, n_pad) if codes.shape[0] % 32 == 0 else None
+      w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt)
       self._wt[key] = w
     return w
 
 
-_cache: "OrderedDict[tuple, PackedKernel]" = OrderedDict()
-_CACHE_MAX = 128
-
-
-def _tkey(t):
-  return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+_cache = TensorCache(128)
 
 
 def get_packed(kernel, desc, mask) -> PackedKernel:
-  key = (_tkey(kernel), desc, _tkey(mask))
-  pk = _cache.get(key)
+  pk = _cache.get((kernel, mask), desc)
   if pk is None:
-    pk = PackedKernel(kernel, desc, mask)
-    _cache[key] = pk
-    while len(_cache) > _CACHE_MAX:
-      _cache.popitem(last=False)
-  else:
-    _cache.move_to_end(key)
+    pk = _cache.put((kernel, mask), desc, PackedKernel(kernel, desc, mask))
   return pk
 
 

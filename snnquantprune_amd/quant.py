@@ -22,6 +22,7 @@ import torch
 from . import _lib as L
 from . import linen as nn
 from . import ops
+from ._cache import TensorCache
 
 Array = Any
 
@@ -92,7 +93,7 @@ def percentile_init(x, bits, sign, perc, axis=None):
 # helpers
 # ---------------------------------------------------------------------------
 
-_scalar_cache = {}
+_scalar_cache = TensorCache(4096)
 
 
 def host_scalar(t) -> float:
@@ -100,13 +101,9 @@ def host_scalar(t) -> float:
   device->host readback of the pack step)."""
   if not isinstance(t, torch.Tensor):
     return float(t)
-  key = (t.data_ptr(), t._version, t.device)
-  v = _scalar_cache.get(key)
+  v = _scalar_cache.get((t,))
   if v is None:
-    if len(_scalar_cache) > 4096:
-      _scalar_cache.clear()
-    v = float(t.reshape(-1)[0].item())
-    _scalar_cache[key] = v
+    v = _scalar_cache.put((t,), None, float(t.reshape(-1)[0].item()))
   return v
 
 

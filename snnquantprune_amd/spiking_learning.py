@@ -23,6 +23,7 @@ from . import _lib as L
 from . import linen as nn
 from . import ops
 from . import packing
+from ._cache import TensorCache
 from .flax_qconv import QuantConv
 from .flax_qdense import QuantDense
 
@@ -82,7 +83,7 @@ def _sigmoid_f32(x):
   return (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
 
 
-_decay_cache = {}
+_decay_cache = TensorCache(256)
 
 
 class _NeuronBase(nn.Module):
@@ -151,13 +152,11 @@ class LIF(_NeuronBase):
   @nn.compact_method
   def neuron(self, features: int) -> ops.Neuron:
     tau = self.param("tau", uniform(self.init_tau), (int(features),))
-    key = (tau.data_ptr(), tau._version, str(tau.device))
-    dec = _decay_cache.get(key)
+    dec = _decay_cache.get((tau,))
     if dec is None:
-      if len(_decay_cache) > 256:
-        _decay_cache.clear()
-      dec = torch.from_numpy(_sigmoid_f32(tau.detach().cpu().numpy())).to(tau.device)
-      _decay_cache[key] = dec
+      dec = _decay_cache.put(
+          (tau,), None,
+          torch.from_numpy(_sigmoid_f32(tau.detach().cpu().numpy())).to(tau.device))
     return ops.Neuron(L.NEURON_LIF, 0.0, self.v_threshold, self.v_reset, decay=dec)
 
   def __call__(self, u, s_in):
@@ -250,10 +249,10 @@ class SpikingBlock(nn.Module):
         perm = None
         if flat is not None:
           perm = _flat_perm(*flat, device=pk.kernel.device)
-        w = pk.int_weight_transposed(n_pad, perm, perm_key=flat)
+        w = pk.int_weight_mfma(n_pad, perm, perm_key=flat)
         flat = None if w is not None else flat
       else:
-        w = pk.int_weight_transposed(conn.features)
+        w = pk.int_weight_mfma((conn.features + 31) // 32 * 32)
     if w is None:
       w = pk.float_weight()
     if flat is not None:

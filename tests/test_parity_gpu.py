@@ -58,7 +58,7 @@ def _weight(leaf, bits, dev, quantized=True, transposed=False):
     return pk.float_weight()
   if transposed:
     n = leaf["kernel"].shape[-1]
-    return pk.int_weight_transposed((n + 31) // 32 * 32)
+    return pk.int_weight_mfma((n + 31) // 32 * 32)
   return pk.int_weight()
 
 
@@ -195,7 +195,7 @@ def test_neurons_bit_exact(dev, oracle, golden_dir):
     np.testing.assert_array_equal(_np(u), g[name + "_u"], err_msg=name)
     _, sp = ops.lif_forward(x, nrn, u0=u0, packed_out=True, want_u=False)
     np.testing.assert_array_equal(_np(sp), packbits_lastaxis(g[name + "_s"]))
-    assert 0.02 < g[name + "_s"].mean() < 0.6
+    assert 0.01 < g[name + "_s"].mean() < 0.6
 
 
 def test_neuron_modules_single_step(dev, oracle):
@@ -283,6 +283,43 @@ def test_dense_block_int_path(dev, oracle, golden_dir, counts):
   with pytest.raises(L.SnnqpError) as ei:
     ops.dense_lif_forward(x.to(torch.float32), w, K, N, _mslif(), impl=L.IMPL_GENERIC)
   assert ei.value.code == L.EUNSUPPORTED
+
+
+@pytest.mark.parametrize("shape", [(6, 5, 256, 70), (20, 37, 2048, 512), (10, 3, 96, 160),
+                                   (33, 9, 64, 33)],
+                         ids=["small", "c2_layer1", "ragged_n", "long_t"])
+def test_dense_block_mfma(dev, oracle, shape):
+  """int8 MFMA dense block vs the oracle and vs the direct-form kernel:
+  rasters and final u bit-exact, incl. a non-zero carry and batch-major input."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, K, N = shape
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N)
+  e = cases.dense_block_expected(oracle, c)
+  assert 0.01 < e["s"].mean() < 0.5
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert w.wt is not None
+  x = ops.pack_bits(_t(c["x"], dev))
+  u0 = _t(c["u0"], dev)
+  u, s = ops.dense_lif_forward(x, w, K, N, _mslif(), u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(e["s"]))
+  np.testing.assert_array_equal(_np(u), e["u"])
+  ug, sg = ops.dense_lif_forward(x, w, K, N, _mslif(), u0=u0, packed_out=True,
+                                 impl=L.IMPL_GENERIC)
+  np.testing.assert_array_equal(_np(s), _np(sg))
+  np.testing.assert_array_equal(_np(u), _np(ug))
+  xb = ops.pack_bits(_t(np.ascontiguousarray(np.swapaxes(c["x"], 0, 1)), dev))
+  ub, sb = ops.dense_lif_forward(xb, w, K, N, _mslif(), u0=u0, packed_out=True,
+                                 impl=L.IMPL_MFMA, time_major=False)
+  np.testing.assert_array_equal(_np(sb), _np(s))
+  for nrn in (ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, 0.8, 0.1),
+              ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, 0.3, 1.0, 0.0),
+              ops.Neuron(L.NEURON_LIF, 0.0, 1.0, 0.0,
+                         decay=_t(np.linspace(0.2, 0.9, N).astype(F32), dev))):
+    ua, sa = ops.dense_lif_forward(x, w, K, N, nrn, packed_out=True, impl=L.IMPL_MFMA)
+    ub, sb = ops.dense_lif_forward(x, w, K, N, nrn, packed_out=True, impl=L.IMPL_GENERIC)
+    np.testing.assert_array_equal(_np(sa), _np(sb))
+    np.testing.assert_array_equal(_np(ua), _np(ub))
 
 
 def test_dense_block_fseq_path(dev, oracle, golden_dir):
