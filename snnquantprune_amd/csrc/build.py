@@ -12,7 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "quantize.hip", "spikes.hip", "elementwise.hip",
            "generic_block.hip", "blocks.hip", "conv3x3_mfma.hip", "dense_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
+         "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP pass pairs adjacent float ops of the unrolled
+# epilogues into v_pk_*_f32, which on gfx950 is no faster than two scalar ops
+# and chains every pair through one register pair with s_nop hazards.
 LIB = os.path.join(HERE, "libsnnqp.so")
 
 

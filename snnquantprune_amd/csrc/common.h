@@ -60,6 +60,16 @@ inline Dequant make_dequant(float L, float m) {
   return d;
 }
 
+// Branch-free form for straight-line epilogues: with L == 1 the three ops are
+// the identity (q = a, e = 0, q' = a).
+__device__ __forceinline__ float dequant_acc_nb(int acc, const Dequant &d) {
+  const float a = (float)acc;
+  float q = a * d.rL;
+  const float e = __builtin_fmaf(-q, d.L, a);
+  q = __builtin_fmaf(e, d.rL, q);
+  return q * d.m;
+}
+
 __device__ __forceinline__ float dequant_acc(int acc, const Dequant &d) {
   float a = (float)acc;
   if (d.has_div) {
