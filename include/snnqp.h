@@ -81,6 +81,7 @@ typedef struct {
   const void *w;
   float L;
   float m;
+  int32_t abs_sum_max; /* W_I8: max over outputs of sum_k |code|; 0 = unknown */
 } snnqp_weight_t;
 
 /* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),
@@ -146,6 +147,8 @@ int snnqp_pack_codes_mfma(const int8_t *w, int64_t K, int32_t N, int32_t Npad,
  * the kernels read/write.  rows x C logical elements. */
 int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
                       snnqp_stream_t stream);
+int snnqp_inspect_u8(const uint8_t *x, int64_t n, int32_t *flags,
+                     snnqp_stream_t stream);
 int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
                     snnqp_stream_t stream);
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
@@ -179,14 +182,17 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       pad 1 / no dilation / groups 1, H % 8 == W % 8 == 0, Cout % 32 == 0 and
  *       (BITS input with Cin == 128 and `wt` = the codes tiled by
  *       snnqp_pack_codes_mfma (K = 9 * Cin), or U8 input with Cin == 2 and
- *       values <= 127), s_type BITS.  SNNQP_IMPL_AUTO picks MFMA when it can. */
+ *       values <= 127), s_type BITS.  SNNQP_IMPL_AUTO picks MFMA when it can.
+ * x_max an upper bound of the input values if known (1 for spikes), else 0: with
+ *       weights' abs_sum_max it bounds |acc| and lets the MFMA kernels dequantise
+ *       through an LDS table instead of arithmetic. */
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
                            const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                            const int8_t *wt, const snnqp_bn_t *bn,
                            const snnqp_neuron_t *nrn, const float *u0,
                            float *u_out, void *s_out, int s_type, int pool,
-                           int impl, snnqp_stream_t stream);
+                           int impl, int x_max, snnqp_stream_t stream);
 
 /* Same for QuantDense: x [T][B][K], weights [K][N] (GENERIC) .
  * IMPL_MFMA additionally needs `wt`: the int8 codes tiled by

@@ -27,7 +27,8 @@ OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 
 
 class WeightT(Structure):
-  _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float)]
+  _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
+              ("abs_sum_max", c_int32)]
 
 
 class BnT(Structure):
@@ -56,6 +57,7 @@ _PROTOTYPES = {
     "snnqp_pack_codes_mfma": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                       c_void_p]),
     "snnqp_inspect_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "snnqp_inspect_u8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_f32_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "snnqp_pack_bits": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p,
                                 c_void_p]),
@@ -65,7 +67,7 @@ _PROTOTYPES = {
     "snnqp_conv_lif_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
-        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "snnqp_dense_lif_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,

@@ -29,6 +29,12 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True, extra_flags=()):
   hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+  if os.environ.get("SNNQP_CXXFLAGS"):    # A/B experiments, e.g. -DSNNQP_U8C2_WPS=3
+    extra_flags = tuple(extra_flags) + tuple(os.environ["SNNQP_CXXFLAGS"].split())
+    force = True
+  if os.environ.get("SNNQP_PROBE"):       # diagnostic build: in-kernel clock stamps
+    extra_flags = tuple(extra_flags) + ("-DSNNQP_CLOCK_PROBE",)
+    force = True
   headers = [os.path.join(HERE, h) for h in ("common.h", "kernels.h")]
   headers.append(os.path.join(HERE, "..", "..", "include", "snnqp.h"))
   headers.append(os.path.abspath(__file__))

@@ -28,6 +28,16 @@ namespace snnqp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#ifndef SNNQP_U8C2_UNROLL
+#define SNNQP_U8C2_UNROLL 1
+#endif
+#ifndef SNNQP_U8C2_WPS
+#define SNNQP_U8C2_WPS 4    // waves per SIMD the conv0 kernel is compiled for (A/B: 2: 22.3, 3: 19.5, 4: 18.6 ms)
+#endif
+
+constexpr int LUT_CAP = 2047;                   // table covers acc in [-LUT_CAP, LUT_CAP]
 
 constexpr int HALO = 10;
 constexpr int PIXB = 128;                       // LDS bytes per halo pixel
@@ -48,6 +58,7 @@ struct ConvMfmaArgs {
   int32_t pool;
   int32_t tiles_y, tiles_x;
   int64_t npatch;
+  int32_t lut_bound;  // > 0: |acc| <= lut_bound guaranteed, dequant by LDS table
 };
 
 // 16-byte chunk c16 of halo pixel (hy, hx).  Two pixels share a 256-byte bank
@@ -67,6 +78,15 @@ __device__ __forceinline__ v4i expand16(uint32_t b) {
   return o;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences
+// global memory, i.e. waits (vmcnt(0)) for the spike stores of the previous step
+// and the prefetched halo loads -- a full memory round trip per timestep.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct LaneConsts {
   float bmean, bmul, bbias, dec;
 };
@@ -76,38 +96,68 @@ struct LaneConsts {
 // (ty + 1, tx) in its high half.  Returns the word this lane stores:
 //   POOL : lanes 0..7  = pooled pixel (pty = lane >> 2, ptx = lane & 3)
 //   !POOL: lanes 0..31 = pixel row `lane` of the tile
-template <bool FAST>
-__device__ __forceinline__ unsigned long long neuron_elem(int acc, float &u,
-                                                          const Dequant &dq,
-                                                          const LaneConsts &lc,
-                                                          const NeuronP &nrn) {
-  float cur = dequant_acc_nb(acc, dq);
-  cur = bn_apply(cur, lc.bmean, lc.bmul, lc.bbias);
-  bool s;
+// lut[i] = fl(fl((i - bound) / L) * m): the dequantised current of accumulator
+// value i - bound, built once per workgroup (same three-instruction division).
+__device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &dq,
+                                          int tid) {
+  for (int i = tid; i <= 2 * bound; i += 256) lut[i] = dequant_acc_nb(i - bound, dq);
+}
+
+// Two neurons (accumulator registers i, i+1: two pixels, same channel) through
+// dequant -> BatchNorm -> neuron, as packed float32 ops (v_pk_*_f32 keep every
+// rounding of the scalar sequence).  `lutc` points at the table entry of acc = 0.
+template <bool FAST, bool LUT>
+__device__ __forceinline__ void neuron_pair(int a0, int a1, float &u0, float &u1,
+                                            const Dequant &dq, const LaneConsts &lc,
+                                            const NeuronP &nrn, const float *lutc,
+                                            unsigned long long &m0,
+                                            unsigned long long &m1) {
+  v2f y;
+  if (LUT) {
+    y = v2f{lutc[a0], lutc[a1]};
+  } else {
+    const v2f a = {(float)a0, (float)a1};
+    v2f q = a * dq.rL;
+    const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
+    q = __builtin_elementwise_fma(e, v2f{dq.rL, dq.rL}, q);
+    y = q * dq.m;
+  }
+  v2f x = y - lc.bmean;
+  x = x * lc.bmul;
+  x = x + lc.bbias;
   if (FAST) {
     // multi_step_LIF with tau a power of two and v_reset == 0
     // (spiking_learning.py:410-414): u - 0 == u exactly, and with float32
     // subnormals kept (hipcc default) (u - v_th) >= 0  <=>  u >= v_th.
-    const float d = cur - u;
-    u = u + d * nrn.inv_k;
-    s = u >= nrn.vth;
-    u = s ? 0.0f : u;
+    v2f uu = {u0, u1};
+    const v2f d = x - uu;
+    const v2f dk = d * nrn.inv_k;
+    uu = uu + dk;
+    const bool s0 = uu.x >= nrn.vth, s1 = uu.y >= nrn.vth;
+    m0 = __ballot(s0);
+    m1 = __ballot(s1);
+    u0 = s0 ? 0.0f : uu.x;
+    u1 = s1 ? 0.0f : uu.y;
   } else {
-    s = neuron_step(u, cur, nrn, lc.dec);
+    m0 = __ballot(neuron_step(u0, x.x, nrn, lc.dec));
+    m1 = __ballot(neuron_step(u1, x.y, nrn, lc.dec));
   }
-  return __ballot(s);
 }
 
-template <bool FAST, bool POOL>
+template <bool FAST, bool POOL, bool LUT, int FENCE = 0>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
-                                                  const NeuronP &nrn, int lane) {
+                                                  const NeuronP &nrn, int lane,
+                                                  const float *lutc) {
   uint32_t myw = 0;
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
-    const unsigned long long m0 = neuron_elem<FAST>(acc[i], u[i], dq, lc, nrn);
-    const unsigned long long m1 = neuron_elem<FAST>(acc[i + 1], u[i + 1], dq, lc, nrn);
+    // FENCE: keep the scheduler from hoisting every pair's compare to one place
+    // (16 live 64-bit masks spill the SGPR file)
+    if (FENCE && i > 0 && (i % (2 * FENCE)) == 0) __builtin_amdgcn_sched_barrier(0);
+    unsigned long long m0, m1;
+    neuron_pair<FAST, LUT>(acc[i], acc[i + 1], u[i], u[i + 1], dq, lc, nrn, lutc, m0, m1);
     if (POOL) {
       const unsigned long long o = m0 | m1;
       const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
@@ -123,20 +173,49 @@ __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16
   return myw;
 }
 
-// Per-lane output word offset (in words) of tile `tl` inside one (t, b) image.
+// Spike words are staged in LDS, obuf[slot = t % FL][pixel][4 words of the 128-
+// channel block], and flushed with 16-byte stores: no global store sits in the
+// per-timestep loop (vmcnt stays a pure load counter there).
 template <bool POOL>
-__device__ __forceinline__ int out_word_offset(const ConvMfmaArgs &a, int y0,
-                                                   int x0, int tl, int cw, int lane) {
-  const int CW = a.Cout >> 5;
-  if (POOL) {
-    const int OW = a.W >> 1;
-    const int oy = (y0 >> 1) + tl * 2 + ((lane >> 2) & 1);
-    const int ox = (x0 >> 1) + (lane & 3);
-    return (oy * OW + ox) * CW + cw;
-  }
+struct OutStage {
+  static constexpr int NPIX = POOL ? 16 : 64;   // (pooled) pixels of one patch
+  static constexpr int FL = POOL ? 32 : 8;      // timesteps between flushes
+  static constexpr int BYTES = FL * NPIX * 16;
+};
+
+// patch-pixel index this lane's word of tile `tl` belongs to
+template <bool POOL>
+__device__ __forceinline__ int out_pix(int tl, int lane) {
+  if (POOL) return (tl * 2 + ((lane >> 2) & 1)) * 4 + (lane & 3);
   const int ty = ((lane >> 2) & 1) | (((lane >> 4) & 1) << 1);
   const int tx = (lane & 3) | (((lane >> 3) & 1) << 2);
-  return ((y0 + tl * 4 + ty) * a.W + (x0 + tx)) * CW + cw;
+  return (tl * 4 + ty) * 8 + tx;
+}
+
+// Writes timesteps [t0, t0 + n) of the patch at (y0, x0) (full-resolution
+// coordinates) from obuf to global memory.  All 256 threads take part.
+template <bool POOL>
+__device__ __forceinline__ void flush_out(const uint32_t *obuf, const ConvMfmaArgs &a,
+                                          int t0, int n, int b, int y0, int x0, int tid) {
+  constexpr int NPIX = OutStage<POOL>::NPIX;
+  constexpr int PW = POOL ? 4 : 8;              // patch width in output pixels
+  const int CW = a.Cout >> 5;
+  const int cwb = blockIdx.y * 4;
+  const int nw = min(4, CW - cwb);
+  const int OH = POOL ? a.H >> 1 : a.H, OW = POOL ? a.W >> 1 : a.W;
+  const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
+  for (int i = tid; i < n * NPIX; i += 256) {
+    const int slot = i / NPIX, pix = i % NPIX;
+    const int t = t0 + slot;
+    const uint32_t *src = obuf + ((t % OutStage<POOL>::FL) * NPIX + pix) * 4;
+    uint32_t *dst = a.s_out + ((((int64_t)t * a.B + b) * OH + (oy0 + pix / PW)) * OW +
+                               (ox0 + pix % PW)) * CW + cwb;
+    if (nw == 4 && (CW & 3) == 0) {
+      *(v4i *)dst = *(const v4i *)src;
+    } else {
+      for (int w = 0; w < nw; ++w) dst[w] = src[w];
+    }
+  }
 }
 
 template <bool LOAD>
@@ -165,24 +244,57 @@ __device__ __forceinline__ void zero_u(float (&u)[2][16]) {
 
 #define ZERO16 v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 
+#ifdef SNNQP_CLOCK_PROBE
+// Diagnostic build only (python csrc/build.py with SNNQP_PROBE=1): shader-clock
+// and 100 MHz real-time stamps of workgroup 0 around the persistent loop, to
+// read the clock the chip sustains inside this kernel.  Never in the product.
+__device__ unsigned long long snnqp_clock_probe[4];
+extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
+  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(snnqp_clock_probe), 32);
+}
+#define PROBE_BEGIN()                                                        \
+  unsigned long long pc0 = 0, pr0 = 0;                                       \
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {              \
+    pc0 = __builtin_amdgcn_s_memtime();                                      \
+    pr0 = __builtin_amdgcn_s_memrealtime();                                  \
+  }
+#define PROBE_END()                                                          \
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {              \
+    snnqp_clock_probe[0] = __builtin_amdgcn_s_memtime() - pc0;               \
+    snnqp_clock_probe[1] = __builtin_amdgcn_s_memrealtime() - pr0;           \
+  }
+#else
+#define PROBE_BEGIN()
+#define PROBE_END()
+#endif
+
 // ---------------------------------------------------------------------------
 // Bit-packed input, Cin = 128.
 // ---------------------------------------------------------------------------
-template <bool FAST, bool POOL>
+template <bool FAST, bool POOL, bool LUT>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   constexpr int CIN = 128;
   constexpr int KK = CIN / 32;
   constexpr int NTASK = HALO * HALO * KK;        // (pixel, word) staging tasks
   constexpr int TPT = (NTASK + 255) / 256;       // tasks per thread
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * HALO_BYTES];
+  constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
+  constexpr int FL = OutStage<POOL>::FL;
+  __shared__ __attribute__((aligned(16))) uint8_t
+      lds[2 * HALO_BYTES + LUT_BYTES + OutStage<POOL>::BYTES];
+  uint32_t *obuf = (uint32_t *)(lds + 2 * HALO_BYTES + LUT_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
-  const int cw = cout_base >> 5;
+  const float *lutc = nullptr;
+  if (LUT) {
+    float *lut = (float *)(lds + 2 * HALO_BYTES);
+    build_lut(lut, a.lut_bound, a.dq, tid);
+    lutc = lut + a.lut_bound;
+  }
 
   // B operand: lane (n, h) holds W[tap][cin = 32 kk + 16 h + j][cout], j < 16:
   // k-step tap * KK + kk of this wave's 32-column block in the MFMA-tiled codes.
@@ -215,8 +327,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   }
   constexpr int TILE1 = 4 * HALO * PIXB;
   const uint32_t *xb = (const uint32_t *)a.x;
-  const int64_t img_words = (int64_t)(POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * (a.Cout >> 5);
+  // LDS word index of this lane's spike word (tile 0 / 1) inside one obuf slot
+  const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
+  const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
+  const bool store_lane = POOL ? lane < 8 : lane < 32;
 
+  PROBE_BEGIN()
   for (int64_t p = blockIdx.x; p < a.npatch; p += gridDim.x) {
     int64_t q = p;
     const int px = (int)(q % a.tiles_x); q /= a.tiles_x;
@@ -283,16 +399,118 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         }
       }
     };
-    const int ow0 = out_word_offset<POOL>(a, y0, x0, 0, cw, lane);
-    const int ow1 = out_word_offset<POOL>(a, y0, x0, 1, cw, lane);
-    const bool store_lane = wave_on && (POOL ? lane < 8 : lane < 32);
-    auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
-      const uint32_t w0 = tile_epilogue<FAST, POOL>(acc0, u[0], a.dq, lc, a.nrn, lane);
-      const uint32_t w1 = tile_epilogue<FAST, POOL>(acc1, u[1], a.dq, lc, a.nrn, lane);
+    // One pipelined step in a hand-placed order: 72 issue slots, each = one MFMA
+    // of step t+1, one A-fragment read for the next tap, and one quarter of a
+    // neuron pair of step t's epilogue (16 pairs x 4 pieces = 64 slots), fenced
+    // with sched_barrier so the order survives.  An in-order wave overlaps the
+    // matrix pipe and the VALU only when their instructions alternate; left to
+    // itself the scheduler emits bursts of MFMAs and bursts of VALU (measured:
+    // time = sum of the two instead of their maximum).
+    //   piece 1 (pair j+1): dequantise (LDS table reads or packed arithmetic)
+    //   piece 2 (pair j)  : BatchNorm (3 packed ops)
+    //   piece 3 (pair j)  : membrane update (3 packed ops) + threshold compares
+    //   piece 4 (pair j)  : reset + spike word select
+    auto fused_step = [&](const uint8_t *base, v16i &accN0, v16i &accN1,
+                          const v16i &accC0, const v16i &accC1, int t) {
+      v4i A[2][2 * KK];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        A[0][2 * kk] = *(const v4i *)(base + aoff[0][kk]);
+        A[0][2 * kk + 1] = *(const v4i *)(base + aoff[0][kk] + TILE1);
+      }
+      accN0 = ZERO16;
+      accN1 = ZERO16;
+      v2f y[2], x, uu;
+      unsigned long long m0 = 0, m1 = 0;
+      uint32_t w0 = 0, w1 = 0;
+      auto piece1 = [&](int j) {            // j = pair index 0..15
+        const int a0 = (j < 8) ? accC0[(j & 7) * 2] : accC1[(j & 7) * 2];
+        const int a1 = (j < 8) ? accC0[(j & 7) * 2 + 1] : accC1[(j & 7) * 2 + 1];
+        if (LUT) {
+          y[j & 1] = v2f{lutc[a0], lutc[a1]};
+        } else {
+          const v2f af = {(float)a0, (float)a1};
+          v2f q = af * a.dq.rL;
+          const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
+          q = __builtin_elementwise_fma(e, v2f{a.dq.rL, a.dq.rL}, q);
+          y[j & 1] = q * a.dq.m;
+        }
+      };
+      piece1(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int slot = 0; slot < 72; ++slot) {
+        const int tap = slot >> 3, m = slot & 7, kk = m >> 1, tl = m & 1;
+        // A fragment for the same position of the next tap
+        if (tap + 1 < 9)
+          A[(tap + 1) & 1][m] = *(const v4i *)(base + aoff[tap + 1][kk] + tl * TILE1);
+        if (tl == 0)
+          accN0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN0, 0, 0, 0);
+        else
+          accN1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN1, 0, 0, 0);
+        if (slot < 64) {
+          const int j = slot >> 2, piece = slot & 3;
+          float *up = (j < 8) ? &u[0][(j & 7) * 2] : &u[1][(j & 7) * 2];
+          if (piece == 0) {
+            if (j + 1 < 16) piece1(j + 1);
+          } else if (piece == 1) {
+            x = y[j & 1] - lc.bmean;
+            x = x * lc.bmul;
+            x = x + lc.bbias;
+          } else if (piece == 2) {
+            if (FAST) {
+              uu = v2f{up[0], up[1]};
+              const v2f d = x - uu;
+              const v2f dk = d * a.nrn.inv_k;
+              uu = uu + dk;
+              m0 = __ballot(uu.x >= a.nrn.vth);
+              m1 = __ballot(uu.y >= a.nrn.vth);
+            } else {
+              m0 = __ballot(neuron_step(up[0], x.x, a.nrn, lc.dec));
+              m1 = __ballot(neuron_step(up[1], x.y, a.nrn, lc.dec));
+            }
+          } else {
+            if (FAST) {
+              up[0] = (uu.x >= a.nrn.vth) ? 0.0f : uu.x;
+              up[1] = (uu.y >= a.nrn.vth) ? 0.0f : uu.y;
+            }
+            uint32_t &w = (j < 8) ? w0 : w1;
+            const int i = (j & 7) * 2;
+            if (POOL) {
+              const unsigned long long o = m0 | m1;
+              const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
+              w = (lane == (i >> 1)) ? pw : w;
+            } else {
+              const int r0 = (i & 3) + 8 * (i >> 2);
+              w = (lane == r0) ? (uint32_t)m0 : w;
+              w = (lane == r0 + 4) ? (uint32_t)(m0 >> 32) : w;
+              w = (lane == r0 + 1) ? (uint32_t)m1 : w;
+              w = (lane == r0 + 5) ? (uint32_t)(m1 >> 32) : w;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (store_lane) {
-        uint32_t *o = a.s_out + ((int64_t)t * a.B + b) * img_words;
-        o[ow0] = w0;
-        o[ow1] = w1;
+        uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
+        o[ob0] = w0;
+        o[ob1] = w1;
+      }
+    };
+    auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
+      const uint32_t w0 = tile_epilogue<FAST, POOL, LUT>(acc0, u[0], a.dq, lc, a.nrn, lane, lutc);
+      const uint32_t w1 = tile_epilogue<FAST, POOL, LUT>(acc1, u[1], a.dq, lc, a.nrn, lane, lutc);
+      if (store_lane) {
+        uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
+        o[ob0] = w0;
+        o[ob1] = w1;
+      }
+    };
+    // call right after the barrier that follows epilogue(t)
+    auto flush_after = [&](int t) {
+      if ((t + 1) % FL == 0 || t + 1 == a.T) {
+        flush_out<POOL>(obuf, a, t - t % FL, t % FL + 1, b, y0, x0, tid);
+        lds_barrier();
       }
     };
 
@@ -301,37 +519,42 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     stage_load(0);
     stage_store(0);
     if (a.T > 1) stage_load(1);
-    __syncthreads();
+    lds_barrier();
     mfma_step(lds, accA0, accA1);
     if (a.T > 1) stage_store(1);
-    __syncthreads();
+    lds_barrier();
 
     // steady state, unrolled by two so the accumulator roles alternate:
     //   MFMA(t+1) -> next  ||  epilogue(t) <- cur ; then stage halo(t+2)
     int t = 0;
     for (; t + 2 < a.T; t += 2) {
       stage_load(t + 2);
-      mfma_step(lds + HALO_BYTES, accB0, accB1);       // step t+1 (odd buffer)
-      epilogue(accA0, accA1, t);
+      fused_step(lds + HALO_BYTES, accB0, accB1, accA0, accA1, t);   // MFMA(t+1) || epilogue(t)
       stage_store(0);                                  // halo(t+2) -> even buffer
-      __syncthreads();
+      lds_barrier();
+      flush_after(t);
       if (t + 3 < a.T) stage_load(t + 3);
-      mfma_step(lds, accA0, accA1);                    // step t+2 (even buffer)
-      epilogue(accB0, accB1, t + 1);
+      fused_step(lds, accA0, accA1, accB0, accB1, t + 1);            // MFMA(t+2) || epilogue(t+1)
       if (t + 3 < a.T) stage_store(1);                 // halo(t+3) -> odd buffer
-      __syncthreads();
+      lds_barrier();
+      flush_after(t + 1);
     }
     // here MFMA(t) is in accA and, if t+1 < T, halo(t+1) is staged in the odd buffer
     if (t + 1 < a.T) {
-      mfma_step(lds + HALO_BYTES, accB0, accB1);
-      epilogue(accA0, accA1, t);
+      fused_step(lds + HALO_BYTES, accB0, accB1, accA0, accA1, t);
+      lds_barrier();
+      flush_after(t);
       epilogue(accB0, accB1, t + 1);
+      lds_barrier();
+      flush_after(t + 1);
     } else {
       epilogue(accA0, accA1, t);
+      lds_barrier();   // also: LDS is re-staged by the next patch
+      flush_after(t);
     }
-    __syncthreads();   // LDS is re-staged by the next patch
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
   }
+  PROBE_END()
 }
 
 // ---------------------------------------------------------------------------
@@ -345,16 +568,26 @@ constexpr int HROW2 = 24;                 // LDS bytes per halo row (10 px x 2 B
 constexpr int HIMG2 = HALO * HROW2;       // one timestep
 constexpr int TCHUNK = 32;                // timesteps staged per pass
 
-template <bool FAST, bool POOL>
-__global__ void __launch_bounds__(256, 3)
+template <bool FAST, bool POOL, bool LUT>
+__global__ void __launch_bounds__(256, SNNQP_U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[TCHUNK * HIMG2];
+  constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
+  constexpr int FL = OutStage<POOL>::FL;
+  static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
+  __shared__ __attribute__((aligned(16))) uint8_t
+      lds[TCHUNK * HIMG2 + LUT_BYTES + OutStage<POOL>::BYTES];
+  uint32_t *obuf = (uint32_t *)(lds + TCHUNK * HIMG2 + LUT_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
-  const int cw = cout_base >> 5;
+  const float *lutc = nullptr;
+  if (LUT) {
+    float *lut = (float *)(lds + TCHUNK * HIMG2);
+    build_lut(lut, a.lut_bound, a.dq, tid);   // visible after the first staging barrier
+    lutc = lut + a.lut_bound;
+  }
 
   v4i bf;
   {
@@ -393,7 +626,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   for (int d = 0; d < 4; ++d)
     amask[d] = h == 0 ? 0xFFFFFFFFu : (d == 0 ? 0x0000FFFFu : 0u);
   const uint8_t *xb = (const uint8_t *)a.x;
-  const int64_t img_words = (int64_t)(POOL ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * (a.Cout >> 5);
+  const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
+  const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
+  const bool store_lane = POOL ? lane < 8 : lane < 32;
 
   for (int64_t p = blockIdx.x; p < a.npatch; p += gridDim.x) {
     int64_t q = p;
@@ -405,13 +640,10 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     float u[2][16];
     if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
     else zero_u(u);
-    const int ow0 = out_word_offset<POOL>(a, y0, x0, 0, cw, lane);
-    const int ow1 = out_word_offset<POOL>(a, y0, x0, 1, cw, lane);
-    const bool store_lane = wave_on && (POOL ? lane < 8 : lane < 32);
 
     for (int tc = 0; tc < a.T; tc += TCHUNK) {
       const int nt = min(TCHUNK, a.T - tc);
-      __syncthreads();                       // previous readers of the LDS image are done
+      lds_barrier();                       // previous readers of the LDS image are done
       {
         constexpr int NT2 = (TCHUNK * HALO * HALO + 255) / 256;
         uint16_t v[NT2];
@@ -433,9 +665,11 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             *(uint16_t *)(lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2) = v[k];
         }
       }
-      __syncthreads();
-      if (wave_on) {
-        for (int tt = 0; tt < nt; ++tt) {
+      lds_barrier();
+      for (int tf = 0; tf < nt; tf += FL) {          // FL steps, then flush
+        const int nf = min(FL, nt - tf);
+#pragma unroll SNNQP_U8C2_UNROLL
+        for (int tt = tf; tt < tf + nf; ++tt) {
           const uint8_t *base = lds + tt * HIMG2;
           uint32_t words[2];
 #pragma unroll
@@ -451,14 +685,17 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             v16i acc = ZERO16;
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{av[0], av[1], av[2], av[3]},
                                                         bf, acc, 0, 0, 0);
-            words[tl] = tile_epilogue<FAST, POOL>(acc, u[tl], a.dq, lc, a.nrn, lane);
+            words[tl] = tile_epilogue<FAST, POOL, LUT, 2>(acc, u[tl], a.dq, lc, a.nrn, lane, lutc);
           }
           if (store_lane) {
-            uint32_t *o = a.s_out + ((int64_t)(tc + tt) * a.B + b) * img_words;
-            o[ow0] = words[0];
-            o[ow1] = words[1];
+            uint32_t *o = obuf + ((tc + tt) % FL) * (OutStage<POOL>::NPIX * 4);
+            o[ob0] = words[0];
+            o[ob1] = words[1];
           }
         }
+        lds_barrier();
+        flush_out<POOL>(obuf, a, tc + tf, nf, b, y0, x0, tid);
+        lds_barrier();
       }
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
@@ -515,7 +752,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     hipStream_t st) {
+                     int x_max, hipStream_t st) {
   SNNQP_REQUIRE(x && w->w && s_out, SNNQP_EINVAL, "conv3x3 mfma: null pointer");
   SNNQP_REQUIRE(in_type != SNNQP_BITS || wt, SNNQP_EINVAL,
                 "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
@@ -539,17 +776,23 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                     a.nrn.vr == 0.0f;
   const bool pl = pool == 2;
   const unsigned gy = (unsigned)((g->Cout + 127) / 128);
-  if (in_type == SNNQP_BITS) {
-    if (fast && pl) launch_persistent(conv3x3_bits_kernel<true, true>, a, gy, st);
-    else if (fast) launch_persistent(conv3x3_bits_kernel<true, false>, a, gy, st);
-    else if (pl) launch_persistent(conv3x3_bits_kernel<false, true>, a, gy, st);
-    else launch_persistent(conv3x3_bits_kernel<false, false>, a, gy, st);
-  } else {
-    if (fast && pl) launch_persistent(conv3x3_u8c2_kernel<true, true>, a, gy, st);
-    else if (fast) launch_persistent(conv3x3_u8c2_kernel<true, false>, a, gy, st);
-    else if (pl) launch_persistent(conv3x3_u8c2_kernel<false, true>, a, gy, st);
-    else launch_persistent(conv3x3_u8c2_kernel<false, false>, a, gy, st);
-  }
+  // |acc| <= abs_sum_max * x_max; small enough -> dequantise through the LDS table
+  const int64_t xm = in_type == SNNQP_BITS ? 1 : x_max;
+  const int64_t bound = (int64_t)w->abs_sum_max * xm;
+  a.lut_bound = (fast && w->abs_sum_max > 0 && xm > 0 && bound <= LUT_CAP) ? (int32_t)bound : 0;
+  const bool lut = a.lut_bound > 0;
+#define SNNQP_CONV_LAUNCH(KERN)                                                    \
+  do {                                                                             \
+    if (fast && pl && lut) launch_persistent(KERN<true, true, true>, a, gy, st);    \
+    else if (fast && pl) launch_persistent(KERN<true, true, false>, a, gy, st);     \
+    else if (fast && lut) launch_persistent(KERN<true, false, true>, a, gy, st);    \
+    else if (fast) launch_persistent(KERN<true, false, false>, a, gy, st);          \
+    else if (pl) launch_persistent(KERN<false, true, false>, a, gy, st);            \
+    else launch_persistent(KERN<false, false, false>, a, gy, st);                   \
+  } while (0)
+  if (in_type == SNNQP_BITS) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel);
+  else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel);
+#undef SNNQP_CONV_LAUNCH
   SNNQP_CHECK_LAUNCH("conv3x3 mfma kernel");
   return SNNQP_OK;
 }

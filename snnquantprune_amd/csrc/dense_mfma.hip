@@ -47,6 +47,14 @@ __device__ __forceinline__ v4i expand16b(uint32_t b) {
   return o;
 }
 
+// Workgroup barrier ordering LDS traffic only (see conv3x3_mfma.hip): the K loop
+// keeps the next chunk's global loads in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int a_addr(int row, int c16) {
   return row * BK + ((c16 ^ (row & 15)) << 4);
 }
@@ -110,7 +118,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
 
   stage_load(0);
   stage_store(0);
-  __syncthreads();
+  lds_barrier();
   for (int c = 0; c < nchunks; ++c) {
     if (c + 1 < nchunks) stage_load(c + 1);
     if (wave_on) {
@@ -126,7 +134,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
       }
     }
     if (c + 1 < nchunks) stage_store((c + 1) & 1);
-    __syncthreads();
+    lds_barrier();
   }
 
   // int32 tile -> LDS [row][128]; C/D layout: col = lane & 31,
@@ -141,7 +149,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
         et[row * 128 + wave * 32 + n] = acc[r][i];
       }
   }
-  __syncthreads();
+  lds_barrier();
 
   // one (sample, feature) pair per thread and pass; 64 consecutive features of
   // one sample per wave, so a ballot is two output words

@@ -19,7 +19,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     hipStream_t st);
+                     int x_max, hipStream_t st);
 
 const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
                                    const snnqp_weight_t *w, const int8_t *wt,

@@ -20,6 +20,18 @@ inspect_f32_kernel(const float *__restrict__ x, int64_t n,
 }
 
 __global__ void __launch_bounds__(256)
+inspect_u8_kernel(const uint8_t *__restrict__ x, int64_t n, int32_t *__restrict__ flags) {
+  int32_t f = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint8_t v = x[i];
+    if (v > 1) f |= SNNQP_FLAG_GT_ONE;
+    if (v > 127) f |= SNNQP_FLAG_GT_127;
+  }
+  if (f) atomicOr(flags, f);
+}
+
+__global__ void __launch_bounds__(256)
 f32_to_u8_kernel(const float *__restrict__ x, uint8_t *__restrict__ y,
                  int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -148,6 +160,17 @@ int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
   hipLaunchKernelGGL(inspect_f32_kernel, dim3(grid_for(n)), dim3(256), 0,
                      (hipStream_t)stream, x, n, flags);
   SNNQP_CHECK_LAUNCH("inspect_f32_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_inspect_u8(const uint8_t *x, int64_t n, int32_t *flags,
+                     snnqp_stream_t stream) {
+  SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "inspect_u8: negative size");
+  if (n == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && flags, SNNQP_EINVAL, "inspect_u8: null argument");
+  hipLaunchKernelGGL(inspect_u8_kernel, dim3(grid_for(n)), dim3(256), 0,
+                     (hipStream_t)stream, x, n, flags);
+  SNNQP_CHECK_LAUNCH("inspect_u8_kernel");
   return SNNQP_OK;
 }
 

@@ -114,9 +114,11 @@ class Weight:
   L: float = 1.0
   m: float = 1.0
   wt: Optional[torch.Tensor] = None
+  abs_sum_max: int = 0      # max over outputs of sum_k |code| (bounds |acc|)
 
   def struct(self) -> L.WeightT:
-    return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m))
+    return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
+                     int(self.abs_sum_max))
 
   @property
   def is_int(self):
@@ -240,6 +242,32 @@ def inspect_f32(x: torch.Tensor) -> int:
   return int(flags.item())
 
 
+_u8_flag_cache = None
+
+
+def input_max_bound(x) -> int:
+  """Upper bound of an integer-typed activation: 1 for spikes; for uint8 tensors
+  1 / 127 / 255 from one device pass (cached per tensor version)."""
+  global _u8_flag_cache
+  if isinstance(x, PackedSpikes):
+    return 1
+  if x.dtype != torch.uint8:
+    return 0
+  if _u8_flag_cache is None:
+    from ._cache import TensorCache
+    _u8_flag_cache = TensorCache(16)
+  v = _u8_flag_cache.get((x,))
+  if v is None:
+    _require_gpu(x)
+    xc = x.contiguous()
+    flags = torch.zeros(1, dtype=torch.int32, device=x.device)
+    L.check(L.lib().snnqp_inspect_u8(_ptr(xc), xc.numel(), _ptr(flags), _stream()))
+    f = int(flags.item())
+    v = 255 if f & L.FLAG_GT_127 else (127 if f & L.FLAG_GT_ONE else 1)
+    _u8_flag_cache.put((x,), None, v)
+  return v
+
+
 def f32_to_u8(x: torch.Tensor) -> torch.Tensor:
   x = _f32c(x)
   _require_gpu(x)
@@ -344,7 +372,7 @@ def _tb_strides(x, T, B, time_major: bool, unit: int):
 def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
                      bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
                      want_u: bool = True, packed_out: bool = False, pool: int = 1,
-                     impl: int = L.IMPL_AUTO, time_major: bool = True):
+                     impl: int = L.IMPL_AUTO, time_major: bool = True, x_max: int = 0):
   """x [T, B, H, W, Cin] (or [B, T, ...] with time_major=False) ->
   (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout])."""
   xt, in_type = _in_desc(x)
@@ -373,7 +401,7 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
         _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
         _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
         _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
-        _stream()))
+        int(x_max), _stream()))
   return u_out, (PackedSpikes(s, geom.Cout) if packed_out else s)
 
 

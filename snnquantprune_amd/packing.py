@@ -48,7 +48,8 @@ class PackedKernel:
                                    want_fq=False, want_codes=True)
     if int(flags.item()) & (L.FLAG_CODE_OVERFLOW | L.FLAG_MASK_NOT_BINARY):
       return None
-    self._int = ops.Weight(L.W_I8, codes, d.L, d.m)
+    asm = int(codes.reshape(-1, codes.shape[-1]).to(torch.int32).abs().sum(0).max().item())
+    self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=asm)
     return self._int
 
   def float_weight(self) -> ops.Weight:
@@ -82,7 +83,7 @@ class PackedKernel:
         codes = codes.index_select(0, row_perm)
       codes = codes.contiguous()
       wt = ops.pack_codes_mfma(codes, n_pad) if codes.shape[0] % 32 == 0 else None
-      w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt)
+      w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max)
       self._wt[key] = w
     return w
 

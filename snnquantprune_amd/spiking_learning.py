@@ -279,6 +279,10 @@ class SpikingBlock(nn.Module):
       raise ValueError("QuantConv block expects [T, B, spatial..., C] inputs, got %s"
                        % (x.shape,))
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
+    x_max = ops.input_max_bound(x) if integer else 0
+    impl = self.impl
+    if x_max > 127 and impl == L.IMPL_AUTO:
+      impl = L.IMPL_GENERIC            # counts above 127 are not int8 MFMA operands
     T, B = (x.shape[0], x.shape[1]) if tm else (x.shape[1], x.shape[0])
     if nsp == 1 and not tm:
       raise NotImplementedError("batch-major input for 1-D convolution blocks")
@@ -292,13 +296,14 @@ class SpikingBlock(nn.Module):
     try:
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,
-                                      pool=self.pool, impl=self.impl, time_major=tm)
+                                      pool=self.pool, impl=impl, time_major=tm,
+                                      x_max=x_max)
     except L.SnnqpError as e:
-      if e.code != L.EUNSUPPORTED or self.pool != 2 or self.impl == L.IMPL_MFMA:
+      if e.code != L.EUNSUPPORTED or self.pool != 2 or impl == L.IMPL_MFMA:
         raise
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,
-                                      pool=1, impl=self.impl, time_major=tm)
+                                      pool=1, impl=impl, time_major=tm, x_max=x_max)
       s = ops.maxpool2x2(s)
     if nsp == 1:
       if isinstance(s, ops.PackedSpikes):
