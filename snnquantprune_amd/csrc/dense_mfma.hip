@@ -114,26 +114,46 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     }
   };
 
-  const v4i *wtile = (const v4i *)a.wt + ((int64_t)nb * a.KS) * 64 + lane;
-
-  stage_load(0);
-  stage_store(0);
-  lds_barrier();
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) stage_load(c + 1);
-    if (wave_on) {
-      const uint8_t *base = lds + (c & 1) * ABYTES;
-      const int ks_n = min(KSC, a.KS - c * KSC);
-      for (int ks = 0; ks < ks_n; ++ks) {
-        const v4i bf = wtile[(int64_t)(c * KSC + ks) * 64];
+  // B fragments of a whole chunk (KSC k-steps) are prefetched into registers one
+  // chunk ahead, next to the A words of that chunk: every global access of the K
+  // loop is issued a full chunk of MFMAs before its first use.
+  const v4i *wtile = (const v4i *)a.wt + ((int64_t)(wave_on ? nb : 0) * a.KS) * 64 + lane;
+  v4i bfA[KSC], bfB[KSC];
+  auto load_b = [&](v4i (&bf)[KSC], int chunk) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          const v4i av = *(const v4i *)(base + a_addr(r * 32 + n, ks * 2 + h));
-          acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf, acc[r], 0, 0, 0);
-        }
+    for (int ks = 0; ks < KSC; ++ks) {
+      const int kg = chunk * KSC + ks;
+      bf[ks] = kg < a.KS ? wtile[(int64_t)kg * 64] : v4i{0, 0, 0, 0};
+    }
+  };
+  auto compute = [&](const uint8_t *base, const v4i (&bf)[KSC]) {
+    if (!wave_on) return;
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const v4i av = *(const v4i *)(base + a_addr(r * 32 + n, ks * 2 + h));
+        acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[ks], acc[r], 0, 0, 0);
       }
     }
-    if (c + 1 < nchunks) stage_store((c + 1) & 1);
+  };
+
+  stage_load(0);
+  load_b(bfA, 0);
+  stage_store(0);
+  lds_barrier();
+  // chunks beyond K contribute zero B fragments and zero A bytes, so the loop
+  // runs over pairs of chunks without a tail case
+  for (int c = 0; c < nchunks; c += 2) {
+    stage_load(c + 1);
+    load_b(bfB, c + 1);
+    compute(lds, bfA);
+    stage_store(1);
+    lds_barrier();
+    stage_load(c + 2);
+    load_b(bfA, c + 2);
+    compute(lds + ABYTES, bfB);
+    stage_store(0);
     lds_barrier();
   }
 
