@@ -44,6 +44,16 @@ def flatten_channel_major(x):
   return x.reshape(x.shape[0], x.shape[1], -1).contiguous()
 
 
+def _layer_bits(cfg, i):
+  """Bit width of the i-th quantised layer: `config.quant.layer_bits[i]` when
+  given (mixed precision, BASELINE config C5), else `config.quant.bits`; every
+  layer has its own `bits` attribute in the reference (flax_qconv.py:89)."""
+  q = cfg.quant
+  if "layer_bits" in q and q.layer_bits is not None:
+    return int(q.layer_bits[i])
+  return q.bits
+
+
 def _require_eval(train):
   if train:
     raise NotImplementedError(
@@ -74,7 +84,7 @@ class DenseSNN(nn.Module):
     hidden = cfg.hidden if "hidden" in cfg else cfg.channels * 2 * 2
     layer = SpikingBlock(
         connection_fn=QuantDense(hidden, use_bias=False, dtype=self.dtype,
-                                 config=cfg.quant, bits=cfg.quant.bits,
+                                 config=cfg.quant, bits=_layer_bits(cfg, 0),
                                  g_scale=cfg.quant.g_scale),
         neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
         return_state=False, batch_major_input=True)
@@ -82,7 +92,7 @@ class DenseSNN(nn.Module):
     layer = SpikingBlock(
         connection_fn=QuantDense(self.num_classes * 10, use_bias=False,
                                  dtype=self.dtype, config=cfg.quant,
-                                 bits=cfg.quant.bits, g_scale=cfg.quant.g_scale),
+                                 bits=_layer_bits(cfg, 1), g_scale=cfg.quant.g_scale),
         neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
         return_state=False)
     _, x = layer(None, x)
@@ -110,7 +120,7 @@ class ConvDenseSNN(nn.Module):
           connection_fn=QuantConv(features=cfg.channels, kernel_size=(3, 3),
                                   padding=((1, 1), (1, 1)), use_bias=False,
                                   dtype=self.dtype, config=cfg.quant,
-                                  bits=cfg.quant.bits, g_scale=cfg.quant.g_scale),
+                                  bits=_layer_bits(cfg, i), g_scale=cfg.quant.g_scale),
           neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
           norm_fn=norm(),
           pool=2,                       # the reduce_window max of models.py:145-147
@@ -122,7 +132,7 @@ class ConvDenseSNN(nn.Module):
     layer = SpikingBlock(
         connection_fn=QuantDense(self.num_classes * 10, use_bias=False,
                                  dtype=self.dtype, config=cfg.quant,
-                                 bits=cfg.quant.bits, g_scale=cfg.quant.g_scale),
+                                 bits=_layer_bits(cfg, nblocks), g_scale=cfg.quant.g_scale),
         neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
         return_state=False)
     _, x = layer(None, x)

@@ -208,22 +208,23 @@ def dense_net_expected(o, c):
 
 
 def conv_net_case(T=4, B=2, hw=16, bits=4, p=0.9, random_bn=True, counts=False,
-                  gains=(4.0, 5.0, 6.0, 10.0)):
+                  gains=(4.0, 5.0, 6.0, 10.0), layer_bits=None, out=110):
   # gains for the tiny 16x16 topology (fan-in of the read-out is only 512)
-  v = syn.conv_net_variables(hw=hw, prune_p=p, random_bn=random_bn, gains=gains)
+  v = syn.conv_net_variables(hw=hw, prune_p=p, random_bn=random_bn, gains=gains, out=out)
   if counts:
     x = syn.poisson_counts((B, T, hw, hw, 2), 0.2, seed=951)
   else:
     x = syn.poisson_spikes((B, T, hw, hw, 2), 0.1, seed=951)
-  return {"vars": v, "x": x, "bits": bits}
+  return {"vars": v, "x": x, "bits": bits, "layer_bits": layer_bits}
 
 
 def conv_net_expected(o, c):
   p = c["vars"]["params"]
+  lb = c.get("layer_bits") or [c["bits"]] * 4
   r = o.conv3_dense_forward(
-      c["x"], [qweight_of(o, p["QuantConv_%d" % i], c["bits"]) for i in range(3)],
+      c["x"], [qweight_of(o, p["QuantConv_%d" % i], lb[i]) for i in range(3)],
       [bn_of(c["vars"], i) for i in range(3)],
-      qweight_of(o, p["QuantDense_0"], c["bits"]), mode="int")
+      qweight_of(o, p["QuantDense_0"], lb[3]), mode="int")
   out = {"pool%d_bits" % i: packbits_lastaxis(r["pool%d" % i]) for i in range(3)}
   out["dense_s"] = r["dense_s"].astype(np.uint8)
   out["logits"] = r["logits"]

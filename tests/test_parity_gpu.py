@@ -479,6 +479,27 @@ def test_conv_block_mfma_and_generic(dev, oracle, golden_dir, which):
   np.testing.assert_array_equal(_np(ua), eu)
 
 
+@pytest.mark.parametrize("T", [1, 2, 5, 33])
+def test_conv_block_pipeline_tails(dev, oracle, T):
+  """The t-pipelined MFMA kernels at odd / even / single step counts and across
+  the flush period of the LDS-staged spike words (32 steps): pooled rasters and
+  final membrane potentials bit-exact."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  for cin, hw in ((128, 8), (2, 16)):
+    c = cases.conv_block_case(T=T, B=2, hw=hw, cin=cin, seed=970 + T, gain=5.0 if cin > 2 else 4.0)
+    e = cases.conv_block_expected(oracle, c)
+    w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+    geom = ops.ConvGeom(hw, hw, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+    x = _t(c["x"], dev)
+    xin = x if cin == 2 else ops.pack_bits(x)
+    for pool, key in ((2, "pooled_bits"), (1, "s_bits")):
+      u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                  pool=pool, impl=L.IMPL_MFMA, x_max=ops.input_max_bound(xin))
+      np.testing.assert_array_equal(_np(s), e[key], err_msg="T=%d cin=%d pool=%d" % (T, cin, pool))
+      np.testing.assert_array_equal(_np(u), e["u"])
+
+
 def test_mfma_kernel_refuses_unsupported_shapes(dev):
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
@@ -561,6 +582,76 @@ def test_conv_dense_snn_with_event_counts(dev, oracle):
   (logits, _) = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None,
                             train=False, rng=None)
   np.testing.assert_array_equal(_np(logits), e["logits"])
+
+
+def test_mixed_precision_c5_like_model(dev, oracle):
+  """BASELINE config C5 composed from the same blocks: per-layer 2/4-bit weights,
+  95 % unstructured prune, 10 classes (read-out 100), odd T."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  lb = [2, 4, 2, 4]
+  c = cases.conv_net_case(T=7, B=3, hw=16, p=0.95, layer_bits=lb, out=100,
+                          gains=(8.0, 12.0, 14.0, 20.0))
+  e = cases.conv_net_expected(oracle, c)
+  assert np.all(e["rates"] > 0.005), e["rates"]
+  cfg = syn.make_config(bits=4, prune_percentage=0.95)
+  cfg.quant.layer_bits = lb
+  model = models.ConvDenseSNN(num_classes=10, config=cfg)
+  (logits, _), mut = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None,
+                                 train=False, rng=None, mutable=["intermediates"])
+  assert tuple(logits.shape) == (3, 10)
+  for i in range(3):
+    np.testing.assert_array_equal(_np(mut["intermediates"]["pool%d" % i][0]), e["pool%d_bits" % i])
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+
+
+def test_full_size_c2_against_oracle(dev, oracle):
+  """BASELINE config 2 at full size: 2048 -> 512 -> 110, 8-bit, 50 % magnitude
+  prune, T = 20, B = 256: both rasters and the logits bit-exact."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.dense_net_case(True, T=20, B=256, K=2048, hidden=512)
+  e = cases.dense_net_expected(oracle, c)
+  assert 0.01 < e["s1"].mean() < 0.3 and 0.01 < e["s2"].mean() < 0.3
+  cfg = syn.make_config(bits=8, prune_percentage=0.5, hidden=512)
+  model = models.DenseSNN(num_classes=11, config=cfg)
+  (logits, _), mut = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None,
+                                 train=False, rng=None, mutable=["intermediates"])
+  np.testing.assert_array_equal(_np(mut["intermediates"]["dense2_out"][0].to_dense()).astype(np.uint8),
+                                e["s2"])
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+
+
+def test_prepare_params_masks_and_ac(dev, oracle):
+  """Mask + a, c construction (train_inpt_spikingjelly.py:147-223) vs the oracle."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import prune_utils, synthetic as syn
+  from snnquantprune_amd.quant import gaussian_init
+  v = syn.conv_net_variables(hw=16, prune_p=-1.0)
+  params = nn.tree_from_numpy(v["params"], dev)
+  names = [k for k in params if k.startswith("Quant")]
+  kernels = [v["params"][k]["kernel"] for k in names]
+  loc = prune_utils.update_prune_mask(params, 0.75)
+  for k in names:
+    np.testing.assert_array_equal(_np(loc[k]["prune_0"]["mask"]),
+                                  oracle.local_prune_mask(v["params"][k]["kernel"], 0.75))
+  glob = prune_utils.update_global_prune_mask(params, 0.6)
+  for k, m in zip(names, oracle.global_prune_masks(kernels, 0.6)):
+    np.testing.assert_array_equal(_np(glob[k]["prune_0"]["mask"]), m)
+  q = prune_utils.update_quant_params(params, gaussian_init, 4)
+  for k in names:
+    a = float(q[k]["DuQ_0"]["a"])
+    assert q[k]["DuQ_0"]["a"].shape == (1,)
+    np.testing.assert_allclose(a, float(oracle.gaussian_init(v["params"][k]["kernel"], 4)), rtol=2e-6)
+    assert float(q[k]["DuQ_0"]["c"]) == a
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  cfg.quant.prune_global = True
+  cfg.quant.start_epoch = -1
+  full = prune_utils.prepare_params(params, cfg)
+  tot = sum(int(np.prod(k.shape)) for k in kernels)
+  kept = sum(float(full[k]["prune_0"]["mask"].sum()) for k in names)
+  assert kept == tot - int(tot * 0.9)
+  assert "BatchNorm_0" in full and "scale" in full["BatchNorm_0"]
 
 
 def test_full_size_c3_layers_against_oracle(dev, oracle):
