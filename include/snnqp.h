@@ -226,6 +226,19 @@ int snnqp_batchnorm_forward(const float *x, int64_t rows, int32_t C,
 int snnqp_maxpool2x2(const void *x, int type, int64_t NB, int32_t H, int32_t W,
                      int32_t C, void *y, snnqp_stream_t stream);
 
+/* ---- TCJA attention pieces (examples/tcja/models.py:41-99) ---------------------
+ * replaces: jnp.mean(x_seq, axis=[2, 3]) (:42): x [NB][HW][C] (F32 or BITS) ->
+ *           y float32 [NB][C], sequential float32 sum over pixels / HW. */
+int snnqp_spatial_mean(const void *x, int type, int64_t NB, int32_t HW, int32_t C,
+                       float *y, snnqp_stream_t stream);
+/* replaces: jax.nn.sigmoid(conv_c_out * conv_t_out) (:95): g = sigmoid(a * b),
+ *           float32 product, logistic in float64 rounded once. */
+int snnqp_sigmoid_gate(const float *a, const float *b, int64_t n, float *g,
+                       snnqp_stream_t stream);
+/* replaces: x_seq * out[:, :, None, None, :] (:97): y[img][p][c] = x * g[img][c]. */
+int snnqp_apply_gate(const void *x, int type, const float *g, int64_t NB, int32_t HW,
+                     int32_t C, float *y, snnqp_stream_t stream);
+
 /* replaces: the rate "vote", examples/tcja/models.py:253-255
  * s [T][B][N] (F32 or BITS) -> logits float32 [B][N / group]:
  * mean over T (sequential float32 sum / T), then mean over `group` neurons. */

@@ -719,6 +719,58 @@ def conv3_dense_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
   return out
 
 
+def tcja(x_seq, qw_t: QWeight, qw_c: QWeight):
+  """TCJA gate, examples/tcja/models.py:41-99, on x_seq [T, B, H, W, C].
+
+  Channel means are sequential float32 sums / (H*W); the two 1-D QuantConvs
+  (k = 4, SAME) run in 'fseq' mode on their real-valued inputs; the logistic is
+  evaluated in float64 on the float32 product and rounded once."""
+  x_seq = np.asarray(x_seq, dtype=F32)
+  T, B, H, W, C = x_seq.shape
+  acc = np.zeros((T, B, C), F32)
+  flat = x_seq.reshape(T, B, H * W, C)
+  for p in range(H * W):
+    acc = acc + flat[:, :, p]
+  m = acc / F32(H * W)                                   # [T, B, C]
+  x = np.ascontiguousarray(np.transpose(m, (1, 0, 2)))   # [B, T, C]
+  x_c = np.ascontiguousarray(np.transpose(x, (0, 2, 1)))  # [B, C, T]
+  conv_t = quant_conv(x_c, qw_t, None, "SAME", mode="fseq")   # [B, C, T]
+  conv_c = quant_conv(x, qw_c, None, "SAME", mode="fseq")     # [B, T, C]
+  conv_t = np.transpose(conv_t, (2, 0, 1))               # [T, B, C]
+  conv_c = np.transpose(conv_c, (1, 0, 2))               # [T, B, C]
+  z = (conv_c * conv_t).astype(F32)
+  gate = (1.0 / (1.0 + np.exp(-z.astype(np.float64)))).astype(F32)
+  return (x_seq * gate[:, :, None, None, :]).astype(F32), gate
+
+
+def cextnet_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
+                    tcja_qw: Sequence[Tuple[QWeight, QWeight]], dense_qw: Sequence[QWeight],
+                    neuron_cfg=None, group=10):
+  """Full CextNet (models.py:31-257), eval.  conv_qw: the five 3x3 kernels;
+  tcja_qw: [(conv_t, conv_c)] x 2; dense_qw: the two dense kernels.  Integer
+  mode while activations are spikes, 'fseq' once they are real-valued."""
+  x = np.swapaxes(np.asarray(inputs), 0, 1)
+  out = {}
+  for i in range(3):
+    _, s = conv_block(x, conv_qw[i], bns[i], neuron_cfg, "int")
+    x = max_pool_2x2(s)
+    out["pool%d" % i] = x
+  mode = "int"
+  for i in range(2):
+    _, s = conv_block(x, conv_qw[3 + i], bns[3 + i], neuron_cfg, mode)
+    out["conv_t_%d" % i] = s
+    y, gate = tcja(s, *tcja_qw[i])
+    out["gate%d" % i] = gate
+    x = max_pool_2x2(y)
+    mode = "fseq"
+  xf = flatten_channel_major(x)
+  _, s1 = dense_block(xf, dense_qw[0], neuron_cfg, "fseq")
+  _, s2 = dense_block(s1, dense_qw[1], neuron_cfg, "int")
+  out["dense1_s"], out["dense2_s"] = s1, s2
+  out["logits"] = vote(s2, group)
+  return out
+
+
 # ---------------------------------------------------------------------------
 # Synthetic inputs shared by tests and bench (SURVEY.md section 8d)
 # ---------------------------------------------------------------------------

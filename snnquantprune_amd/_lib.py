@@ -79,6 +79,11 @@ _PROTOTYPES = {
                                         c_void_p, c_void_p]),
     "snnqp_maxpool2x2": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_int32,
                                  c_void_p, c_void_p]),
+    "snnqp_spatial_mean": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_void_p,
+                                   c_void_p]),
+    "snnqp_sigmoid_gate": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "snnqp_apply_gate": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_int32,
+                                 c_void_p, c_void_p]),
     "snnqp_vote": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int32, c_int32,
                            c_void_p, c_void_p]),
 }

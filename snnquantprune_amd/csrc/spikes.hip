@@ -141,6 +141,65 @@ vote_kernel(const void *__restrict__ s, int32_t T, int32_t B, int32_t N,
   }
 }
 
+// TCJA pieces (examples/tcja/models.py:41-99) ---------------------------------
+// mean over the HW pixels of each (image, channel): one thread per (image, c),
+// sequential float32 sum over pixels (exact integer count for spikes) / HW.
+template <bool BITS>
+__global__ void __launch_bounds__(256)
+spatial_mean_kernel(const void *__restrict__ x, int64_t NB, int32_t HW, int32_t C,
+                    float *__restrict__ y) {
+  const int32_t CW = (C + 31) / 32;
+  const int64_t n = NB * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t img = i / C;
+    const int32_t c = (int32_t)(i - img * C);
+    float acc = 0.0f;
+    for (int32_t p = 0; p < HW; ++p) {
+      float v;
+      if (BITS)
+        v = (float)((((const uint32_t *)x)[(img * HW + p) * CW + (c >> 5)] >> (c & 31)) & 1u);
+      else
+        v = ((const float *)x)[(img * HW + p) * C + c];
+      acc = acc + v;
+    }
+    y[i] = acc / (float)HW;
+  }
+}
+
+// gate = sigmoid(a * b): float32 product, logistic evaluated in float64 and
+// rounded once (the array is tiny: [T, B, C]).
+__global__ void __launch_bounds__(256)
+sigmoid_gate_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
+                    float *__restrict__ g) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float z = a[i] * b[i];
+    g[i] = (float)(1.0 / (1.0 + exp(-(double)z)));
+  }
+}
+
+// y[img][p][c] = x[img][p][c] * g[img][c]   (x spikes or float32)
+template <bool BITS>
+__global__ void __launch_bounds__(256)
+apply_gate_kernel(const void *__restrict__ x, const float *__restrict__ g, int64_t NB,
+                  int32_t HW, int32_t C, float *__restrict__ y) {
+  const int32_t CW = (C + 31) / 32;
+  const int64_t n = NB * HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / C;
+    const int32_t c = (int32_t)(i - pix * C);
+    const int64_t img = pix / HW;
+    float v;
+    if (BITS)
+      v = (float)((((const uint32_t *)x)[pix * CW + (c >> 5)] >> (c & 31)) & 1u);
+    else
+      v = ((const float *)x)[i];
+    y[i] = v * g[img * C + c];
+  }
+}
+
 static inline int grid_for(int64_t n) {
   const int64_t b = ceil_div64(n, 256);
   return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
@@ -235,6 +294,52 @@ int snnqp_maxpool2x2(const void *x, int type, int64_t NB, int32_t H, int32_t W,
                        NB, H, W, CW, (uint32_t *)y);
   }
   SNNQP_CHECK_LAUNCH("maxpool kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_spatial_mean(const void *x, int type, int64_t NB, int32_t HW, int32_t C,
+                       float *y, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(NB >= 0 && HW > 0 && C > 0, SNNQP_EINVAL, "spatial_mean: bad shape");
+  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
+                "spatial_mean: type must be F32 or BITS");
+  if (NB == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && y, SNNQP_EINVAL, "spatial_mean: null argument");
+  if (type == SNNQP_BITS)
+    hipLaunchKernelGGL(spatial_mean_kernel<true>, dim3(grid_for(NB * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, NB, HW, C, y);
+  else
+    hipLaunchKernelGGL(spatial_mean_kernel<false>, dim3(grid_for(NB * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, NB, HW, C, y);
+  SNNQP_CHECK_LAUNCH("spatial_mean_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_sigmoid_gate(const float *a, const float *b, int64_t n, float *g,
+                       snnqp_stream_t stream) {
+  SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "sigmoid_gate: negative size");
+  if (n == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(a && b && g, SNNQP_EINVAL, "sigmoid_gate: null argument");
+  hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(grid_for(n)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, n, g);
+  SNNQP_CHECK_LAUNCH("sigmoid_gate_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_apply_gate(const void *x, int type, const float *g, int64_t NB, int32_t HW,
+                     int32_t C, float *y, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(NB >= 0 && HW > 0 && C > 0, SNNQP_EINVAL, "apply_gate: bad shape");
+  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
+                "apply_gate: type must be F32 or BITS");
+  if (NB == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && g && y, SNNQP_EINVAL, "apply_gate: null argument");
+  const int64_t n = NB * HW * C;
+  if (type == SNNQP_BITS)
+    hipLaunchKernelGGL(apply_gate_kernel<true>, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, x, g, NB, HW, C, y);
+  else
+    hipLaunchKernelGGL(apply_gate_kernel<false>, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, x, g, NB, HW, C, y);
+  SNNQP_CHECK_LAUNCH("apply_gate_kernel");
   return SNNQP_OK;
 }
 

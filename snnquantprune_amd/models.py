@@ -2,6 +2,9 @@
 with the same call signature as the reference's CextNet
 (examples/tcja/models.py:31-257):
 
+  CextNet       the reference's full DVS128 model: 3 conv blocks, 2 conv blocks each
+                followed by a TCJA attention gate, channel-major flatten, two
+                dense blocks, vote (models.py:31-257)
   DenseSNN      configs C1 / C2: the two-layer head of CextNet,
                 QuantDense(hidden)+LIF -> QuantDense(num_classes*10)+LIF -> vote
                 (models.py:200-255)
@@ -22,6 +25,7 @@ import torch
 
 from . import linen as nn
 from . import ops
+from . import packing
 from .flax_qconv import QuantConv
 from .flax_qdense import QuantDense
 from .spiking_learning import SpikingBlock
@@ -137,4 +141,81 @@ class ConvDenseSNN(nn.Module):
         return_state=False)
     _, x = layer(None, x)
     self.sow("intermediates", "dense_out", x)
+    return ops.vote(x, 10), None
+
+
+class CextNet(nn.Module):
+  """TCJA-SNN, examples/tcja/models.py:31-257 (eval forward).
+
+  inputs [B, T, H, W, 2] -> (logits [B, num_classes], None).  Variables:
+  QuantConv_0..8, BatchNorm_0..4, QuantDense_0..1 in the reference's order
+  (tcja_load_pretrained_weights.py:19-36).  After the first TCJA gate the
+  activations are real-valued: those layers use the float (fmaf-chain) kernels
+  with the fake-quantised weights, as the reference does."""
+  num_classes: int = 11
+  dtype: Any = torch.float32
+  config: dict = nn.FrozenConfigDict({})
+
+  def __call__(self, inputs, trgt=None, train: bool = False, rng: Any = None,
+               u_state=None, online=False):
+    _require_eval(train)
+    cfg = self.config
+
+    def qconv1d(features, x):
+      return QuantConv(features=features, kernel_size=[4], padding="SAME", use_bias=False,
+                       dtype=self.dtype, config=cfg.quant, bits=cfg.quant.bits,
+                       g_scale=cfg.quant.g_scale)(x)
+
+    def TCJA(x_seq, i=0):                               # models.py:41-99
+      T, C = x_seq.shape[0], x_seq.shape[-1]
+      m = ops.spatial_mean(x_seq)                       # [T, B, C]
+      x = m.transpose(0, 1).contiguous()                # [B, T, C]
+      x_c = x.transpose(1, 2).contiguous()              # [B, C, T]
+      with packing.integer_inputs(False):               # channel means are real-valued
+        conv_t_out = qconv1d(T, x_c)                    # [B, C, T]
+        conv_c_out = qconv1d(C, x)                      # [B, T, C]
+      conv_t_out = conv_t_out.permute(2, 0, 1).contiguous()   # [T, B, C]
+      conv_c_out = conv_c_out.transpose(0, 1).contiguous()    # [T, B, C]
+      gate = ops.sigmoid_gate(conv_c_out, conv_t_out)
+      self.sow("intermediates", "tcja_gate_%d" % i, gate)
+      return ops.apply_gate(x_seq, gate)                # [T, B, H, W, C] float32
+
+    def conv_block(x, first, pool):
+      layer = SpikingBlock(
+          connection_fn=QuantConv(features=cfg.channels, kernel_size=(3, 3),
+                                  padding=((1, 1), (1, 1)), use_bias=False,
+                                  dtype=self.dtype, config=cfg.quant, bits=cfg.quant.bits,
+                                  g_scale=cfg.quant.g_scale),
+          neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
+          norm_fn=nn.BatchNorm(use_running_average=not train, momentum=0.9, epsilon=1e-5,
+                               use_bias=True, use_scale=True, dtype=self.dtype),
+          pool=pool, return_state=False, batch_major_input=first)
+      return layer(None, x)[1]
+
+    def dense_block(x, features):
+      layer = SpikingBlock(
+          connection_fn=QuantDense(features, use_bias=False, dtype=self.dtype,
+                                   config=cfg.quant, bits=cfg.quant.bits,
+                                   g_scale=cfg.quant.g_scale),
+          neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype), return_state=False)
+      return layer(None, x)[1]
+
+    x = _as_input(inputs)
+    for i in range(3):                                  # models.py:111-147
+      x = conv_block(x, first=(i == 0), pool=2)
+      self.sow("intermediates", "pool%d" % i, x)
+    real_valued = False
+    for i in range(2):                                  # models.py:149-187
+      with packing.integer_inputs(not real_valued):
+        x = conv_block(x, first=False, pool=1)          # TCJA needs the unpooled raster
+      self.sow("intermediates", "conv_t_%d" % i, x)
+      x = TCJA(x, i)
+      real_valued = True
+      x = ops.maxpool2x2(x)
+    x = flatten_channel_major(x)                        # models.py:189-190
+    with packing.integer_inputs(False):
+      x = dense_block(x, cfg.channels * 2 * 2)          # models.py:200-216
+    self.sow("intermediates", "dense1_out", x)
+    x = dense_block(x, self.num_classes * 10)           # models.py:231-246
+    self.sow("intermediates", "dense2_out", x)
     return ops.vote(x, 10), None

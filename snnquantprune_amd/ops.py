@@ -502,6 +502,51 @@ def maxpool2x2(x):
   return y
 
 
+def spatial_mean(x) -> torch.Tensor:
+  """[..., H, W, C] (float32 or PackedSpikes) -> float32 [..., C] (mean over H, W)."""
+  if isinstance(x, PackedSpikes):
+    t, typ, C = x.bits, L.BITS, x.channels
+  else:
+    t, typ, C = _f32c(x), L.F32, x.shape[-1]
+  _require_gpu(t)
+  lead = tuple(t.shape[:-3])
+  HW = t.shape[-3] * t.shape[-2]
+  NB = 1
+  for d in lead:
+    NB *= d
+  y = torch.empty(lead + (C,), dtype=torch.float32, device=t.device)
+  L.check(L.lib().snnqp_spatial_mean(_ptr(t), typ, NB, HW, C, _ptr(y), _stream()))
+  return y
+
+
+def sigmoid_gate(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+  a, b = _f32c(a), _f32c(b)
+  _require_gpu(a, b)
+  assert a.shape == b.shape
+  g = torch.empty_like(a)
+  L.check(L.lib().snnqp_sigmoid_gate(_ptr(a), _ptr(b), a.numel(), _ptr(g), _stream()))
+  return g
+
+
+def apply_gate(x, g: torch.Tensor) -> torch.Tensor:
+  """x [..., H, W, C] * g [..., C] broadcast over H, W -> float32."""
+  if isinstance(x, PackedSpikes):
+    t, typ, C = x.bits, L.BITS, x.channels
+  else:
+    t, typ, C = _f32c(x), L.F32, x.shape[-1]
+  g = _f32c(g)
+  _require_gpu(t, g)
+  lead = tuple(t.shape[:-3])
+  H, W = t.shape[-3], t.shape[-2]
+  assert tuple(g.shape) == lead + (C,), (g.shape, lead, C)
+  NB = 1
+  for d in lead:
+    NB *= d
+  y = torch.empty(lead + (H, W, C), dtype=torch.float32, device=t.device)
+  L.check(L.lib().snnqp_apply_gate(_ptr(t), typ, _ptr(g), NB, H * W, C, _ptr(y), _stream()))
+  return y
+
+
 def vote(s, group: int = 10) -> torch.Tensor:
   """spikes [T, B, N] -> logits float32 [B, N // group] (models.py:253-255)."""
   if isinstance(s, PackedSpikes):

@@ -25,6 +25,22 @@ from .quant import QuantDesc
 AUTO_INTEGER_INPUTS = True
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def integer_inputs(enabled: bool):
+  """Scoped override of AUTO_INTEGER_INPUTS (e.g. False around layers whose
+  inputs are real-valued by construction, so the arithmetic path never depends
+  on the data)."""
+  global AUTO_INTEGER_INPUTS
+  old, AUTO_INTEGER_INPUTS = AUTO_INTEGER_INPUTS, enabled
+  try:
+    yield
+  finally:
+    AUTO_INTEGER_INPUTS = old
+
+
 class PackedKernel:
   def __init__(self, kernel: torch.Tensor, desc: Optional[QuantDesc],
                mask: Optional[torch.Tensor]):

@@ -105,6 +105,31 @@ def conv_net_variables(channels=128, cin=2, nblocks=3, hw=128, out=110,
   return {"params": params, "batch_stats": stats}
 
 
+def cextnet_variables(channels=128, frames=20, hw=128, out=110, prune_p=0.9,
+                      gains=(4.0, 5.0, 5.0, 6.0, 12.0, 6.0, 6.0, 16.0, 8.0), random_bn=False,
+                      seed=WEIGHT_SEED):
+  """Variables of models.CextNet in the reference's naming and order
+  (tcja_load_pretrained_weights.py:19-36): QuantConv_0..2 (3x3), QuantConv_3 (3x3),
+  QuantConv_4 / 5 (TCJA over T / over C), QuantConv_6 (3x3), QuantConv_7 / 8 (TCJA),
+  BatchNorm_0..4, QuantDense_0 (flatten -> 4 * channels), QuantDense_1 (-> out).
+  gains: conv0..4, tcja (both), dense0, dense1."""
+  params, stats = {}, {}
+  shapes = {0: (3, 3, 2, channels), 1: (3, 3, channels, channels), 2: (3, 3, channels, channels),
+            3: (3, 3, channels, channels), 4: (4, frames, frames), 5: (4, channels, channels),
+            6: (3, 3, channels, channels), 7: (4, frames, frames), 8: (4, channels, channels)}
+  g = {0: gains[0], 1: gains[1], 2: gains[2], 3: gains[3], 6: gains[4], 4: gains[5], 5: gains[6],
+       7: gains[5], 8: gains[6]}
+  for i in range(9):
+    params["QuantConv_%d" % i] = quant_leaf(shapes[i], g[i], seed + i, True, prune_p)
+  for i in range(5):
+    p, s = bn_leaf(channels, random_bn, seed + 100 + i)
+    params["BatchNorm_%d" % i], stats["BatchNorm_%d" % i] = p, s
+  flat = (hw // 32) * (hw // 32) * channels
+  params["QuantDense_0"] = quant_leaf((flat, channels * 4), gains[7], seed + 50, True, prune_p)
+  params["QuantDense_1"] = quant_leaf((channels * 4, out), gains[8], seed + 51, True, prune_p)
+  return {"params": params, "batch_stats": stats}
+
+
 def make_config(bits=4, prune_percentage=0.9, channels=128, tau=2.0, quantized=True,
                 **extra):
   """ConfigDict shaped like examples/tcja/configs/prune_quant_joint.py."""

@@ -233,6 +233,30 @@ def conv_net_expected(o, c):
   return out
 
 
+def cextnet_case(T=4, B=2, hw=64, bits=4, p=0.9):
+  v = syn.cextnet_variables(frames=T, hw=hw, prune_p=p, random_bn=True)
+  x = syn.poisson_spikes((B, T, hw, hw, 2), 0.1, seed=991)
+  return {"vars": v, "x": x, "bits": bits}
+
+
+def cextnet_expected(o, c):
+  p, b = c["vars"]["params"], c["bits"]
+  r = o.cextnet_forward(
+      c["x"], [qweight_of(o, p["QuantConv_%d" % i], b) for i in (0, 1, 2, 3, 6)],
+      [bn_of(c["vars"], i) for i in range(5)],
+      [(qweight_of(o, p["QuantConv_4"], b), qweight_of(o, p["QuantConv_5"], b)),
+       (qweight_of(o, p["QuantConv_7"], b), qweight_of(o, p["QuantConv_8"], b))],
+      [qweight_of(o, p["QuantDense_0"], b), qweight_of(o, p["QuantDense_1"], b)])
+  out = {"pool%d_bits" % i: packbits_lastaxis(r["pool%d" % i]) for i in range(3)}
+  for i in range(2):
+    out["conv_t_%d_bits" % i] = packbits_lastaxis(r["conv_t_%d" % i])
+    out["gate%d" % i] = r["gate%d" % i]
+  out["dense1_s"] = r["dense1_s"].astype(np.uint8)
+  out["dense2_s"] = r["dense2_s"].astype(np.uint8)
+  out["logits"] = r["logits"]
+  return out
+
+
 GOLDEN = {
     "quant": lambda o: quant_expected(o),
     "dense_block": lambda o: dense_block_expected(o, dense_block_case()),
@@ -245,6 +269,7 @@ GOLDEN = {
     "dense_net_c1": lambda o: dense_net_expected(o, dense_net_case(False)),
     "dense_net_c2": lambda o: dense_net_expected(o, dense_net_case(True)),
     "conv_net_c3_tiny": lambda o: conv_net_expected(o, conv_net_case()),
+    "cextnet_tiny": lambda o: cextnet_expected(o, cextnet_case()),
 }
 for _name in [g[0] for g in REF_CONV_GEOMS]:
   GOLDEN["conv_geom_" + _name] = (

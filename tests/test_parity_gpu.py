@@ -584,6 +584,45 @@ def test_conv_dense_snn_with_event_counts(dev, oracle):
   np.testing.assert_array_equal(_np(logits), e["logits"])
 
 
+def test_full_cextnet_with_tcja(dev, oracle, golden_dir):
+  """The reference's full DVS128 model (5 conv blocks, 2 TCJA gates, 2 dense
+  blocks, models.py:31-257) at 64x64 input: spike rasters bit-exact throughout,
+  including the layers fed by real-valued (gated) activations; gate values equal
+  to the oracle's float64-logistic to the last bit."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.cextnet_case()
+  g = _golden(golden_dir, "cextnet_tiny")
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  model = models.CextNet(num_classes=11, config=cfg)
+  x = _t(c["x"], dev)
+  iv = model.init({"params": 0}, x, rng=None, trgt=None, train=False)
+  assert sorted(iv["params"]) == sorted(["QuantConv_%d" % i for i in range(9)] +
+                                        ["BatchNorm_%d" % i for i in range(5)] +
+                                        ["QuantDense_0", "QuantDense_1"])
+  assert tuple(iv["params"]["QuantConv_4"]["kernel"].shape) == (4, 4, 4)        # over T
+  assert tuple(iv["params"]["QuantConv_5"]["kernel"].shape) == (4, 128, 128)    # over C
+  assert tuple(iv["params"]["QuantDense_0"]["kernel"].shape) == (2 * 2 * 128, 512)
+  (logits, _), mut = model.apply(nn.tree_from_numpy(c["vars"], dev), x, trgt=None, train=False,
+                                 rng=None, mutable=["intermediates"])
+  im = mut["intermediates"]
+  for i in range(3):
+    np.testing.assert_array_equal(_np(im["pool%d" % i][0]), g["pool%d_bits" % i])
+  for i in range(2):
+    np.testing.assert_array_equal(_np(im["tcja_gate_%d" % i][0]), g["gate%d" % i])
+    s = im["conv_t_%d" % i][0]
+    s = _np(s) if hasattr(s, "bits") else packbits_lastaxis(_np(s))
+    np.testing.assert_array_equal(s, g["conv_t_%d_bits" % i])
+  d1 = im["dense1_out"][0]
+  d1 = d1.to_dense() if hasattr(d1, "to_dense") else d1
+  np.testing.assert_array_equal(_np(d1).astype(np.uint8), g["dense1_s"])
+  d2 = im["dense2_out"][0]
+  d2 = d2.to_dense() if hasattr(d2, "to_dense") else d2
+  np.testing.assert_array_equal(_np(d2).astype(np.uint8), g["dense2_s"])
+  np.testing.assert_array_equal(_np(logits), g["logits"])
+  assert 0.02 < g["dense1_s"].mean() < 0.5 and 0.02 < g["dense2_s"].mean() < 0.5
+
+
 def test_mixed_precision_c5_like_model(dev, oracle):
   """BASELINE config C5 composed from the same blocks: per-layer 2/4-bit weights,
   95 % unstructured prune, 10 classes (read-out 100), odd T."""
