@@ -239,6 +239,22 @@ int snnqp_sigmoid_gate(const float *a, const float *b, int64_t n, float *g,
 int snnqp_apply_gate(const void *x, int type, const float *g, int64_t NB, int32_t HW,
                      int32_t C, float *y, snnqp_stream_t stream);
 
+/* ---- event front end and probes ------------------------------------------------
+ * replaces: preprocess_data_number, examples/input_pipeline.py:142-219
+ *           (split_by = "number"): N time-ordered events (x, y, polarity) ->
+ *           T frames of N // T events (the last takes the remainder), counts per
+ *           pixel and polarity (channel 0 = polarity 0).  counts int32
+ *           [T][H][W][2] (zeroed here); frames_u8 optional saturated copy.
+ *           Coordinates are divided by `scale` (config.resolution_scale). */
+int snnqp_events_to_frames(const int32_t *ex, const int32_t *ey, const int32_t *ep,
+                           int64_t N, int32_t T, int32_t H, int32_t W, float scale,
+                           int32_t *counts, uint8_t *frames_u8, snnqp_stream_t stream);
+/* replaces: the activation-density probes sown at examples/tcja/models.py:128-142
+ *           (consumed by examples/sparsity.py:143-170): non-zero count of each of
+ *           NB slices of n elements (C innermost; F32 or BITS). */
+int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int32_t *nnz,
+                  snnqp_stream_t stream);
+
 /* replaces: the rate "vote", examples/tcja/models.py:253-255
  * s [T][B][N] (F32 or BITS) -> logits float32 [B][N / group]:
  * mean over T (sequential float32 sum / T), then mean over `group` neurons. */

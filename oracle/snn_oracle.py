@@ -719,6 +719,33 @@ def conv3_dense_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
   return out
 
 
+def events_to_frames(x, y, p, T, H, W, scale=1.0):
+  """preprocess_data_number, examples/input_pipeline.py:142-219 (split_by 'number'):
+  equal-count slices of the time-ordered events, bincount per pixel and polarity."""
+  x, y, p = np.asarray(x), np.asarray(y), np.asarray(p)
+  n = x.shape[0]
+  di = n // T
+  frames = np.zeros((T, 2, H * W), np.int32)
+  for i in range(T):
+    lo = i * di
+    hi = lo + di if i < T - 1 else n
+    xs = np.floor(x[lo:hi].astype(F32) / F32(scale)).astype(np.int64)
+    ys = np.floor(y[lo:hi].astype(F32) / F32(scale)).astype(np.int64)
+    ps = p[lo:hi]
+    for j, mask in enumerate((ps == 0, ps != 0)):
+      pos = ys[mask] * W + xs[mask]
+      frames[i, j] += np.bincount(pos, minlength=H * W)[:H * W].astype(np.int32)
+  return np.transpose(frames.reshape(T, 2, H, W), (0, 2, 3, 1))
+
+
+def density(x, lead_dims=2):
+  """sparse_nums of examples/tcja/models.py:128-131."""
+  x = np.asarray(x)
+  lead = x.shape[:lead_dims]
+  flat = x.reshape(lead + (-1,))
+  return (np.sum(flat != 0, axis=-1) / F32(flat.shape[-1])).astype(F32)
+
+
 def tcja(x_seq, qw_t: QWeight, qw_c: QWeight):
   """TCJA gate, examples/tcja/models.py:41-99, on x_seq [T, B, H, W, C].
 

@@ -84,6 +84,9 @@ _PROTOTYPES = {
     "snnqp_sigmoid_gate": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_apply_gate": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int32, c_int32,
                                  c_void_p, c_void_p]),
+    "snnqp_events_to_frames": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                       c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "snnqp_density": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "snnqp_vote": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int32, c_int32,
                            c_void_p, c_void_p]),
 }

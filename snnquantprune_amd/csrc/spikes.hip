@@ -200,6 +200,52 @@ apply_gate_kernel(const void *__restrict__ x, const float *__restrict__ g, int64
   }
 }
 
+// Event front end (examples/input_pipeline.py:142-219, split_by = "number"):
+// N time-ordered events -> T frames of N // T events each (the last takes the
+// remainder), each a per-pixel, per-polarity count.  counts: int32 [T][H][W][2].
+__global__ void __launch_bounds__(256)
+events_to_frames_kernel(const int32_t *__restrict__ ex, const int32_t *__restrict__ ey,
+                        const int32_t *__restrict__ ep, int64_t N, int32_t T, int32_t H,
+                        int32_t W, float scale, int32_t *__restrict__ counts) {
+  const int64_t di = N / T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t f = di > 0 ? i / di : T - 1;
+    if (f > T - 1) f = T - 1;
+    const int32_t x = (int32_t)floorf((float)ex[i] / scale);
+    const int32_t y = (int32_t)floorf((float)ey[i] / scale);
+    if (x < 0 || x >= W || y < 0 || y >= H) continue;
+    const int32_t c = ep[i] == 0 ? 0 : 1;            // mask[0] = (p == 0), :180-183
+    atomicAdd(&counts[((f * H + y) * W + x) * 2 + c], 1);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+i32_to_u8_sat_kernel(const int32_t *__restrict__ x, uint8_t *__restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (uint8_t)min(max(x[i], 0), 255);
+}
+
+// Activation density probe (examples/tcja/models.py:128-142): fraction of non-zero
+// entries of each of the NB leading slices of n elements.  One wave per slice chunk.
+template <bool BITS>
+__global__ void __launch_bounds__(256)
+density_kernel(const void *__restrict__ x, int64_t NB, int64_t n, int32_t C,
+               int32_t *__restrict__ nnz) {
+  // BITS: the slice is n / C rows of ceil(C / 32) words (padding bits are zero)
+  const int64_t units = BITS ? (n / C) * ((C + 31) / 32) : n;
+  const int64_t total = NB * units;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t img = i / units;
+    int32_t c;
+    if (BITS) c = __popc(((const uint32_t *)x)[i]);
+    else c = ((const float *)x)[i] != 0.0f;
+    if (c) atomicAdd(&nnz[img], c);
+  }
+}
+
 static inline int grid_for(int64_t n) {
   const int64_t b = ceil_div64(n, 256);
   return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
@@ -340,6 +386,49 @@ int snnqp_apply_gate(const void *x, int type, const float *g, int64_t NB, int32_
     hipLaunchKernelGGL(apply_gate_kernel<false>, dim3(grid_for(n)), dim3(256), 0,
                        (hipStream_t)stream, x, g, NB, HW, C, y);
   SNNQP_CHECK_LAUNCH("apply_gate_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_events_to_frames(const int32_t *ex, const int32_t *ey, const int32_t *ep,
+                           int64_t N, int32_t T, int32_t H, int32_t W, float scale,
+                           int32_t *counts, uint8_t *frames_u8, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(N >= 0 && T > 0 && H > 0 && W > 0 && scale > 0.0f, SNNQP_EINVAL,
+                "events_to_frames: bad shape");
+  SNNQP_REQUIRE(counts, SNNQP_EINVAL, "events_to_frames: null counts buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)T * H * W * 2;
+  SNNQP_HIP(hipMemsetAsync(counts, 0, n * 4, st));
+  if (N > 0) {
+    SNNQP_REQUIRE(ex && ey && ep, SNNQP_EINVAL, "events_to_frames: null events");
+    hipLaunchKernelGGL(events_to_frames_kernel, dim3(grid_for(N)), dim3(256), 0, st, ex, ey,
+                       ep, N, T, H, W, scale, counts);
+    SNNQP_CHECK_LAUNCH("events_to_frames_kernel");
+  }
+  if (frames_u8) {
+    hipLaunchKernelGGL(i32_to_u8_sat_kernel, dim3(grid_for(n)), dim3(256), 0, st, counts,
+                       frames_u8, n);
+    SNNQP_CHECK_LAUNCH("i32_to_u8_sat_kernel");
+  }
+  return SNNQP_OK;
+}
+
+int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int32_t *nnz,
+                  snnqp_stream_t stream) {
+  SNNQP_REQUIRE(NB >= 0 && n > 0 && C > 0 && n % C == 0, SNNQP_EINVAL, "density: bad shape");
+  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
+                "density: type must be F32 or BITS");
+  if (NB == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && nnz, SNNQP_EINVAL, "density: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  SNNQP_HIP(hipMemsetAsync(nnz, 0, NB * 4, st));
+  const int64_t units = type == SNNQP_BITS ? (n / C) * ((C + 31) / 32) : n;
+  if (type == SNNQP_BITS)
+    hipLaunchKernelGGL(density_kernel<true>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
+                       NB, n, C, nnz);
+  else
+    hipLaunchKernelGGL(density_kernel<false>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
+                       NB, n, C, nnz);
+  SNNQP_CHECK_LAUNCH("density_kernel");
   return SNNQP_OK;
 }
 

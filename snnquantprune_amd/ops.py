@@ -547,6 +547,42 @@ def apply_gate(x, g: torch.Tensor) -> torch.Tensor:
   return y
 
 
+def events_to_frames(x, y, p, T: int, H: int, W: int, scale: float = 1.0, as_u8=True):
+  """N time-ordered DVS events -> [T, H, W, 2] count frames (input_pipeline.py:142-219)."""
+  x = x.to(torch.int32).contiguous()
+  y = y.to(torch.int32).contiguous()
+  p = p.to(torch.int32).contiguous()
+  _require_gpu(x, y, p)
+  counts = torch.empty((T, H, W, 2), dtype=torch.int32, device=x.device)
+  u8 = torch.empty((T, H, W, 2), dtype=torch.uint8, device=x.device) if as_u8 else None
+  L.check(L.lib().snnqp_events_to_frames(_ptr(x), _ptr(y), _ptr(p), x.numel(), T, H, W,
+                                         float(scale), _ptr(counts), _ptr(u8), _stream()))
+  return u8 if as_u8 else counts
+
+
+def density(x, lead_dims: int = 2, counts: bool = False) -> torch.Tensor:
+  """Fraction of non-zero activations of each leading slice (default per [T, B]),
+  the probe of examples/tcja/models.py:128-142; float32 of shape x.shape[:lead_dims]
+  (or the exact int32 non-zero counts with counts=True)."""
+  if isinstance(x, PackedSpikes):
+    t, typ, C, shape = x.bits, L.BITS, x.channels, x.shape
+  else:
+    t, typ, C, shape = _f32c(x), L.F32, x.shape[-1], tuple(x.shape)
+  _require_gpu(t)
+  lead = tuple(shape[:lead_dims])
+  NB = 1
+  for d in lead:
+    NB *= d
+  n = 1
+  for d in shape[lead_dims:]:
+    n *= d
+  nnz = torch.empty(lead, dtype=torch.int32, device=t.device)
+  L.check(L.lib().snnqp_density(_ptr(t), typ, NB, n, C, _ptr(nnz), _stream()))
+  if counts:
+    return nnz
+  return nnz.to(torch.float32) / float(n)
+
+
 def vote(s, group: int = 10) -> torch.Tensor:
   """spikes [T, B, N] -> logits float32 [B, N // group] (models.py:253-255)."""
   if isinstance(s, PackedSpikes):

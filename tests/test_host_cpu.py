@@ -205,3 +205,61 @@ def test_sharded_eval_on_gloo_world_size_2(tmp_path):
   for p, o in zip(procs, outs):
     assert p.returncode == 0, o
     assert "ok" in o
+
+
+def test_checkpoint_import_roundtrip_and_torch_layouts(tmp_path):
+  """F2: the Flax msgpack wire format (ext 1 = ndarray) and the PyTorch layout
+  contract of tcja_load_pretrained_weights.py:19-36,117,127,137-139."""
+  from snnquantprune_amd import checkpoint, synthetic as syn
+  v = syn.cextnet_variables(frames=4, hw=32)
+  state = {"step": np.int32(7), "params": {"params": v["params"]},
+           "batch_stats": v["batch_stats"], "opt_state": {"count": np.float32(1.5)}}
+  path = tmp_path / "checkpoint_7"
+  path.write_bytes(checkpoint.msgpack_serialize(state))
+  got = checkpoint.load_flax_checkpoint(str(path))
+  assert sorted(got["params"]) == sorted(v["params"])
+  for name, leaf in v["params"].items():
+    for k, val in leaf.items():
+      if isinstance(val, dict):
+        for kk, vv in val.items():
+          np.testing.assert_array_equal(got["params"][name][k][kk], vv)
+      else:
+        np.testing.assert_array_equal(got["params"][name][k], val)
+  np.testing.assert_array_equal(got["batch_stats"]["BatchNorm_2"]["var"],
+                                v["batch_stats"]["BatchNorm_2"]["var"])
+  # torch state dict -> tree
+  rng = np.random.default_rng(0)
+  net = {"conv.0.0.weight": torch.from_numpy(rng.standard_normal((128, 2, 3, 3)).astype(np.float32)),
+         "conv.0.1.weight": torch.ones(128), "conv.0.1.bias": torch.zeros(128),
+         "conv.0.1.running_mean": torch.full((128,), 0.5), "conv.0.1.running_var": torch.ones(128),
+         "conv.0.1.num_batches_tracked": torch.tensor(3),
+         "conv.11.conv.weight": torch.from_numpy(rng.standard_normal((20, 20, 4)).astype(np.float32)),
+         "fc.5.0.weight": torch.from_numpy(rng.standard_normal((110, 512)).astype(np.float32))}
+  tree = checkpoint.from_torch_state_dict(net)
+  k0 = tree["params"]["QuantConv_0"]["kernel"]
+  assert k0.shape == (3, 3, 2, 128)
+  assert k0[1, 2, 0, 5] == net["conv.0.0.weight"][5, 0, 1, 2].item()
+  assert tree["params"]["QuantConv_4"]["kernel"].shape == (4, 20, 20)
+  assert tree["params"]["QuantDense_1"]["kernel"].shape == (512, 110)
+  assert tree["params"]["QuantDense_1"]["kernel"][3, 7] == net["fc.5.0.weight"][7, 3].item()
+  assert float(tree["params"]["QuantConv_0"]["DuQ_0"]["a"][0]) == -1.0
+  assert tree["params"]["QuantConv_0"]["prune_0"]["mask"].min() == 1.0
+  assert tree["batch_stats"]["BatchNorm_0"]["mean"][0] == 0.5
+  assert sorted(tree["params"]["BatchNorm_0"]) == ["bias", "scale"]
+
+
+def test_prune_utils_on_cpu_tensors():
+  """Mask / a, c builders are host-side: they run on CPU tensors too."""
+  from oracle import snn_oracle as o
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import prune_utils, synthetic as syn
+  from snnquantprune_amd.quant import gaussian_init
+  v = syn.dense_net_variables(K=64, hidden=32, out=20, prune_p=-1.0)
+  params = nn.tree_from_numpy(v["params"], torch.device("cpu"))
+  g = prune_utils.update_global_prune_mask(params, 0.5)
+  ks = [v["params"]["QuantDense_0"]["kernel"], v["params"]["QuantDense_1"]["kernel"]]
+  for name, m in zip(("QuantDense_0", "QuantDense_1"), o.global_prune_masks(ks, 0.5)):
+    np.testing.assert_array_equal(g[name]["prune_0"]["mask"].numpy(), m)
+  q = prune_utils.update_quant_params(params, gaussian_init, 4)
+  np.testing.assert_allclose(float(q["QuantDense_0"]["DuQ_0"]["a"]),
+                             float(o.gaussian_init(ks[0], 4)), rtol=2e-6)

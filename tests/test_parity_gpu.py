@@ -734,3 +734,29 @@ def test_eval_step_metrics(dev, oracle):
   em = oracle.compute_metrics(e["logits"], labels)
   assert abs(float(m["loss"]) - float(em["loss"])) < 1e-7
   np.testing.assert_array_equal(_np(m["accuracy"]), em["accuracy"])
+
+
+def test_event_front_end_and_density_probes(dev, oracle):
+  """F3 / F4: event -> frame histogram (input_pipeline.py:142-219) and the density
+  probes (models.py:128-142), exact integer results."""
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(31))
+  n, T, H, W = 100003, 20, 128, 128
+  x = rng.integers(0, W, n)
+  y = rng.integers(0, H, n)
+  p = rng.integers(0, 2, n)
+  x[:500] = 7; y[:500] = 9; p[:500] = 1               # a hot pixel: counts > 255 saturate in u8
+  e = oracle.events_to_frames(x, y, p, T, H, W)
+  c = ops.events_to_frames(_t(x, dev), _t(y, dev), _t(p, dev), T, H, W, as_u8=False)
+  np.testing.assert_array_equal(_np(c), e)
+  u8 = ops.events_to_frames(_t(x, dev), _t(y, dev), _t(p, dev), T, H, W)
+  np.testing.assert_array_equal(_np(u8), np.minimum(e, 255).astype(np.uint8))
+  assert e.sum() == n and e[0, 9, 7, 1] >= 500
+  e2 = oracle.events_to_frames(x, y, p, T, 64, 64, scale=2.0)
+  c2 = ops.events_to_frames(_t(x, dev), _t(y, dev), _t(p, dev), T, 64, 64, scale=2.0, as_u8=False)
+  np.testing.assert_array_equal(_np(c2), e2)
+  s = (rng.random((5, 3, 6, 6, 70)) < 0.2).astype(F32)
+  nnz = (s != 0).reshape(5, 3, -1).sum(-1)
+  for inp in (_t(s, dev), ops.pack_bits(_t(s, dev))):
+    np.testing.assert_array_equal(_np(ops.density(inp, counts=True)), nnz)     # exact counts
+    np.testing.assert_allclose(_np(ops.density(inp)), oracle.density(s), rtol=2e-7)
