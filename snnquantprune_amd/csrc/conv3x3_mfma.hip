@@ -103,25 +103,26 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
   for (int i = tid; i <= 2 * bound; i += 256) lut[i] = dequant_acc_nb(i - bound, dq);
 }
 
-// Two neurons (accumulator registers i, i+1: two pixels, same channel) through
-// dequant -> BatchNorm -> neuron, as packed float32 ops (v_pk_*_f32 keep every
-// rounding of the scalar sequence).  `lutc` points at the table entry of acc = 0.
-template <bool FAST, bool LUT>
-__device__ __forceinline__ void neuron_pair(int a0, int a1, float &u0, float &u1,
-                                            const Dequant &dq, const LaneConsts &lc,
-                                            const NeuronP &nrn, const float *lutc,
+// Dequantised currents of two accumulator registers (two pixels, same channel),
+// as packed float32 ops (v_pk_*_f32 keep every rounding of the scalar sequence).
+// `lutc` points at the table entry of acc = 0.
+template <bool LUT>
+__device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq,
+                                            const float *lutc) {
+  if (LUT) return v2f{lutc[a0], lutc[a1]};
+  const v2f a = {(float)a0, (float)a1};
+  v2f q = a * dq.rL;
+  const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
+  q = __builtin_elementwise_fma(e, v2f{dq.rL, dq.rL}, q);
+  return q * dq.m;
+}
+
+// BatchNorm + neuron for two dequantised currents (two pixels, same channel).
+template <bool FAST>
+__device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
+                                            const LaneConsts &lc, const NeuronP &nrn,
                                             unsigned long long &m0,
                                             unsigned long long &m1) {
-  v2f y;
-  if (LUT) {
-    y = v2f{lutc[a0], lutc[a1]};
-  } else {
-    const v2f a = {(float)a0, (float)a1};
-    v2f q = a * dq.rL;
-    const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
-    q = __builtin_elementwise_fma(e, v2f{dq.rL, dq.rL}, q);
-    y = q * dq.m;
-  }
   v2f x = y - lc.bmean;
   x = x * lc.bmul;
   x = x + lc.bbias;
@@ -144,20 +145,22 @@ __device__ __forceinline__ void neuron_pair(int a0, int a1, float &u0, float &u1
   }
 }
 
-template <bool FAST, bool POOL, bool LUT, int FENCE = 0>
+// Whole-tile epilogue (used where no MFMA stream runs beside it): all table
+// reads are issued first, then the pairs are processed.
+template <bool FAST, bool POOL, bool LUT>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
                                                   const NeuronP &nrn, int lane,
                                                   const float *lutc) {
+  v2f y[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUT>(acc[2 * j], acc[2 * j + 1], dq, lutc);
   uint32_t myw = 0;
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
-    // FENCE: keep the scheduler from hoisting every pair's compare to one place
-    // (16 live 64-bit masks spill the SGPR file)
-    if (FENCE && i > 0 && (i % (2 * FENCE)) == 0) __builtin_amdgcn_sched_barrier(0);
     unsigned long long m0, m1;
-    neuron_pair<FAST, LUT>(acc[i], acc[i + 1], u[i], u[i + 1], dq, lc, nrn, lutc, m0, m1);
+    neuron_pair<FAST>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
     if (POOL) {
       const unsigned long long o = m0 | m1;
       const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
@@ -685,7 +688,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             v16i acc = ZERO16;
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{av[0], av[1], av[2], av[3]},
                                                         bf, acc, 0, 0, 0);
-            words[tl] = tile_epilogue<FAST, POOL, LUT, 2>(acc, u[tl], a.dq, lc, a.nrn, lane, lutc);
+            words[tl] = tile_epilogue<FAST, POOL, LUT>(acc, u[tl], a.dq, lc, a.nrn, lane, lutc);
           }
           if (store_lane) {
             uint32_t *o = obuf + ((tc + tt) % FL) * (OutStage<POOL>::NPIX * 4);
