@@ -34,7 +34,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define SNNQP_U8C2_UNROLL 1
 #endif
 #ifndef SNNQP_U8C2_WPS
-#define SNNQP_U8C2_WPS 4    // waves per SIMD the conv0 kernel is compiled for (A/B: 2: 22.3, 3: 19.5, 4: 18.6 ms)
+#define SNNQP_U8C2_WPS 2    // waves per SIMD the conv0 kernel is compiled for: 3 and 4 spill to
+                            // scratch (per-patch code) and are no faster (17.4 ms either way)
 #endif
 
 constexpr int LUT_CAP = 2047;                   // table covers acc in [-LUT_CAP, LUT_CAP]
@@ -59,6 +60,7 @@ struct ConvMfmaArgs {
   int32_t tiles_y, tiles_x;
   int64_t npatch;
   int32_t lut_bound;  // > 0: |acc| <= lut_bound guaranteed, dequant by LDS table
+  int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
 };
 
 // 16-byte chunk c16 of halo pixel (hy, hx).  Two pixels share a 256-byte bank
@@ -78,6 +80,40 @@ __device__ __forceinline__ v4i expand16(uint32_t b) {
   return o;
 }
 
+// Patch schedule of a persistent workgroup.  With xcd_split the workgroups that
+// share an XCD (blockIdx.x % 8 under the observed round-robin placement -- a speed
+// assumption only) walk the samples b = xcd (mod 8), neighbouring patches at the
+// same time, so the halo lines neighbouring patches share are served by that
+// XCD's L2 instead of being fetched once per XCD.
+struct PatchWalk {
+  int64_t first, count, stride;
+  int ppb, xcd;
+  bool split;
+  __device__ __forceinline__ explicit PatchWalk(const ConvMfmaArgs &a) {
+    ppb = a.tiles_y * a.tiles_x;
+    split = a.xcd_split != 0;
+    if (split) {
+      xcd = blockIdx.x & 7;
+      first = blockIdx.x >> 3;
+      stride = gridDim.x >> 3;
+      count = (int64_t)((a.B - xcd + 7) >> 3) * ppb;
+    } else {
+      xcd = 0;
+      first = blockIdx.x;
+      stride = gridDim.x;
+      count = a.npatch;
+    }
+  }
+  __device__ __forceinline__ void decode(const ConvMfmaArgs &a, int64_t r, int &b, int &y0,
+                                         int &x0) const {
+    const int within = (int)(r % ppb);
+    const int bi = (int)(r / ppb);
+    b = split ? xcd + 8 * bi : bi;
+    y0 = (within / a.tiles_x) * 8;
+    x0 = (within % a.tiles_x) * 8;
+  }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences
 // global memory, i.e. waits (vmcnt(0)) for the spike stores of the previous step
 // and the prefetched halo loads -- a full memory round trip per timestep.
@@ -85,6 +121,19 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// old with lane `lane` replaced by the wave-uniform `val`.  v_writelane_b32 may
+// name only one SGPR besides M0, so the lane select goes through M0.  hipcc pads
+// nothing inside asm: `val` may have been written by a VALU compare one
+// instruction earlier and M0 by the s_mov just before; v_{read,write}lane needs up
+// to 4 wait states after either (seen as wrong words on one build), hence s_nop 3.
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t val, int lane, uint32_t old) {
+  asm("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0"
+      : "+v"(old)
+      : "s"(val), "s"(lane)
+      : "m0");
+  return old;
 }
 
 struct LaneConsts {
@@ -109,6 +158,9 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
 template <bool LUT>
 __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq,
                                             const float *lutc) {
+#if defined(SNNQP_ABL) && (SNNQP_ABL & 4)   // diagnostic build: no dequantisation
+  return v2f{__int_as_float(a0), __int_as_float(a1)};
+#endif
   if (LUT) return v2f{lutc[a0], lutc[a1]};
   const v2f a = {(float)a0, (float)a1};
   v2f q = a * dq.rL;
@@ -123,6 +175,11 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
                                             const LaneConsts &lc, const NeuronP &nrn,
                                             unsigned long long &m0,
                                             unsigned long long &m1) {
+#if defined(SNNQP_ABL) && (SNNQP_ABL & 1)   // diagnostic build: no BN / neuron math
+  m0 = __ballot(y.x > u0);
+  m1 = __ballot(y.y > u1);
+  return;
+#endif
   v2f x = y - lc.bmean;
   x = x * lc.bmul;
   x = x + lc.bbias;
@@ -161,16 +218,18 @@ __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
     unsigned long long m0, m1;
     neuron_pair<FAST>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
+    // the masks are wave-uniform: v_writelane drops each word into the lane that
+    // stores it (no per-lane compare masks to keep in SGPRs)
     if (POOL) {
       const unsigned long long o = m0 | m1;
       const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
-      myw = (lane == (i >> 1)) ? pw : myw;
+      myw = writelane_u32(pw, i >> 1, myw);
     } else {
       const int r0 = (i & 3) + 8 * (i >> 2);          // row of element i, low half
-      myw = (lane == r0) ? (uint32_t)m0 : myw;
-      myw = (lane == r0 + 4) ? (uint32_t)(m0 >> 32) : myw;
-      myw = (lane == r0 + 1) ? (uint32_t)m1 : myw;
-      myw = (lane == r0 + 5) ? (uint32_t)(m1 >> 32) : myw;
+      myw = writelane_u32((uint32_t)m0, r0, myw);
+      myw = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, myw);
+      myw = writelane_u32((uint32_t)m1, r0 + 1, myw);
+      myw = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, myw);
     }
   }
   return myw;
@@ -266,9 +325,27 @@ extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
     snnqp_clock_probe[0] = __builtin_amdgcn_s_memtime() - pc0;               \
     snnqp_clock_probe[1] = __builtin_amdgcn_s_memrealtime() - pr0;           \
   }
+#define PHASE_DECL() unsigned long long ph_t = 0, ph_acc[3] = {0, 0, 0};
+#define PHASE_START() ph_t = __builtin_amdgcn_s_memtime();
+#define PHASE_MARK(i)                                         \
+  {                                                           \
+    const unsigned long long n__ = __builtin_amdgcn_s_memtime(); \
+    ph_acc[i] += n__ - ph_t;                                  \
+    ph_t = n__;                                               \
+  }
+#define PHASE_DUMP()                                                    \
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {         \
+    snnqp_clock_probe[1] = ph_acc[0];                                   \
+    snnqp_clock_probe[2] = ph_acc[1];                                   \
+    snnqp_clock_probe[3] = ph_acc[2];                                   \
+  }
 #else
 #define PROBE_BEGIN()
 #define PROBE_END()
+#define PHASE_DECL()
+#define PHASE_START()
+#define PHASE_MARK(i)
+#define PHASE_DUMP()
 #endif
 
 // ---------------------------------------------------------------------------
@@ -336,12 +413,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const bool store_lane = POOL ? lane < 8 : lane < 32;
 
   PROBE_BEGIN()
-  for (int64_t p = blockIdx.x; p < a.npatch; p += gridDim.x) {
-    int64_t q = p;
-    const int px = (int)(q % a.tiles_x); q /= a.tiles_x;
-    const int py = (int)(q % a.tiles_y); q /= a.tiles_y;
-    const int b = (int)q;
-    const int y0 = py * 8, x0 = px * 8;
+  PatchWalk pw(a);
+  for (int64_t r = pw.first; r < pw.count; r += pw.stride) {
+    int b, y0, x0;
+    pw.decode(a, r, b, y0, x0);
 
     float u[2][16];
     if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
@@ -415,6 +490,17 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     //   piece 4 (pair j)  : reset + spike word select
     auto fused_step = [&](const uint8_t *base, v16i &accN0, v16i &accN1,
                           const v16i &accC0, const v16i &accC1, int t) {
+      if (!FAST) {     // general neuron kinds: branchy update, keep the two phases apart
+        mfma_step(base, accN0, accN1);
+        const uint32_t w0 = tile_epilogue<FAST, POOL, LUT>(accC0, u[0], a.dq, lc, a.nrn, lane, lutc);
+        const uint32_t w1 = tile_epilogue<FAST, POOL, LUT>(accC1, u[1], a.dq, lc, a.nrn, lane, lutc);
+        if (store_lane) {
+          uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
+          o[ob0] = w0;
+          o[ob1] = w1;
+        }
+        return;
+      }
       v4i A[2][2 * KK];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
@@ -482,13 +568,13 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
             if (POOL) {
               const unsigned long long o = m0 | m1;
               const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
-              w = (lane == (i >> 1)) ? pw : w;
+              w = writelane_u32(pw, i >> 1, w);
             } else {
               const int r0 = (i & 3) + 8 * (i >> 2);
-              w = (lane == r0) ? (uint32_t)m0 : w;
-              w = (lane == r0 + 4) ? (uint32_t)(m0 >> 32) : w;
-              w = (lane == r0 + 1) ? (uint32_t)m1 : w;
-              w = (lane == r0 + 5) ? (uint32_t)(m1 >> 32) : w;
+              w = writelane_u32((uint32_t)m0, r0, w);
+              w = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, w);
+              w = writelane_u32((uint32_t)m1, r0 + 1, w);
+              w = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, w);
             }
           }
         }
@@ -633,12 +719,12 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
   const bool store_lane = POOL ? lane < 8 : lane < 32;
 
-  for (int64_t p = blockIdx.x; p < a.npatch; p += gridDim.x) {
-    int64_t q = p;
-    const int px = (int)(q % a.tiles_x); q /= a.tiles_x;
-    const int py = (int)(q % a.tiles_y); q /= a.tiles_y;
-    const int b = (int)q;
-    const int y0 = py * 8, x0 = px * 8;
+  PHASE_DECL()
+  PROBE_BEGIN()
+  PatchWalk pw(a);
+  for (int64_t r = pw.first; r < pw.count; r += pw.stride) {
+    int b, y0, x0;
+    pw.decode(a, r, b, y0, x0);
 
     float u[2][16];
     if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
@@ -646,6 +732,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
 
     for (int tc = 0; tc < a.T; tc += TCHUNK) {
       const int nt = min(TCHUNK, a.T - tc);
+      PHASE_START()
       lds_barrier();                       // previous readers of the LDS image are done
       {
         constexpr int NT2 = (TCHUNK * HALO * HALO + 255) / 256;
@@ -669,6 +756,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         }
       }
       lds_barrier();
+      PHASE_MARK(0)
       for (int tf = 0; tf < nt; tf += FL) {          // FL steps, then flush
         const int nf = min(FL, nt - tf);
 #pragma unroll SNNQP_U8C2_UNROLL
@@ -686,9 +774,16 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
               av[d] = (int)((lo | (hi << 16)) & amask[d]);
             }
             v16i acc = ZERO16;
+#if defined(SNNQP_ABL) && (SNNQP_ABL & 2)   // diagnostic build: no MFMA
+            acc[0] = av[0]; acc[5] = av[1]; acc[9] = av[2]; acc[13] = av[3];
+#else
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{av[0], av[1], av[2], av[3]},
                                                         bf, acc, 0, 0, 0);
+#endif
             words[tl] = tile_epilogue<FAST, POOL, LUT>(acc, u[tl], a.dq, lc, a.nrn, lane, lutc);
+            // one tile at a time: overlapping both tiles' temporaries costs more
+            // registers than the 128-VGPR budget of 4 waves per SIMD (scratch spills)
+            __builtin_amdgcn_sched_barrier(0);
           }
           if (store_lane) {
             uint32_t *o = obuf + ((tc + tt) % FL) * (OutStage<POOL>::NPIX * 4);
@@ -696,13 +791,17 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             o[ob1] = words[1];
           }
         }
+        PHASE_MARK(1)
         lds_barrier();
         flush_out<POOL>(obuf, a, tc + tf, nf, b, y0, x0, tid);
         lds_barrier();
+        PHASE_MARK(2)
       }
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
   }
+  PROBE_END()
+  PHASE_DUMP()
 }
 
 // ---------------------------------------------------------------------------
@@ -737,7 +836,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
 }
 
 template <typename K>
-static void launch_persistent(K kernel, const ConvMfmaArgs &a, unsigned gy, hipStream_t st) {
+static void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st) {
   int dev = 0, cus = 256, occ = 2;
   if (hipGetDevice(&dev) == hipSuccess)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -746,7 +845,12 @@ static void launch_persistent(K kernel, const ConvMfmaArgs &a, unsigned gy, hipS
     occ = 1;
   if (occ > 8) occ = 8;
   const int64_t gmax = (int64_t)cus * occ;
-  const unsigned gx = (unsigned)(a.npatch < gmax ? a.npatch : gmax);
+  unsigned gx = (unsigned)(a.npatch < gmax ? a.npatch : gmax);
+  a.xcd_split = 0;
+  if (gx >= 64 && a.B >= 8) {     // whole samples per XCD
+    gx &= ~7u;
+    a.xcd_split = 1;
+  }
   hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), 0, st, a);
 }
 

@@ -500,6 +500,24 @@ def test_conv_block_pipeline_tails(dev, oracle, T):
       np.testing.assert_array_equal(_np(u), e["u"])
 
 
+def test_conv_block_xcd_split_schedule(dev, oracle):
+  """Batches of 8 or more samples take the XCD-aware patch schedule (samples
+  b = xcd mod 8 per XCD); uneven B = 19 leaves XCDs with different sample counts."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  for cin, hw in ((128, 16), (2, 16)):
+    c = cases.conv_block_case(T=3, B=19, hw=hw, cin=cin, seed=985, gain=5.0 if cin > 2 else 4.0)
+    e = cases.conv_block_expected(oracle, c)
+    w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+    geom = ops.ConvGeom(hw, hw, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+    x = _t(c["x"], dev)
+    xin = x if cin == 2 else ops.pack_bits(x)
+    u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                pool=2, impl=L.IMPL_MFMA, x_max=ops.input_max_bound(xin))
+    np.testing.assert_array_equal(_np(s), e["pooled_bits"])
+    np.testing.assert_array_equal(_np(u), e["u"])
+
+
 def test_mfma_kernel_refuses_unsupported_shapes(dev):
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
