@@ -123,17 +123,23 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// old with lane `lane` replaced by the wave-uniform `val`.  v_writelane_b32 may
-// name only one SGPR besides M0, so the lane select goes through M0.  hipcc pads
-// nothing inside asm: `val` may have been written by a VALU compare one
-// instruction earlier and M0 by the s_mov just before; v_{read,write}lane needs up
-// to 4 wait states after either (seen as wrong words on one build), hence s_nop 3.
+// old with lane `lane` replaced by the wave-uniform `val` (v_writelane_b32).
+// This hipcc has no __builtin_amdgcn_writelane; binding the LLVM intrinsic by its
+// name keeps the instruction visible to the compiler, which then inserts the wait
+// states a VALU-written SGPR needs before it (inline asm would hide that hazard).
+extern "C" __device__ uint32_t snnqp_writelane_i32(uint32_t, uint32_t, uint32_t)
+    __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ uint32_t writelane_u32(uint32_t val, int lane, uint32_t old) {
-  asm("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0"
-      : "+v"(old)
-      : "s"(val), "s"(lane)
-      : "m0");
-  return old;
+  return snnqp_writelane_i32(val, (uint32_t)lane, old);
+}
+
+// u with the lanes of `mask` zeroed: the hard reset reuses the ballot of the
+// threshold compare (written as a C++ select the compiler emits a second, negated
+// v_cmp per element).  VALU readers of a VALU-written SGPR need no wait states.
+__device__ __forceinline__ float reset_where(float u, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(r) : "v"(u), "s"(mask));
+  return r;
 }
 
 struct LaneConsts {
@@ -191,11 +197,10 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
     const v2f d = x - uu;
     const v2f dk = d * nrn.inv_k;
     uu = uu + dk;
-    const bool s0 = uu.x >= nrn.vth, s1 = uu.y >= nrn.vth;
-    m0 = __ballot(s0);
-    m1 = __ballot(s1);
-    u0 = s0 ? 0.0f : uu.x;
-    u1 = s1 ? 0.0f : uu.y;
+    m0 = __ballot(uu.x >= nrn.vth);
+    m1 = __ballot(uu.y >= nrn.vth);
+    u0 = reset_where(uu.x, m0);
+    u1 = reset_where(uu.y, m1);
   } else {
     m0 = __ballot(neuron_step(u0, x.x, nrn, lc.dec));
     m1 = __ballot(neuron_step(u1, x.y, nrn, lc.dec));
@@ -560,8 +565,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
             }
           } else {
             if (FAST) {
-              up[0] = (uu.x >= a.nrn.vth) ? 0.0f : uu.x;
-              up[1] = (uu.y >= a.nrn.vth) ? 0.0f : uu.y;
+              up[0] = reset_where(uu.x, m0);
+              up[1] = reset_where(uu.y, m1);
             }
             uint32_t &w = (j < 8) ? w0 : w1;
             const int i = (j & 7) * 2;
