@@ -147,6 +147,7 @@ int snnqp_pack_codes_mfma(const int8_t *w, int64_t K, int32_t N, int32_t Npad,
  * the kernels read/write.  rows x C logical elements. */
 int snnqp_inspect_f32(const float *x, int64_t n, int32_t *flags,
                       snnqp_stream_t stream);
+/* inspect_u8: *flags (zeroed by the caller) = (max(x) << 8) | SNNQP_FLAG_GT_* bits */
 int snnqp_inspect_u8(const uint8_t *x, int64_t n, int32_t *flags,
                      snnqp_stream_t stream);
 int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,

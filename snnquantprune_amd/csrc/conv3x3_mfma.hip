@@ -38,7 +38,23 @@ typedef float v2f __attribute__((ext_vector_type(2)));
                             // scratch (per-patch code) and are no faster (17.4 ms either way)
 #endif
 
-constexpr int LUT_CAP = 2047;                   // table covers acc in [-LUT_CAP, LUT_CAP]
+// Dequantisation by LDS table (fast neuron path only).  The accumulator is made
+// to BE the table address: the A operand carries 4x the input (spike bytes {0,4},
+// event counts << 2) and the MFMA chain starts from C = byte address of the entry
+// of acc = 0, so ds_read_b32 takes the MFMA result as is (no index arithmetic).
+//   LUT_SHARED : one table, entry = fl(fl(acc / L) * m), |acc| <= LUT_CAP
+//   LUT_CHANNEL: one table per output channel with BatchNorm applied to the entry
+//                as well (conv0: |acc| <= LUT2_CAP), so the epilogue starts at the
+//                membrane update
+enum { LUT_NONE = 0, LUT_SHARED = 1, LUT_CHANNEL = 2 };
+constexpr int LUT_CAP = 2047;
+constexpr int LUT2_CAP = 40;
+constexpr int LUT_XMAX = 31;                    // 4 * x must stay an int8
+template <int LUTM>
+struct LutBytes {
+  static constexpr int value = LUTM == LUT_CHANNEL ? 128 * (2 * LUT2_CAP + 1) * 4
+                               : LUTM == LUT_SHARED ? (2 * LUT_CAP + 2) * 4 : 0;
+};
 
 constexpr int HALO = 10;
 constexpr int PIXB = 128;                       // LDS bytes per halo pixel
@@ -71,12 +87,16 @@ __device__ __forceinline__ int halo_addr(int hy, int hx, int c16) {
   return (hy * HALO + hx) * PIXB + ((c16 ^ g) << 4);
 }
 
+// 16 spike bits -> 16 bytes {0, 1} (or {0, 4} when the accumulator indexes a table)
+template <bool X4>
 __device__ __forceinline__ v4i expand16(uint32_t b) {
+  constexpr uint32_t MUL = X4 ? 0x00810204u : 0x00204081u;
+  constexpr uint32_t AND = X4 ? 0x04040404u : 0x01010101u;
   v4i o;
-  o.x = (int)((((b >> 0) & 0xFu) * 0x00204081u) & 0x01010101u);
-  o.y = (int)((((b >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-  o.z = (int)((((b >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-  o.w = (int)((((b >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+  o.x = (int)((((b >> 0) & 0xFu) * MUL) & AND);
+  o.y = (int)((((b >> 4) & 0xFu) * MUL) & AND);
+  o.z = (int)((((b >> 8) & 0xFu) * MUL) & AND);
+  o.w = (int)((((b >> 12) & 0xFu) * MUL) & AND);
   return o;
 }
 
@@ -146,11 +166,6 @@ struct LaneConsts {
   float bmean, bmul, bbias, dec;
 };
 
-// Dequant + BN + neuron for one 32x32 tile, straight-line.  The lane mask of
-// register i holds pixel (ty = 2*(i>>3), tx = i&7) in its low half and
-// (ty + 1, tx) in its high half.  Returns the word this lane stores:
-//   POOL : lanes 0..7  = pooled pixel (pty = lane >> 2, ptx = lane & 3)
-//   !POOL: lanes 0..31 = pixel row `lane` of the tile
 // lut[i] = fl(fl((i - bound) / L) * m): the dequantised current of accumulator
 // value i - bound, built once per workgroup (same three-instruction division).
 __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &dq,
@@ -158,16 +173,31 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
   for (int i = tid; i <= 2 * bound; i += 256) lut[i] = dequant_acc_nb(i - bound, dq);
 }
 
-// Dequantised currents of two accumulator registers (two pixels, same channel),
-// as packed float32 ops (v_pk_*_f32 keep every rounding of the scalar sequence).
-// `lutc` points at the table entry of acc = 0.
-template <bool LUT>
+// Per-channel tables of the workgroup's 128 output channels, row stride
+// 2 * bound + 1: entry = BatchNorm_c(dequant(acc)), the same op sequence the
+// epilogue would run (bn_apply on dequant_acc_nb), so folding changes no bit.
+__device__ __forceinline__ void build_lut_channel(float *lut, int bound, const Dequant &dq,
+                                                  const BnP &bn, int cout0, int Cout,
+                                                  int tid) {
+  const int stride = 2 * bound + 1;
+  for (int i = tid; i < 128 * stride; i += 256) {
+    const int c = i / stride, v = i - c * stride - bound;
+    const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
+    float y = dequant_acc_nb(v, dq);
+    y = bn.mean ? bn_apply(y, bn.mean[co], bn.mul[co], bn.bias[co]) : bn_apply(y, 0.f, 1.f, 0.f);
+    lut[i] = y;
+  }
+}
+
+// Dequantised currents of two accumulator registers (two pixels, same channel).
+// Table modes: the register is the LDS byte address of its entry (`ldsb` = LDS
+// address 0).  Otherwise packed float32 ops (v_pk_*_f32 keep every rounding of
+// the scalar sequence).
+template <int LUTM>
 __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq,
-                                            const float *lutc) {
-#if defined(SNNQP_ABL) && (SNNQP_ABL & 4)   // diagnostic build: no dequantisation
-  return v2f{__int_as_float(a0), __int_as_float(a1)};
-#endif
-  if (LUT) return v2f{lutc[a0], lutc[a1]};
+                                            const uint8_t *ldsb) {
+  if (LUTM != LUT_NONE)
+    return v2f{*(const float *)(ldsb + (uint32_t)a0), *(const float *)(ldsb + (uint32_t)a1)};
   const v2f a = {(float)a0, (float)a1};
   v2f q = a * dq.rL;
   const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
@@ -175,8 +205,9 @@ __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq,
   return q * dq.m;
 }
 
-// BatchNorm + neuron for two dequantised currents (two pixels, same channel).
-template <bool FAST>
+// BatchNorm (unless the table already applied it) + neuron for two dequantised
+// currents (two pixels, same channel).
+template <bool FAST, bool BNDONE>
 __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
                                             const LaneConsts &lc, const NeuronP &nrn,
                                             unsigned long long &m0,
@@ -186,9 +217,12 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
   m1 = __ballot(y.y > u1);
   return;
 #endif
-  v2f x = y - lc.bmean;
-  x = x * lc.bmul;
-  x = x + lc.bbias;
+  v2f x = y;
+  if (!BNDONE) {
+    x = x - lc.bmean;
+    x = x * lc.bmul;
+    x = x + lc.bbias;
+  }
   if (FAST) {
     // multi_step_LIF with tau a power of two and v_reset == 0
     // (spiking_learning.py:410-414): u - 0 == u exactly, and with float32
@@ -209,20 +243,20 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
 
 // Whole-tile epilogue (used where no MFMA stream runs beside it): all table
 // reads are issued first, then the pairs are processed.
-template <bool FAST, bool POOL, bool LUT>
+template <bool FAST, bool POOL, int LUTM>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
                                                   const NeuronP &nrn, int lane,
-                                                  const float *lutc) {
+                                                  const uint8_t *ldsb) {
   v2f y[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUT>(acc[2 * j], acc[2 * j + 1], dq, lutc);
+  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM>(acc[2 * j], acc[2 * j + 1], dq, ldsb);
   uint32_t myw = 0;
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
     unsigned long long m0, m1;
-    neuron_pair<FAST>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
+    neuron_pair<FAST, LUTM == LUT_CHANNEL>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
     // the masks are wave-uniform: v_writelane drops each word into the lane that
     // stores it (no per-lane compare masks to keep in SGPRs)
     if (POOL) {
@@ -309,7 +343,9 @@ __device__ __forceinline__ void zero_u(float (&u)[2][16]) {
     for (int i = 0; i < 16; ++i) u[tl][i] = 0.0f;
 }
 
-#define ZERO16 v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+__device__ __forceinline__ v16i splat16(int v) {
+  return v16i{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
+}
 
 #ifdef SNNQP_CLOCK_PROBE
 // Diagnostic build only (python csrc/build.py with SNNQP_PROBE=1): shader-clock
@@ -356,30 +392,31 @@ extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
 // ---------------------------------------------------------------------------
 // Bit-packed input, Cin = 128.
 // ---------------------------------------------------------------------------
-template <bool FAST, bool POOL, bool LUT>
+template <bool FAST, bool POOL, int LUTM>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
+  static_assert(LUTM != LUT_CHANNEL, "per-channel tables of K = 1152 do not fit LDS");
   constexpr int CIN = 128;
   constexpr int KK = CIN / 32;
   constexpr int NTASK = HALO * HALO * KK;        // (pixel, word) staging tasks
   constexpr int TPT = (NTASK + 255) / 256;       // tasks per thread
-  constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
+  constexpr int LUT_BYTES = LutBytes<LUTM>::value;
+  constexpr int LUT_OFF = 2 * HALO_BYTES;
   constexpr int FL = OutStage<POOL>::FL;
+  // the kernel's only LDS object, i.e. LDS address 0: table addresses carried in
+  // the accumulators are offsets into this array
   __shared__ __attribute__((aligned(16))) uint8_t
       lds[2 * HALO_BYTES + LUT_BYTES + OutStage<POOL>::BYTES];
-  uint32_t *obuf = (uint32_t *)(lds + 2 * HALO_BYTES + LUT_BYTES);
+  uint32_t *obuf = (uint32_t *)(lds + LUT_OFF + LUT_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
-  const float *lutc = nullptr;
-  if (LUT) {
-    float *lut = (float *)(lds + 2 * HALO_BYTES);
-    build_lut(lut, a.lut_bound, a.dq, tid);
-    lutc = lut + a.lut_bound;
-  }
+  if (LUTM == LUT_SHARED) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid);
+  // start value of every accumulator chain: the address of the entry of acc = 0
+  const v16i cb = splat16(LUTM == LUT_SHARED ? LUT_OFF + 4 * a.lut_bound : 0);
 
   // B operand: lane (n, h) holds W[tap][cin = 32 kk + 16 h + j][cout], j < 16:
   // k-step tap * KK + kk of this wave's 32-column block in the MFMA-tiled codes.
@@ -451,8 +488,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         if (task < NTASK) {
           const int pix = task / KK, wi = task % KK;
           const int hy = pix / HALO, hx = pix % HALO;
-          *(v4i *)(base + halo_addr(hy, hx, wi * 2)) = expand16(stg[k] & 0xFFFFu);
-          *(v4i *)(base + halo_addr(hy, hx, wi * 2 + 1)) = expand16(stg[k] >> 16);
+          *(v4i *)(base + halo_addr(hy, hx, wi * 2)) = expand16<LUTM != LUT_NONE>(stg[k] & 0xFFFFu);
+          *(v4i *)(base + halo_addr(hy, hx, wi * 2 + 1)) = expand16<LUTM != LUT_NONE>(stg[k] >> 16);
         }
       }
     };
@@ -464,8 +501,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         A[0][kk] = *(const v4i *)(base + aoff[0][kk]);
         A[0][KK + kk] = *(const v4i *)(base + aoff[0][kk] + TILE1);
       }
-      acc0 = ZERO16;
-      acc1 = ZERO16;
+      acc0 = cb;
+      acc1 = cb;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         if (tap + 1 < 9) {
@@ -497,8 +534,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
                           const v16i &accC0, const v16i &accC1, int t) {
       if (!FAST) {     // general neuron kinds: branchy update, keep the two phases apart
         mfma_step(base, accN0, accN1);
-        const uint32_t w0 = tile_epilogue<FAST, POOL, LUT>(accC0, u[0], a.dq, lc, a.nrn, lane, lutc);
-        const uint32_t w1 = tile_epilogue<FAST, POOL, LUT>(accC1, u[1], a.dq, lc, a.nrn, lane, lutc);
+        const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(accC0, u[0], a.dq, lc, a.nrn, lane, lds);
+        const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(accC1, u[1], a.dq, lc, a.nrn, lane, lds);
         if (store_lane) {
           uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
           o[ob0] = w0;
@@ -512,23 +549,15 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         A[0][2 * kk] = *(const v4i *)(base + aoff[0][kk]);
         A[0][2 * kk + 1] = *(const v4i *)(base + aoff[0][kk] + TILE1);
       }
-      accN0 = ZERO16;
-      accN1 = ZERO16;
+      accN0 = cb;
+      accN1 = cb;
       v2f y[2], x, uu;
       unsigned long long m0 = 0, m1 = 0;
       uint32_t w0 = 0, w1 = 0;
       auto piece1 = [&](int j) {            // j = pair index 0..15
         const int a0 = (j < 8) ? accC0[(j & 7) * 2] : accC1[(j & 7) * 2];
         const int a1 = (j < 8) ? accC0[(j & 7) * 2 + 1] : accC1[(j & 7) * 2 + 1];
-        if (LUT) {
-          y[j & 1] = v2f{lutc[a0], lutc[a1]};
-        } else {
-          const v2f af = {(float)a0, (float)a1};
-          v2f q = af * a.dq.rL;
-          const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
-          q = __builtin_elementwise_fma(e, v2f{a.dq.rL, a.dq.rL}, q);
-          y[j & 1] = q * a.dq.m;
-        }
+        y[j & 1] = dequant_pair<LUTM>(a0, a1, a.dq, lds);
       };
       piece1(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -592,8 +621,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       }
     };
     auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
-      const uint32_t w0 = tile_epilogue<FAST, POOL, LUT>(acc0, u[0], a.dq, lc, a.nrn, lane, lutc);
-      const uint32_t w1 = tile_epilogue<FAST, POOL, LUT>(acc1, u[1], a.dq, lc, a.nrn, lane, lutc);
+      const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(acc0, u[0], a.dq, lc, a.nrn, lane, lds);
+      const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane, lds);
       if (store_lane) {
         uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
         o[ob0] = w0;
@@ -662,26 +691,31 @@ constexpr int HROW2 = 24;                 // LDS bytes per halo row (10 px x 2 B
 constexpr int HIMG2 = HALO * HROW2;       // one timestep
 constexpr int TCHUNK = 32;                // timesteps staged per pass
 
-template <bool FAST, bool POOL, bool LUT>
+template <bool FAST, bool POOL, int LUTM>
 __global__ void __launch_bounds__(256, SNNQP_U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
-  constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
+  constexpr int LUT_BYTES = LutBytes<LUTM>::value;
+  constexpr int LUT_OFF = TCHUNK * HIMG2;
   constexpr int FL = OutStage<POOL>::FL;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
-  __shared__ __attribute__((aligned(16))) uint8_t
+  __shared__ __attribute__((aligned(16))) uint8_t   // the only LDS object: address 0
       lds[TCHUNK * HIMG2 + LUT_BYTES + OutStage<POOL>::BYTES];
-  uint32_t *obuf = (uint32_t *)(lds + TCHUNK * HIMG2 + LUT_BYTES);
+  uint32_t *obuf = (uint32_t *)(lds + LUT_OFF + LUT_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
-  const float *lutc = nullptr;
-  if (LUT) {
-    float *lut = (float *)(lds + TCHUNK * HIMG2);
-    build_lut(lut, a.lut_bound, a.dq, tid);   // visible after the first staging barrier
-    lutc = lut + a.lut_bound;
-  }
+  // tables become visible with the first staging barrier
+  if (LUTM == LUT_SHARED) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid);
+  if (LUTM == LUT_CHANNEL)
+    build_lut_channel((float *)(lds + LUT_OFF), a.lut_bound, a.dq, a.bn, blockIdx.y * 128,
+                      a.Cout, tid);
+  // start value of the accumulators: the address of this lane's entry of acc = 0
+  const v16i cb = splat16(LUTM == LUT_SHARED ? LUT_OFF + 4 * a.lut_bound
+                          : LUTM == LUT_CHANNEL
+                              ? LUT_OFF + 4 * ((wave * 32 + n) * (2 * a.lut_bound + 1) + a.lut_bound)
+                              : 0);
 
   v4i bf;
   {
@@ -756,8 +790,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         for (int k = 0; k < NT2; ++k) {
           const int task = tid + k * 256;
           const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
-          if (tt < nt)
-            *(uint16_t *)(lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2) = v[k];
+          if (tt < nt)     // table modes: counts <= 31, both bytes scale without a carry
+            *(uint16_t *)(lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2) =
+                LUTM != LUT_NONE ? (uint16_t)(v[k] << 2) : v[k];
         }
       }
       lds_barrier();
@@ -778,14 +813,14 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
               const uint32_t hi = *(const uint16_t *)(base + toff[2 * d + 1] + tl * 4 * HROW2);
               av[d] = (int)((lo | (hi << 16)) & amask[d]);
             }
-            v16i acc = ZERO16;
+            v16i acc = cb;
 #if defined(SNNQP_ABL) && (SNNQP_ABL & 2)   // diagnostic build: no MFMA
-            acc[0] = av[0]; acc[5] = av[1]; acc[9] = av[2]; acc[13] = av[3];
+            acc[0] += (av[0] ^ av[1] ^ av[2] ^ av[3]) & 4;
 #else
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{av[0], av[1], av[2], av[3]},
                                                         bf, acc, 0, 0, 0);
 #endif
-            words[tl] = tile_epilogue<FAST, POOL, LUT>(acc, u[tl], a.dq, lc, a.nrn, lane, lutc);
+            words[tl] = tile_epilogue<FAST, POOL, LUTM>(acc, u[tl], a.dq, lc, a.nrn, lane, lds);
             // one tile at a time: overlapping both tiles' temporaries costs more
             // registers than the 128-VGPR budget of 4 waves per SIMD (scratch spills)
             __builtin_amdgcn_sched_barrier(0);
@@ -888,22 +923,28 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                     a.nrn.vr == 0.0f;
   const bool pl = pool == 2;
   const unsigned gy = (unsigned)((g->Cout + 127) / 128);
-  // |acc| <= abs_sum_max * x_max; small enough -> dequantise through the LDS table
+  // |acc| <= abs_sum_max * x_max; small enough -> dequantise through an LDS table
+  // (the A operand then carries 4 * x, which must stay an int8)
   const int64_t xm = in_type == SNNQP_BITS ? 1 : x_max;
   const int64_t bound = (int64_t)w->abs_sum_max * xm;
-  a.lut_bound = (fast && w->abs_sum_max > 0 && xm > 0 && bound <= LUT_CAP) ? (int32_t)bound : 0;
-  const bool lut = a.lut_bound > 0;
-#define SNNQP_CONV_LAUNCH(KERN)                                                    \
+  const bool lut = fast && w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
+  a.lut_bound = lut ? (int32_t)bound : 0;
+  const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP;
+#define SNNQP_CONV_LAUNCH(KERN, LM)                                                \
   do {                                                                             \
-    if (fast && pl && lut) launch_persistent(KERN<true, true, true>, a, gy, st);    \
-    else if (fast && pl) launch_persistent(KERN<true, true, false>, a, gy, st);     \
-    else if (fast && lut) launch_persistent(KERN<true, false, true>, a, gy, st);    \
-    else if (fast) launch_persistent(KERN<true, false, false>, a, gy, st);          \
-    else if (pl) launch_persistent(KERN<false, true, false>, a, gy, st);            \
-    else launch_persistent(KERN<false, false, false>, a, gy, st);                   \
+    if (fast && pl) launch_persistent(KERN<true, true, LM>, a, gy, st);             \
+    else if (fast) launch_persistent(KERN<true, false, LM>, a, gy, st);             \
+    else if (pl) launch_persistent(KERN<false, true, LUT_NONE>, a, gy, st);         \
+    else launch_persistent(KERN<false, false, LUT_NONE>, a, gy, st);                \
   } while (0)
-  if (in_type == SNNQP_BITS) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel);
-  else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel);
+  if (in_type == SNNQP_BITS) {
+    if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED);
+    else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE);
+  } else {
+    if (lutc) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_CHANNEL);
+    else if (lut) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_SHARED);
+    else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_NONE);
+  }
 #undef SNNQP_CONV_LAUNCH
   SNNQP_CHECK_LAUNCH("conv3x3 mfma kernel");
   return SNNQP_OK;

@@ -21,14 +21,14 @@ inspect_f32_kernel(const float *__restrict__ x, int64_t n,
 
 __global__ void __launch_bounds__(256)
 inspect_u8_kernel(const uint8_t *__restrict__ x, int64_t n, int32_t *__restrict__ flags) {
-  int32_t f = 0;
+  int32_t m = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const uint8_t v = x[i];
-    if (v > 1) f |= SNNQP_FLAG_GT_ONE;
-    if (v > 127) f |= SNNQP_FLAG_GT_127;
-  }
-  if (f) atomicOr(flags, f);
+       i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, (int32_t)x[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  // word = (max << 8) | flags(max) grows with max, so one atomicMax keeps both
+  int32_t f = (m > 1 ? SNNQP_FLAG_GT_ONE : 0) | (m > 127 ? SNNQP_FLAG_GT_127 : 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(flags, (m << 8) | f);
 }
 
 __global__ void __launch_bounds__(256)

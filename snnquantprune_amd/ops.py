@@ -247,7 +247,7 @@ _u8_flag_cache = None
 
 def input_max_bound(x) -> int:
   """Upper bound of an integer-typed activation: 1 for spikes; for uint8 tensors
-  1 / 127 / 255 from one device pass (cached per tensor version)."""
+  the maximum (at least 1) from one device pass (cached per tensor version)."""
   global _u8_flag_cache
   if isinstance(x, PackedSpikes):
     return 1
@@ -263,7 +263,7 @@ def input_max_bound(x) -> int:
     flags = torch.zeros(1, dtype=torch.int32, device=x.device)
     L.check(L.lib().snnqp_inspect_u8(_ptr(xc), xc.numel(), _ptr(flags), _stream()))
     f = int(flags.item())
-    v = 255 if f & L.FLAG_GT_127 else (127 if f & L.FLAG_GT_ONE else 1)
+    v = max(1, f >> 8)
     _u8_flag_cache.put((x,), None, v)
   return v
 

@@ -173,6 +173,10 @@ def test_inspect_and_u8(dev):
   assert ops.inspect_f32(torch.tensor([-1.0], device=dev)) & L.FLAG_NOT_INTEGER
   assert ops.inspect_f32(torch.tensor([200.0], device=dev)) & L.FLAG_GT_127
   np.testing.assert_array_equal(_np(ops.f32_to_u8(x)), [0, 1, 3, 127])
+  for vmax in (0, 1, 2, 19, 127, 128, 255):            # exact maximum of a u8 tensor
+    xu = torch.zeros(100003, dtype=torch.uint8, device=dev)
+    xu[70001] = vmax
+    assert ops.input_max_bound(xu) == max(vmax, 1)
 
 
 def test_neurons_bit_exact(dev, oracle, golden_dir):
@@ -498,6 +502,60 @@ def test_conv_block_pipeline_tails(dev, oracle, T):
                                   pool=pool, impl=L.IMPL_MFMA, x_max=ops.input_max_bound(xin))
       np.testing.assert_array_equal(_np(s), e[key], err_msg="T=%d cin=%d pool=%d" % (T, cin, pool))
       np.testing.assert_array_equal(_np(u), e["u"])
+
+
+@pytest.mark.parametrize("mode", ["channel", "channel_nobn", "shared_counts", "shared_8bit",
+                                  "none_xmax", "c128_none", "channel_cout160"])
+def test_conv_block_table_modes(dev, oracle, mode):
+  """The MFMA kernels dequantise through LDS tables when the accumulator bound
+  allows (per-channel tables with BatchNorm folded in, one shared table, or plain
+  arithmetic); every mode gives the oracle's rasters and membrane potentials."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  cin, hw, bits, cout, lam, x_hint = 2, 16, 4, 128, None, None
+  if mode == "shared_8bit":
+    bits = 8
+  if mode == "c128_none":
+    cin, hw = 128, 8
+  if mode == "channel_cout160":
+    cout = 160
+  c = cases.conv_block_case(T=4, B=3, hw=hw, cin=cin, cout=cout, bits=bits, seed=1201,
+                            gain=5.0 if cin > 2 else 4.0, random_bn=mode != "channel_nobn")
+  x = c["x"]
+  if cin == 2:
+    if mode.startswith("channel") or mode == "shared_8bit":
+      x = np.minimum(x, 1).astype(np.uint8)              # binary events: bound = sum |code|
+    elif mode == "shared_counts":
+      x = (x * 5).astype(np.uint8)                        # counts up to ~20
+    elif mode == "none_xmax":
+      x = (x * 30).astype(np.uint8)                       # counts > 31: no table
+    c["x"] = x
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  geom = ops.ConvGeom(hw, hw, cin, cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xt = _t(c["x"], dev)
+  xin = xt if cin == 2 else ops.pack_bits(xt)
+  x_max = ops.input_max_bound(xin)
+  bound = int(w.abs_sum_max) * x_max
+  if mode.startswith("channel"):
+    assert 0 < bound <= 40, bound
+  elif mode.startswith("shared"):
+    assert 40 < bound <= 2047 and x_max <= 31, (bound, x_max)
+  elif mode == "none_xmax":
+    assert 31 < x_max <= 127
+  if mode == "c128_none":
+    x_max = 0                                             # no bound given: arithmetic dequant
+  bn = _bn(c["bn"], dev) if mode != "channel_nobn" else None
+  if bn is None:
+    qw = qweight_of(oracle, c["leaf"], c["bits"])
+    eu, es = oracle.conv_block(c["x"], qw, None, None, "int")
+    e = {"u": eu, "s_bits": packbits_lastaxis(es),
+         "pooled_bits": packbits_lastaxis(oracle.max_pool_2x2(es))}
+  for pool, key in ((2, "pooled_bits"), (1, "s_bits")):
+    u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=bn, packed_out=True, pool=pool,
+                                impl=L.IMPL_MFMA, x_max=x_max)
+    np.testing.assert_array_equal(_np(s), e[key], err_msg="%s pool=%d" % (mode, pool))
+    np.testing.assert_array_equal(_np(u), e["u"])
 
 
 def test_conv_block_xcd_split_schedule(dev, oracle):
