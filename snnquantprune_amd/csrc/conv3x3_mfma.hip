@@ -34,8 +34,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define SNNQP_U8C2_UNROLL 1
 #endif
 #ifndef SNNQP_U8C2_WPS
-#define SNNQP_U8C2_WPS 2    // waves per SIMD the conv0 kernel is compiled for: 3 and 4 spill to
-                            // scratch (per-patch code) and are no faster (17.4 ms either way)
+#define SNNQP_U8C2_WPS 3    // waves per SIMD the conv0 kernel is compiled for (168 VGPRs; uses ~135)
 #endif
 
 // Dequantisation by LDS table (fast neuron path only).  The accumulator is made
@@ -48,7 +47,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //                membrane update
 enum { LUT_NONE = 0, LUT_SHARED = 1, LUT_CHANNEL = 2 };
 constexpr int LUT_CAP = 2047;
-constexpr int LUT2_CAP = 40;
+#ifndef SNNQP_LUT2_CAP
+#define SNNQP_LUT2_CAP 40
+#endif
+constexpr int LUT2_CAP = SNNQP_LUT2_CAP;
 constexpr int LUT_XMAX = 31;                    // 4 * x must stay an int8
 template <int LUTM>
 struct LutBytes {
@@ -77,6 +79,7 @@ struct ConvMfmaArgs {
   int64_t npatch;
   int32_t lut_bound;  // > 0: |acc| <= lut_bound guaranteed, dequant by LDS table
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
+  int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
 };
 
 // 16-byte chunk c16 of halo pixel (hy, hx).  Two pixels share a 256-byte bank
@@ -166,6 +169,17 @@ struct LaneConsts {
   float bmean, bmul, bbias, dec;
 };
 
+// LDS accesses by absolute 32-bit LDS address (address space 3): the table reads
+// take the MFMA result itself as the address, with no per-read base add.
+typedef __attribute__((address_space(3))) const float lds_cfloat_t;
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8_t;
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(lds_cu8_t *)p;
+}
+__device__ __forceinline__ float lds_read_f32(uint32_t addr) {
+  return *(lds_cfloat_t *)(uintptr_t)addr;
+}
+
 // lut[i] = fl(fl((i - bound) / L) * m): the dequantised current of accumulator
 // value i - bound, built once per workgroup (same three-instruction division).
 __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &dq,
@@ -190,14 +204,11 @@ __device__ __forceinline__ void build_lut_channel(float *lut, int bound, const D
 }
 
 // Dequantised currents of two accumulator registers (two pixels, same channel).
-// Table modes: the register is the LDS byte address of its entry (`ldsb` = LDS
-// address 0).  Otherwise packed float32 ops (v_pk_*_f32 keep every rounding of
-// the scalar sequence).
+// Table modes: the register is the LDS address of its entry.  Otherwise packed
+// float32 ops (v_pk_*_f32 keep every rounding of the scalar sequence).
 template <int LUTM>
-__device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq,
-                                            const uint8_t *ldsb) {
-  if (LUTM != LUT_NONE)
-    return v2f{*(const float *)(ldsb + (uint32_t)a0), *(const float *)(ldsb + (uint32_t)a1)};
+__device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq) {
+  if (LUTM != LUT_NONE) return v2f{lds_read_f32((uint32_t)a0), lds_read_f32((uint32_t)a1)};
   const v2f a = {(float)a0, (float)a1};
   v2f q = a * dq.rL;
   const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
@@ -247,11 +258,10 @@ template <bool FAST, bool POOL, int LUTM>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
-                                                  const NeuronP &nrn, int lane,
-                                                  const uint8_t *ldsb) {
+                                                  const NeuronP &nrn, int lane) {
   v2f y[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM>(acc[2 * j], acc[2 * j + 1], dq, ldsb);
+  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM>(acc[2 * j], acc[2 * j + 1], dq);
   uint32_t myw = 0;
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
@@ -403,8 +413,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   constexpr int LUT_BYTES = LutBytes<LUTM>::value;
   constexpr int LUT_OFF = 2 * HALO_BYTES;
   constexpr int FL = OutStage<POOL>::FL;
-  // the kernel's only LDS object, i.e. LDS address 0: table addresses carried in
-  // the accumulators are offsets into this array
   __shared__ __attribute__((aligned(16))) uint8_t
       lds[2 * HALO_BYTES + LUT_BYTES + OutStage<POOL>::BYTES];
   uint32_t *obuf = (uint32_t *)(lds + LUT_OFF + LUT_BYTES);
@@ -416,7 +424,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const int cout = wave_on ? cout_base + n : n;
   if (LUTM == LUT_SHARED) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid);
   // start value of every accumulator chain: the address of the entry of acc = 0
-  const v16i cb = splat16(LUTM == LUT_SHARED ? LUT_OFF + 4 * a.lut_bound : 0);
+  const v16i cb = splat16(LUTM == LUT_SHARED ? (int)lds_addr(lds) + LUT_OFF + 4 * a.lut_bound : 0);
 
   // B operand: lane (n, h) holds W[tap][cin = 32 kk + 16 h + j][cout], j < 16:
   // k-step tap * KK + kk of this wave's 32-column block in the MFMA-tiled codes.
@@ -534,8 +542,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
                           const v16i &accC0, const v16i &accC1, int t) {
       if (!FAST) {     // general neuron kinds: branchy update, keep the two phases apart
         mfma_step(base, accN0, accN1);
-        const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(accC0, u[0], a.dq, lc, a.nrn, lane, lds);
-        const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(accC1, u[1], a.dq, lc, a.nrn, lane, lds);
+        const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(accC0, u[0], a.dq, lc, a.nrn, lane);
+        const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(accC1, u[1], a.dq, lc, a.nrn, lane);
         if (store_lane) {
           uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
           o[ob0] = w0;
@@ -557,7 +565,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       auto piece1 = [&](int j) {            // j = pair index 0..15
         const int a0 = (j < 8) ? accC0[(j & 7) * 2] : accC1[(j & 7) * 2];
         const int a1 = (j < 8) ? accC0[(j & 7) * 2 + 1] : accC1[(j & 7) * 2 + 1];
-        y[j & 1] = dequant_pair<LUTM>(a0, a1, a.dq, lds);
+        y[j & 1] = dequant_pair<LUTM>(a0, a1, a.dq);
       };
       piece1(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -621,8 +629,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       }
     };
     auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
-      const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(acc0, u[0], a.dq, lc, a.nrn, lane, lds);
-      const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane, lds);
+      const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(acc0, u[0], a.dq, lc, a.nrn, lane);
+      const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane);
       if (store_lane) {
         uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
         o[ob0] = w0;
@@ -681,44 +689,72 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// u8 event-count input with Cin = 2 (the DVS polarity pair, conv0): K = 18
-// padded to one 32-deep MFMA step, k = 2 * tap + cin.  The kernel is bound by
-// the per-neuron epilogue (one MFMA per 1024 neuron updates), so the halo of
-// ALL timesteps of a patch is staged in LDS at once (T x 240 B) and the t loop
-// runs without global loads or barriers.
+// u8 event-count input with Cin = 2 (the DVS polarity pair, conv0): K = 18 of
+// one 32-deep MFMA step.  One MFMA feeds 1024 neuron updates, so the kernel is
+// bound by the epilogue and everything else is kept off the VALU:
+//  * the halo of ALL timesteps of a patch (a chunk of <= 32) is staged in LDS at
+//    once, so the t loop has no global loads and no barriers;
+//  * each timestep image holds the 10 x 10 x 2-byte halo twice, copy c with pixel
+//    hx at byte 2 hx + 2 c of its 24-byte row: the 8 bytes that start at any pixel
+//    are then a 4-byte-aligned ds_read2_b32 in the copy of the pixel's parity, and
+//    a lane's A fragment is two such reads and no arithmetic:
+//      half 0: k 0..7 = row dy 0, k 8..15 = row dy 1   (byte b = 2 dx + cin, b < 6)
+//      half 1: k 16..23 = row dy 2, k 24..31 = constants {127,127,127,127,1,0,0,0}
+//    bytes 6, 7 of a row read belong to the next pixel; their B rows are zero;
+//  * the constant k rows carry the table address: B rows 24..28 of a channel sum
+//    to the byte address of its entry of acc = 0 (C = 0, no accumulator preload).
 // ---------------------------------------------------------------------------
-constexpr int HROW2 = 24;                 // LDS bytes per halo row (10 px x 2 B, padded)
-constexpr int HIMG2 = HALO * HROW2;       // one timestep
-constexpr int TCHUNK = 32;                // timesteps staged per pass
+constexpr int HROW2 = 24;                 // LDS bytes per halo row
+constexpr int HCOPY2 = HALO * HROW2;      // one copy of one timestep
+constexpr int HCONST2 = 2 * HCOPY2;       // the 8 constant bytes
+constexpr int HIMG2 = 496;                // one timestep image
+constexpr int TCHUNK = 32;                // most timesteps staged per pass
+
+typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef __attribute__((address_space(3))) const v2i_a4 lds_cv2i_t;
+
+// LDS bytes of the u8c2 kernel: images | table | spike words
+__host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
+  const int b = lutm == LUT_CHANNEL ? 128 * (2 * bound + 1) * 4
+                : lutm == LUT_SHARED ? (2 * bound + 2) * 4 : 0;
+  return (b + 15) & ~15;
+}
 
 template <bool FAST, bool POOL, int LUTM>
 __global__ void __launch_bounds__(256, SNNQP_U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
-  constexpr int LUT_BYTES = LutBytes<LUTM>::value;
-  constexpr int LUT_OFF = TCHUNK * HIMG2;
   constexpr int FL = OutStage<POOL>::FL;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
-  __shared__ __attribute__((aligned(16))) uint8_t   // the only LDS object: address 0
-      lds[TCHUNK * HIMG2 + LUT_BYTES + OutStage<POOL>::BYTES];
-  uint32_t *obuf = (uint32_t *)(lds + LUT_OFF + LUT_BYTES);
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tc = a.tchunk;                       // multiple of 8, <= TCHUNK
+  const int lut_off = tc * HIMG2;
+  uint32_t *obuf = (uint32_t *)(lds + lut_off + u8c2_table_bytes(LUTM, a.lut_bound));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
-  // tables become visible with the first staging barrier
-  if (LUTM == LUT_SHARED) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid);
+  // tables and constants become visible with the first staging barrier
+  if (LUTM == LUT_SHARED) build_lut((float *)(lds + lut_off), a.lut_bound, a.dq, tid);
   if (LUTM == LUT_CHANNEL)
-    build_lut_channel((float *)(lds + LUT_OFF), a.lut_bound, a.dq, a.bn, blockIdx.y * 128,
+    build_lut_channel((float *)(lds + lut_off), a.lut_bound, a.dq, a.bn, blockIdx.y * 128,
                       a.Cout, tid);
-  // start value of the accumulators: the address of this lane's entry of acc = 0
-  const v16i cb = splat16(LUTM == LUT_SHARED ? LUT_OFF + 4 * a.lut_bound
-                          : LUTM == LUT_CHANNEL
-                              ? LUT_OFF + 4 * ((wave * 32 + n) * (2 * a.lut_bound + 1) + a.lut_bound)
-                              : 0);
+  if (tid < tc) {
+    *(uint32_t *)(lds + tid * HIMG2 + HCONST2) = 0x7F7F7F7Fu;
+    *(uint32_t *)(lds + tid * HIMG2 + HCONST2 + 4) = 0x00000001u;
+  }
 
   v4i bf;
   {
+    // byte address of this lane's table entry of acc = 0, as 127 * q + r over the
+    // constant k rows: rows 24..27 take q in parts of at most 127, row 28 takes r
+    int bias = 0;
+    if (LUTM == LUT_SHARED) bias = (int)lds_addr(lds) + lut_off + 4 * a.lut_bound;
+    if (LUTM == LUT_CHANNEL)
+      bias = (int)lds_addr(lds) + lut_off +
+             4 * ((wave * 32 + n) * (2 * a.lut_bound + 1) + a.lut_bound);
+    int q = bias / 127;
+    const int r = bias - 127 * q;
     int v[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -727,7 +763,17 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       for (int j = 0; j < 4; ++j) {
         const int k = 16 * h + 4 * d + j;
         uint32_t bv = 0;
-        if (k < 18) bv = (uint8_t)a.w[(int64_t)k * a.Cout + cout];  // HWIO, Cin = 2
+        if (k < 24) {
+          const int dy = k >> 3, b = k & 7;
+          if (b < 6 && wave_on)      // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
+            bv = (uint8_t)a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
+        } else if (k < 28) {
+          const int part = q < 127 ? q : 127;
+          q -= part;
+          bv = (uint32_t)part;
+        } else if (k == 28) {
+          bv = (uint32_t)r;
+        }
         pk |= bv << (8 * j);
       }
       v[d] = (int)pk;
@@ -741,18 +787,15 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
   const int tx = (n & 3) | (((n >> 3) & 1) << 2);
-  // LDS offsets of the 8 taps this lane gathers (tap = 8h + j); lanes with
-  // h = 1 only own tap 8, their other reads are masked to zero (no branches)
-  int toff[8];
-  uint32_t amask[4];
+  // the two 8-byte reads of this lane's fragment (tile 1 is 4 halo rows further)
+  const int cpy = tx & 1;
+  const int px0 = (int)lds_addr(lds) + cpy * HCOPY2 + 2 * tx + 2 * cpy;
+  int offA[2], offB[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int tap = 8 * h + j;
-    toff[j] = tap < 9 ? (ty + tap / 3) * HROW2 + (tx + tap % 3) * 2 : 0;
+  for (int tl = 0; tl < 2; ++tl) {
+    offA[tl] = px0 + (ty + 4 * tl + (h ? 2 : 0)) * HROW2;
+    offB[tl] = h ? (int)lds_addr(lds) + HCONST2 : px0 + (ty + 4 * tl + 1) * HROW2;
   }
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-    amask[d] = h == 0 ? 0xFFFFFFFFu : (d == 0 ? 0x0000FFFFu : 0u);
   const uint8_t *xb = (const uint8_t *)a.x;
   const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
   const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
@@ -769,30 +812,32 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
     else zero_u(u);
 
-    for (int tc = 0; tc < a.T; tc += TCHUNK) {
-      const int nt = min(TCHUNK, a.T - tc);
+    for (int t0 = 0; t0 < a.T; t0 += tc) {
+      const int nt = min(tc, a.T - t0);
       PHASE_START()
-      lds_barrier();                       // previous readers of the LDS image are done
-      {
-        constexpr int NT2 = (TCHUNK * HALO * HALO + 255) / 256;
-        uint16_t v[NT2];
+      lds_barrier();                       // previous readers of the LDS images are done
+      for (int tb = 0; tb < nt * (HALO * HALO); tb += 8 * 256) {
+        uint16_t v[8];
 #pragma unroll
-        for (int k = 0; k < NT2; ++k) {      // all loads first, then all LDS writes
-          const int task = tid + k * 256;
+        for (int k = 0; k < 8; ++k) {        // all loads first, then all LDS writes
+          const int task = tb + tid + k * 256;
           const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
           const int gy = y0 + pix / HALO - 1, gx = x0 + pix % HALO - 1;
           v[k] = 0;
           if (tt < nt && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            v[k] = *(const uint16_t *)(xb + (int64_t)(tc + tt) * a.xs_t +
+            v[k] = *(const uint16_t *)(xb + (int64_t)(t0 + tt) * a.xs_t +
                                        (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * 2);
         }
 #pragma unroll
-        for (int k = 0; k < NT2; ++k) {
-          const int task = tid + k * 256;
+        for (int k = 0; k < 8; ++k) {
+          const int task = tb + tid + k * 256;
           const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
-          if (tt < nt)     // table modes: counts <= 31, both bytes scale without a carry
-            *(uint16_t *)(lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2) =
-                LUTM != LUT_NONE ? (uint16_t)(v[k] << 2) : v[k];
+          if (tt < nt) {    // table modes: counts <= 31, both bytes scale without a carry
+            const uint16_t val = LUTM != LUT_NONE ? (uint16_t)(v[k] << 2) : v[k];
+            uint8_t *p = lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2;
+            *(uint16_t *)p = val;
+            *(uint16_t *)(p + HCOPY2 + 2) = val;
+          }
         }
       }
       lds_barrier();
@@ -801,39 +846,30 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         const int nf = min(FL, nt - tf);
 #pragma unroll SNNQP_U8C2_UNROLL
         for (int tt = tf; tt < tf + nf; ++tt) {
-          const uint8_t *base = lds + tt * HIMG2;
+          const uint32_t img = (uint32_t)(tt * HIMG2);
           uint32_t words[2];
 #pragma unroll
           for (int tl = 0; tl < 2; ++tl) {
-            // A fragment: dword d = taps (8h + 2d, 8h + 2d + 1), each one u16
-            int av[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              const uint32_t lo = *(const uint16_t *)(base + toff[2 * d] + tl * 4 * HROW2);
-              const uint32_t hi = *(const uint16_t *)(base + toff[2 * d + 1] + tl * 4 * HROW2);
-              av[d] = (int)((lo | (hi << 16)) & amask[d]);
-            }
-            v16i acc = cb;
+            const v2i_a4 lo = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offA[tl]);
+            const v2i_a4 hi = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offB[tl]);
+            v16i acc = splat16(0);
 #if defined(SNNQP_ABL) && (SNNQP_ABL & 2)   // diagnostic build: no MFMA
-            acc[0] += (av[0] ^ av[1] ^ av[2] ^ av[3]) & 4;
+            acc[0] = bf.w + ((lo.x ^ lo.y ^ hi.x) & 4);
 #else
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{av[0], av[1], av[2], av[3]},
-                                                        bf, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bf, acc,
+                                                        0, 0, 0);
 #endif
-            words[tl] = tile_epilogue<FAST, POOL, LUTM>(acc, u[tl], a.dq, lc, a.nrn, lane, lds);
-            // one tile at a time: overlapping both tiles' temporaries costs more
-            // registers than the 128-VGPR budget of 4 waves per SIMD (scratch spills)
-            __builtin_amdgcn_sched_barrier(0);
+            words[tl] = tile_epilogue<FAST, POOL, LUTM>(acc, u[tl], a.dq, lc, a.nrn, lane);
           }
           if (store_lane) {
-            uint32_t *o = obuf + ((tc + tt) % FL) * (OutStage<POOL>::NPIX * 4);
+            uint32_t *o = obuf + ((t0 + tt) % FL) * (OutStage<POOL>::NPIX * 4);
             o[ob0] = words[0];
             o[ob1] = words[1];
           }
         }
         PHASE_MARK(1)
         lds_barrier();
-        flush_out<POOL>(obuf, a, tc + tf, nf, b, y0, x0, tid);
+        flush_out<POOL>(obuf, a, t0 + tf, nf, b, y0, x0, tid);
         lds_barrier();
         PHASE_MARK(2)
       }
@@ -876,11 +912,12 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
 }
 
 template <typename K>
-static void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st) {
+static void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st,
+                              size_t dyn_lds = 0) {
   int dev = 0, cus = 256, occ = 2;
   if (hipGetDevice(&dev) == hipSuccess)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, dyn_lds) != hipSuccess ||
       occ < 1)
     occ = 1;
   if (occ > 8) occ = 8;
@@ -891,7 +928,7 @@ static void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t
     gx &= ~7u;
     a.xcd_split = 1;
   }
-  hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), dyn_lds, st, a);
 }
 
 int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
@@ -929,21 +966,27 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const int64_t bound = (int64_t)w->abs_sum_max * xm;
   const bool lut = fast && w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
   a.lut_bound = lut ? (int32_t)bound : 0;
-  const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP;
-#define SNNQP_CONV_LAUNCH(KERN, LM)                                                \
+  a.tchunk = T >= TCHUNK ? TCHUNK : (T + 7) & ~7;
+  const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
+  // per-channel tables (BatchNorm folded in) while the workgroup stays within 64 KiB of LDS
+  const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP &&
+                    lds_fixed + u8c2_table_bytes(LUT_CHANNEL, (int)bound) <= 65536;
+#define SNNQP_CONV_LAUNCH(KERN, LM, LDS)                                           \
   do {                                                                             \
-    if (fast && pl) launch_persistent(KERN<true, true, LM>, a, gy, st);             \
-    else if (fast) launch_persistent(KERN<true, false, LM>, a, gy, st);             \
-    else if (pl) launch_persistent(KERN<false, true, LUT_NONE>, a, gy, st);         \
-    else launch_persistent(KERN<false, false, LUT_NONE>, a, gy, st);                \
+    if (fast && pl) launch_persistent(KERN<true, true, LM>, a, gy, st, LDS);        \
+    else if (fast) launch_persistent(KERN<true, false, LM>, a, gy, st, LDS);        \
+    else if (pl) launch_persistent(KERN<false, true, LUT_NONE>, a, gy, st, LDS);    \
+    else launch_persistent(KERN<false, false, LUT_NONE>, a, gy, st, LDS);           \
   } while (0)
   if (in_type == SNNQP_BITS) {
-    if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED);
-    else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE);
+    if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED, 0);
+    else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE, 0);
   } else {
-    if (lutc) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_CHANNEL);
-    else if (lut) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_SHARED);
-    else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_NONE);
+    const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
+    const size_t ldsb = lds_fixed + u8c2_table_bytes(lm, a.lut_bound);
+    if (lutc) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_CHANNEL, ldsb);
+    else if (lut) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_SHARED, ldsb);
+    else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_NONE, ldsb);
   }
 #undef SNNQP_CONV_LAUNCH
   SNNQP_CHECK_LAUNCH("conv3x3 mfma kernel");
