@@ -82,6 +82,8 @@ typedef struct {
   float L;
   float m;
   int32_t abs_sum_max; /* W_I8: max over outputs of sum_k |code|; 0 = unknown */
+  int32_t code_max;    /* W_I8: max |code|; 0 = unknown.  Codes of magnitude <= 7 are
+                          exact in fp6 (e2m3) and may take the f8f6f4 MFMA */
 } snnqp_weight_t;
 
 /* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),

@@ -28,7 +28,7 @@ OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 
 class WeightT(Structure):
   _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
-              ("abs_sum_max", c_int32)]
+              ("abs_sum_max", c_int32), ("code_max", c_int32)]
 
 
 class BnT(Structure):

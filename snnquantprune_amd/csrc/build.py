@@ -10,7 +10,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "quantize.hip", "spikes.hip", "elementwise.hip",
-           "generic_block.hip", "blocks.hip", "conv3x3_mfma.hip", "dense_mfma.hip"]
+           "generic_block.hip", "blocks.hip", "conv3x3_mfma.hip", "conv3x3_fp6.hip",
+           "dense_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function"]
@@ -35,7 +36,7 @@ def build(force=False, verbose=True, extra_flags=()):
   if os.environ.get("SNNQP_PROBE"):       # diagnostic build: in-kernel clock stamps
     extra_flags = tuple(extra_flags) + ("-DSNNQP_CLOCK_PROBE",)
     force = True
-  headers = [os.path.join(HERE, h) for h in ("common.h", "kernels.h")]
+  headers = [os.path.join(HERE, h) for h in ("common.h", "kernels.h", "conv_tile.h")]
   headers.append(os.path.join(HERE, "..", "..", "include", "snnqp.h"))
   headers.append(os.path.abspath(__file__))
   objs, jobs = [], []

@@ -1,0 +1,329 @@
+// Fused QuantConv(3x3, stride 1, pad 1) + BatchNorm + neuron (+ 2x2 max-pool) over
+// all T timesteps for bit-packed spikes (Cin = 128) and weight codes of magnitude
+// <= 7 (DuQ up to 4 bits).  Replaces the same reference path as conv3x3_mfma.hip:
+// SpikingBlock.__call__, spiking_learning.py:446-462, QuantConv flax_qconv.py:147-188,
+// pool examples/tcja/models.py:145-147.
+//
+// The contraction runs on the block-scaled f8f6f4 MFMA (32x32x64, K = 64 per
+// instruction): A = spikes as fp4 (e2m1: 0 or 1.0), B = codes as fp6 (e2m3: every
+// integer up to 7 is exact), f32 accumulation of integers below 2^24 -- the same
+// integer the int8 kernel accumulates, at half the A bytes per MAC through LDS (the
+// resource the int8 kernel saturates) and a faster matrix rate.
+//
+// A workgroup is 8 waves on one 8x8-pixel patch: wave w owns output channels
+// [32 (w & 3), +32) of tile w >> 2 (4x8 pixels).  The two waves that share a SIMD
+// (w and w + 4 under the observed placement -- a speed assumption only) work in
+// opposite order inside a timestep: waves 0-3 issue the 18 MFMAs of step t and
+// then run its neuron epilogue, waves 4-7 first run the epilogue of step t - 1 and
+// then the MFMAs of step t.  The matrix pipe and the VALU of a SIMD are busy at the
+// same time without interleaving two instruction streams by hand, each wave needs
+// one accumulator set, and one workgroup barrier per step suffices: within step t
+// everybody reads halo(t) and writes halo(t + 1) into the other LDS buffer.
+//
+// The halo of step t + 1 (10 x 10 pixels x 128 spike bits) is expanded to fp4 by a
+// byte -> 8-nibble LDS table and written to the other LDS buffer during step t; its
+// global load was issued a step earlier.  LDS image: two planes (64-channel
+// halves), rows of 12 pixels, 32 B per pixel = the two 16-byte lane halves, swapped
+// on odd rows: every tap/half offset is an instruction immediate and the reads
+// are bank-conflict free.
+#include "conv_tile.h"
+
+namespace snnqp {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) const v4i lds_cv4i_t;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
+
+constexpr int F6_KS = 18;                    // k-steps of 64: (tap, 64-channel half)
+constexpr int F6_PITCH = 12;                 // pixels per LDS halo row (10 used)
+constexpr int F6_PLANE = HALO * F6_PITCH * 32;   // one 64-channel half of a halo image
+constexpr int F6_HALO = 2 * F6_PLANE;        // one fp4 halo image (7680 B)
+constexpr int F6_TAB = 1024;                 // byte -> 8 fp4 nibbles
+#ifndef SNNQP_F6_PREFETCH
+#define SNNQP_F6_PREFETCH 4
+#endif
+
+// 4 int8 codes (|c| <= 7) -> 4 e2m3 codes, one per byte
+__device__ __forceinline__ uint32_t fp6_codes4(uint32_t x) {
+  const uint32_t m1 = (x >> 7) & 0x01010101u;       // 1 where negative
+  const uint32_t mag = (x ^ (m1 * 0xFFu)) + m1;     // |c| per byte (no carries)
+  // magnitude 0..7 -> 0x00 0x08 0x10 0x14 0x18 0x1A 0x1C 0x1E (v_perm byte select)
+  const uint32_t code = __builtin_amdgcn_perm(0x1E1C1A18u, 0x14100800u, mag);
+  return code | (m1 << 5);
+}
+
+// four 6-bit codes in the bytes of c -> 24 contiguous bits
+__device__ __forceinline__ uint32_t squeeze6(uint32_t c) {
+  return (c & 0x3Fu) | ((c >> 2) & 0xFC0u) | ((c >> 4) & 0x3F000u) | ((c >> 6) & 0xFC0000u);
+}
+
+// 32 int8 codes in k order (lo = k 0..15, hi = k 16..31) -> 32 fp6 values, value j
+// at bits [6j, 6j + 6) of 6 dwords (the B fragment of one lane for one k-step)
+__device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d)[6]) {
+  uint32_t t[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t[i] = squeeze6(fp6_codes4((uint32_t)lo[i]));
+    t[4 + i] = squeeze6(fp6_codes4((uint32_t)hi[i]));
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    d[3 * g + 0] = (int)(t[4 * g] | (t[4 * g + 1] << 24));
+    d[3 * g + 1] = (int)((t[4 * g + 1] >> 8) | (t[4 * g + 2] << 16));
+    d[3 * g + 2] = (int)((t[4 * g + 2] >> 16) | (t[4 * g + 3] << 8));
+  }
+}
+
+#ifdef SNNQP_F6_TRACE
+// Diagnostic build only: shader-clock stamps of one leader and one follower wave of
+// workgroup 0 inside one timestep (tools/f6_trace.py).  Never in the product.
+__device__ unsigned long long snnqp_f6_trace[2][8];
+extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(snnqp_f6_trace), 128);
+}
+#define F6_MARK(i)                                                                  \
+  if (trace_on && t == 10) snnqp_f6_trace[role][i] = __builtin_amdgcn_s_memtime();
+#else
+#define F6_MARK(i)
+#endif
+
+template <bool POOL, bool LUT>
+__global__ void __launch_bounds__(512, 1)
+conv3x3_fp6_kernel(ConvMfmaArgs a) {
+  constexpr int FL = POOL ? 16 : 4;              // timesteps per flush block
+  constexpr int SLOTS = 2 * FL;                  // ring of staged spike words
+  constexpr int NPIX = OutStage<POOL>::NPIX;
+  constexpr int TAB_OFF = 2 * F6_HALO;
+  constexpr int LUT_OFF = TAB_OFF + F6_TAB;
+  constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
+  constexpr int OB_OFF = LUT_OFF + LUT_BYTES;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16];
+  uint32_t *obuf = (uint32_t *)(lds + OB_OFF);
+  const uint32_t lds0 = lds_addr(lds) & 0x3FFFFu;   // < 2^18: offsets fold into immediates
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+#ifdef SNNQP_F6_ADJ
+  const int role = wave & 1;
+  const int cg = wave >> 1;
+#else
+  const int role = wave >> 2;                    // 1: runs one phase behind; owns tile 1
+  const int cg = wave & 3;
+#endif
+  const int cout_base = blockIdx.y * 128 + cg * 32;
+  const bool wave_on = cout_base < a.Cout;
+  const int cout = wave_on ? cout_base + n : n;
+
+  // tables: byte -> 8 nibbles (bit i set -> 1.0 = 0x2 in nibble i); dequant table
+  if (tid < 256) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) v |= ((tid >> bit) & 1) ? (0x2u << (4 * bit)) : 0u;
+    ((uint32_t *)(lds + TAB_OFF))[tid] = v;
+  }
+  if (LUT) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid, 512);
+
+  // B operand: k-step ks = 2 tap + kk covers channels 64 kk .. +63 of the tap; lane
+  // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile 4 tap + 2 kk + h
+  int bf[F6_KS][6];
+  {
+    const v4i *wtile = (const v4i *)a.wt + (int64_t)(cout_base >> 5) * 36 * 64;
+#pragma unroll
+    for (int ks = 0; ks < F6_KS; ++ks) {
+      const int ks8 = (ks >> 1) * 4 + (ks & 1) * 2 + h;
+      v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+      if (wave_on) {
+        lo = wtile[ks8 * 64 + n];
+        hi = wtile[ks8 * 64 + 32 + n];
+      }
+      fp6_pack32(lo, hi, bf[ks]);
+    }
+  }
+
+  LaneConsts lc = {0.f, 1.f, 0.f, 0.f};
+  if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
+
+  // table mode: spikes count 4 (block scale 2^2 on A) and the chain starts from the
+  // address of the entry of acc = 0, so the f32 accumulator is the table address
+  const float c0 = LUT ? (float)(lds0 + LUT_OFF + 4 * a.lut_bound) : 0.0f;
+  constexpr int SCALE_A = LUT ? 129 : 127;       // E8M0: 2^(s - 127)
+
+  const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
+  const int tx = (n & 3) | (((n >> 3) & 1) << 2);
+  // A fragment of tap (dy, dx), half kk: pixel (4 role + ty + dy, tx + dx), 32 B per
+  // pixel, the two 16-byte lane halves swapped on odd halo rows.  With the 12-pixel
+  // row pitch this makes every ds_read_b128 of the wave bank-conflict free
+  // (tools/ubench/lds_conv_patterns.hip: 222 B/clk/CU against 63 for the plain layout).
+  const uint32_t pixb = lds0 + (uint32_t)(((role * 4 + ty) * F6_PITCH + tx) * 32);
+  const uint32_t abase_even = pixb + (uint32_t)((h ^ (ty & 1)) * 16);       // dy = 0, 2
+  const uint32_t abase_odd = pixb + (uint32_t)((h ^ (ty & 1) ^ 1) * 16);    // dy = 1
+
+  // staging task of this thread: word wi of halo pixel pix
+  const int s_pix = tid >> 2, s_wi = tid & 3;
+  const bool s_task = tid < HALO * HALO * 4;
+  const int s_hy = s_pix / HALO, s_hx = s_pix % HALO;
+  uint8_t *s_dst = lds + (s_wi >> 1) * F6_PLANE + (s_hy * F6_PITCH + s_hx) * 32 +
+                   (((s_wi & 1) ^ (s_hy & 1)) * 16);
+  const uint32_t tab0 = lds0 + TAB_OFF;
+  const uint32_t *xb = (const uint32_t *)a.x;
+
+  const int ob = out_pix<POOL>(role, lane) * 4 + cg;
+  const bool store_lane = POOL ? lane < 8 : lane < 32;
+
+  lds_barrier();                                 // tables are visible
+#ifdef SNNQP_F6_TRACE
+  const bool trace_on = blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && cg == 0;
+#endif
+
+  PatchWalk pw(a);
+  for (int64_t r = pw.first; r < pw.count; r += pw.stride) {
+    int b, y0, x0;
+    pw.decode(a, r, b, y0, x0);
+
+    float u[16];
+    if (a.u0 && wave_on) {
+      u_io_tile<true>(u, a, b, y0, x0, cout, h, role);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) u[i] = 0.0f;
+    }
+
+    const int gy = y0 + s_hy - 1, gx = x0 + s_hx - 1;
+    const bool s_valid = s_task && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * 4 + s_wi;
+    uint32_t stg = 0;
+    auto stage_load = [&](int t) {
+      stg = s_valid ? xb[(int64_t)t * a.xs_t + s_goff] : 0u;
+    };
+    v4i s_exp = {0, 0, 0, 0};
+    auto stage_expand = [&]() {                  // table reads; consumed by stage_write
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
+      return;
+#endif
+      if (s_task) {
+        s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg << 2) & 0x3FCu));
+        s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 6) & 0x3FCu));
+        s_exp.z = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 14) & 0x3FCu));
+        s_exp.w = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 22) & 0x3FCu));
+      }
+    };
+    auto stage_write = [&](int buf) {
+      if (s_task) *(v4i *)(s_dst + buf * F6_HALO) = s_exp;
+    };
+    // the 18 MFMAs of one step; A fragments are fetched three k-steps ahead
+    auto a_read = [&](int buf, int ks) -> v4i {
+      const int tap = ks >> 1;
+      const uint32_t off = (uint32_t)(buf * F6_HALO + (ks & 1) * F6_PLANE +
+                                      ((tap / 3) * F6_PITCH + tap % 3) * 32);
+      return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? abase_odd : abase_even) + off);
+    };
+    auto mfma_phase = [&](int buf, v16f &acc) {
+      constexpr int PF = SNNQP_F6_PREFETCH;      // A fragments in flight ahead of the MFMA
+      v4i A[PF + 1];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
+      float c = c0;                            // splat per step (16 v_mov in the MFMA
+      asm volatile("" : "+v"(c));              // phase) instead of 16 live registers
+      acc = v16f{c, c, c, c, c, c, c, c, c, c, c, c, c, c, c, c};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < F6_KS; ++ks) {
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1)   // diagnostic build: 2 of 18 MFMAs
+        if (ks >= 2) break;
+#endif
+        if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
+        const v4i av = A[ks % (PF + 1)];
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+            v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
+            v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, acc,
+            4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+        // keep the read PF k-steps ahead of its MFMA: left alone, the scheduler moves
+        // each read next to its use and every MFMA then waits a full LDS round trip
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the MFMAs are register-only, so nothing else stops the compiler from sinking
+      // them past the barrier into the epilogue phase (which serialises the two)
+      asm volatile("" : "+v"(acc));
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto epilogue = [&](const v16f &acc, int t) {
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 2)   // diagnostic build: no epilogue
+      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = (uint32_t)acc[t & 15];
+      return;
+#endif
+      v2f y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (LUT) {
+          y[j] = v2f{lds_read_f32((uint32_t)acc[2 * j]), lds_read_f32((uint32_t)acc[2 * j + 1])};
+        } else {      // the accumulators are exact integers: same division sequence
+          const v2f af = {acc[2 * j], acc[2 * j + 1]};
+          v2f q = af * a.dq.rL;
+          const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
+          q = __builtin_elementwise_fma(e, v2f{a.dq.rL, a.dq.rL}, q);
+          y[j] = q * a.dq.m;
+        }
+      }
+      const uint32_t w = tile_neurons<true, POOL, false>(y, u, lc, a.nrn);
+      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w;
+    };
+
+    // halo(0) complete, halo(1) in flight
+    stage_load(0);
+    stage_expand();
+    stage_write(0);
+    if (a.T > 1) stage_load(1);
+    lds_barrier();
+
+    // One barrier per step.  Within step t every wave reads halo(t) and writes
+    // halo(t + 1) (the other buffer); leaders run MFMA(t) then epilogue(t), followers
+    // epilogue(t - 1) then MFMA(t), so on each SIMD one wave is on the matrix pipe
+    // while the other is on the VALU.  Block [t - 1 - FL, t - 1) of spike words is
+    // complete once the followers' epilogue(t - 2) is behind a barrier.
+    v16f acc;
+    for (int t = 0; t < a.T; ++t) {
+      if (t > FL && (t - 1) % FL == 0)
+        flush_ring<POOL, SLOTS, 512>(obuf, a, t - 1 - FL, FL, b, y0, x0, tid);
+      const bool more = t + 1 < a.T;
+      F6_MARK(0)
+      if (more) stage_expand();
+      // the word of halo(t + 2) has the whole step to arrive (its register is free
+      // again: the expansion above consumed the word of halo(t + 1))
+      if (t + 2 < a.T) stage_load(t + 2);
+      if (!role) {
+        mfma_phase(t & 1, acc);
+        F6_MARK(1)
+        if (more) stage_write((t + 1) & 1);
+        epilogue(acc, t);
+        F6_MARK(2)
+      } else {
+        if (t > 0) epilogue(acc, t - 1);
+        F6_MARK(1)
+        if (more) stage_write((t + 1) & 1);
+        mfma_phase(t & 1, acc);
+        F6_MARK(2)
+      }
+      F6_MARK(3)
+      lds_barrier();
+      F6_MARK(4)
+    }
+    if (role) epilogue(acc, a.T - 1);
+    lds_barrier();
+    {
+      const int done = a.T >= 2 ? ((a.T - 2) / FL) * FL : 0;
+      flush_ring<POOL, SLOTS, 512>(obuf, a, done, a.T - done, b, y0, x0, tid);
+    }
+    if (a.u_out && wave_on) u_io_tile<false>(u, a, b, y0, x0, cout, h, role);
+  }
+}
+
+void launch_conv3x3_fp6(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
+                        hipStream_t st) {
+  if (pool && lut) launch_persistent(conv3x3_fp6_kernel<true, true>, a, gy, st, 0, 512);
+  else if (pool) launch_persistent(conv3x3_fp6_kernel<true, false>, a, gy, st, 0, 512);
+  else if (lut) launch_persistent(conv3x3_fp6_kernel<false, true>, a, gy, st, 0, 512);
+  else launch_persistent(conv3x3_fp6_kernel<false, false>, a, gy, st, 0, 512);
+}
+
+}  // namespace snnqp

@@ -22,340 +22,9 @@
 //  * the loop is software-pipelined over t: the MFMAs of step t+1 and the
 //    dequant/BN/neuron epilogue of step t are independent instruction streams
 //    in one basic block, so the matrix pipe and the VALU overlap inside a wave.
-#include "kernels.h"
+#include "conv_tile.h"
 
 namespace snnqp {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-#ifndef SNNQP_U8C2_UNROLL
-#define SNNQP_U8C2_UNROLL 1
-#endif
-#ifndef SNNQP_U8C2_WPS
-#define SNNQP_U8C2_WPS 3    // waves per SIMD the conv0 kernel is compiled for (168 VGPRs; uses ~135)
-#endif
-
-// Dequantisation by LDS table (fast neuron path only).  The accumulator is made
-// to BE the table address: the A operand carries 4x the input (spike bytes {0,4},
-// event counts << 2) and the MFMA chain starts from C = byte address of the entry
-// of acc = 0, so ds_read_b32 takes the MFMA result as is (no index arithmetic).
-//   LUT_SHARED : one table, entry = fl(fl(acc / L) * m), |acc| <= LUT_CAP
-//   LUT_CHANNEL: one table per output channel with BatchNorm applied to the entry
-//                as well (conv0: |acc| <= LUT2_CAP), so the epilogue starts at the
-//                membrane update
-enum { LUT_NONE = 0, LUT_SHARED = 1, LUT_CHANNEL = 2 };
-constexpr int LUT_CAP = 2047;
-#ifndef SNNQP_LUT2_CAP
-#define SNNQP_LUT2_CAP 40
-#endif
-constexpr int LUT2_CAP = SNNQP_LUT2_CAP;
-constexpr int LUT_XMAX = 31;                    // 4 * x must stay an int8
-template <int LUTM>
-struct LutBytes {
-  static constexpr int value = LUTM == LUT_CHANNEL ? 128 * (2 * LUT2_CAP + 1) * 4
-                               : LUTM == LUT_SHARED ? (2 * LUT_CAP + 2) * 4 : 0;
-};
-
-constexpr int HALO = 10;
-constexpr int PIXB = 128;                       // LDS bytes per halo pixel
-constexpr int HALO_BYTES = HALO * HALO * PIXB;  // one expanded halo image
-
-struct ConvMfmaArgs {
-  const void *x;
-  int64_t xs_t, xs_b;
-  int32_t T, B, H, W, Cin, Cout;
-  const int8_t *w;   // HWIO int8 codes
-  const int8_t *wt;  // the same codes, MFMA-tiled (snnqp_pack_codes_mfma)
-  Dequant dq;
-  BnP bn;
-  NeuronP nrn;
-  const float *u0;
-  float *u_out;
-  uint32_t *s_out;
-  int32_t pool;
-  int32_t tiles_y, tiles_x;
-  int64_t npatch;
-  int32_t lut_bound;  // > 0: |acc| <= lut_bound guaranteed, dequant by LDS table
-  int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
-  int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
-};
-
-// 16-byte chunk c16 of halo pixel (hy, hx).  Two pixels share a 256-byte bank
-// row; the XOR makes the 16 lanes of every ds_read_b128 lane group (4 pixel
-// rows x 4 consecutive pixel columns, one chunk index) hit 16 distinct slots.
-__device__ __forceinline__ int halo_addr(int hy, int hx, int c16) {
-  const int g = ((hy & 3) << 1) | ((hx >> 1) & 1);
-  return (hy * HALO + hx) * PIXB + ((c16 ^ g) << 4);
-}
-
-// 16 spike bits -> 16 bytes {0, 1} (or {0, 4} when the accumulator indexes a table)
-template <bool X4>
-__device__ __forceinline__ v4i expand16(uint32_t b) {
-  constexpr uint32_t MUL = X4 ? 0x00810204u : 0x00204081u;
-  constexpr uint32_t AND = X4 ? 0x04040404u : 0x01010101u;
-  v4i o;
-  o.x = (int)((((b >> 0) & 0xFu) * MUL) & AND);
-  o.y = (int)((((b >> 4) & 0xFu) * MUL) & AND);
-  o.z = (int)((((b >> 8) & 0xFu) * MUL) & AND);
-  o.w = (int)((((b >> 12) & 0xFu) * MUL) & AND);
-  return o;
-}
-
-// Patch schedule of a persistent workgroup.  With xcd_split the workgroups that
-// share an XCD (blockIdx.x % 8 under the observed round-robin placement -- a speed
-// assumption only) walk the samples b = xcd (mod 8), neighbouring patches at the
-// same time, so the halo lines neighbouring patches share are served by that
-// XCD's L2 instead of being fetched once per XCD.
-struct PatchWalk {
-  int64_t first, count, stride;
-  int ppb, xcd;
-  bool split;
-  __device__ __forceinline__ explicit PatchWalk(const ConvMfmaArgs &a) {
-    ppb = a.tiles_y * a.tiles_x;
-    split = a.xcd_split != 0;
-    if (split) {
-      xcd = blockIdx.x & 7;
-      first = blockIdx.x >> 3;
-      stride = gridDim.x >> 3;
-      count = (int64_t)((a.B - xcd + 7) >> 3) * ppb;
-    } else {
-      xcd = 0;
-      first = blockIdx.x;
-      stride = gridDim.x;
-      count = a.npatch;
-    }
-  }
-  __device__ __forceinline__ void decode(const ConvMfmaArgs &a, int64_t r, int &b, int &y0,
-                                         int &x0) const {
-    const int within = (int)(r % ppb);
-    const int bi = (int)(r / ppb);
-    b = split ? xcd + 8 * bi : bi;
-    y0 = (within / a.tiles_x) * 8;
-    x0 = (within % a.tiles_x) * 8;
-  }
-};
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences
-// global memory, i.e. waits (vmcnt(0)) for the spike stores of the previous step
-// and the prefetched halo loads -- a full memory round trip per timestep.
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// old with lane `lane` replaced by the wave-uniform `val` (v_writelane_b32).
-// This hipcc has no __builtin_amdgcn_writelane; binding the LLVM intrinsic by its
-// name keeps the instruction visible to the compiler, which then inserts the wait
-// states a VALU-written SGPR needs before it (inline asm would hide that hazard).
-extern "C" __device__ uint32_t snnqp_writelane_i32(uint32_t, uint32_t, uint32_t)
-    __asm("llvm.amdgcn.writelane.i32");
-__device__ __forceinline__ uint32_t writelane_u32(uint32_t val, int lane, uint32_t old) {
-  return snnqp_writelane_i32(val, (uint32_t)lane, old);
-}
-
-// u with the lanes of `mask` zeroed: the hard reset reuses the ballot of the
-// threshold compare (written as a C++ select the compiler emits a second, negated
-// v_cmp per element).  VALU readers of a VALU-written SGPR need no wait states.
-__device__ __forceinline__ float reset_where(float u, unsigned long long mask) {
-  float r;
-  asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(r) : "v"(u), "s"(mask));
-  return r;
-}
-
-struct LaneConsts {
-  float bmean, bmul, bbias, dec;
-};
-
-// LDS accesses by absolute 32-bit LDS address (address space 3): the table reads
-// take the MFMA result itself as the address, with no per-read base add.
-typedef __attribute__((address_space(3))) const float lds_cfloat_t;
-typedef __attribute__((address_space(3))) const uint8_t lds_cu8_t;
-__device__ __forceinline__ uint32_t lds_addr(const void *p) {
-  return (uint32_t)(uintptr_t)(lds_cu8_t *)p;
-}
-__device__ __forceinline__ float lds_read_f32(uint32_t addr) {
-  return *(lds_cfloat_t *)(uintptr_t)addr;
-}
-
-// lut[i] = fl(fl((i - bound) / L) * m): the dequantised current of accumulator
-// value i - bound, built once per workgroup (same three-instruction division).
-__device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &dq,
-                                          int tid) {
-  for (int i = tid; i <= 2 * bound; i += 256) lut[i] = dequant_acc_nb(i - bound, dq);
-}
-
-// Per-channel tables of the workgroup's 128 output channels, row stride
-// 2 * bound + 1: entry = BatchNorm_c(dequant(acc)), the same op sequence the
-// epilogue would run (bn_apply on dequant_acc_nb), so folding changes no bit.
-__device__ __forceinline__ void build_lut_channel(float *lut, int bound, const Dequant &dq,
-                                                  const BnP &bn, int cout0, int Cout,
-                                                  int tid) {
-  const int stride = 2 * bound + 1;
-  for (int i = tid; i < 128 * stride; i += 256) {
-    const int c = i / stride, v = i - c * stride - bound;
-    const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
-    float y = dequant_acc_nb(v, dq);
-    y = bn.mean ? bn_apply(y, bn.mean[co], bn.mul[co], bn.bias[co]) : bn_apply(y, 0.f, 1.f, 0.f);
-    lut[i] = y;
-  }
-}
-
-// Dequantised currents of two accumulator registers (two pixels, same channel).
-// Table modes: the register is the LDS address of its entry.  Otherwise packed
-// float32 ops (v_pk_*_f32 keep every rounding of the scalar sequence).
-template <int LUTM>
-__device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq) {
-  if (LUTM != LUT_NONE) return v2f{lds_read_f32((uint32_t)a0), lds_read_f32((uint32_t)a1)};
-  const v2f a = {(float)a0, (float)a1};
-  v2f q = a * dq.rL;
-  const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
-  q = __builtin_elementwise_fma(e, v2f{dq.rL, dq.rL}, q);
-  return q * dq.m;
-}
-
-// BatchNorm (unless the table already applied it) + neuron for two dequantised
-// currents (two pixels, same channel).
-template <bool FAST, bool BNDONE>
-__device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
-                                            const LaneConsts &lc, const NeuronP &nrn,
-                                            unsigned long long &m0,
-                                            unsigned long long &m1) {
-#if defined(SNNQP_ABL) && (SNNQP_ABL & 1)   // diagnostic build: no BN / neuron math
-  m0 = __ballot(y.x > u0);
-  m1 = __ballot(y.y > u1);
-  return;
-#endif
-  v2f x = y;
-  if (!BNDONE) {
-    x = x - lc.bmean;
-    x = x * lc.bmul;
-    x = x + lc.bbias;
-  }
-  if (FAST) {
-    // multi_step_LIF with tau a power of two and v_reset == 0
-    // (spiking_learning.py:410-414): u - 0 == u exactly, and with float32
-    // subnormals kept (hipcc default) (u - v_th) >= 0  <=>  u >= v_th.
-    v2f uu = {u0, u1};
-    const v2f d = x - uu;
-    const v2f dk = d * nrn.inv_k;
-    uu = uu + dk;
-    m0 = __ballot(uu.x >= nrn.vth);
-    m1 = __ballot(uu.y >= nrn.vth);
-    u0 = reset_where(uu.x, m0);
-    u1 = reset_where(uu.y, m1);
-  } else {
-    m0 = __ballot(neuron_step(u0, x.x, nrn, lc.dec));
-    m1 = __ballot(neuron_step(u1, x.y, nrn, lc.dec));
-  }
-}
-
-// Whole-tile epilogue (used where no MFMA stream runs beside it): all table
-// reads are issued first, then the pairs are processed.
-template <bool FAST, bool POOL, int LUTM>
-__device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
-                                                  const Dequant &dq,
-                                                  const LaneConsts &lc,
-                                                  const NeuronP &nrn, int lane) {
-  v2f y[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM>(acc[2 * j], acc[2 * j + 1], dq);
-  uint32_t myw = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
-    unsigned long long m0, m1;
-    neuron_pair<FAST, LUTM == LUT_CHANNEL>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
-    // the masks are wave-uniform: v_writelane drops each word into the lane that
-    // stores it (no per-lane compare masks to keep in SGPRs)
-    if (POOL) {
-      const unsigned long long o = m0 | m1;
-      const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
-      myw = writelane_u32(pw, i >> 1, myw);
-    } else {
-      const int r0 = (i & 3) + 8 * (i >> 2);          // row of element i, low half
-      myw = writelane_u32((uint32_t)m0, r0, myw);
-      myw = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, myw);
-      myw = writelane_u32((uint32_t)m1, r0 + 1, myw);
-      myw = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, myw);
-    }
-  }
-  return myw;
-}
-
-// Spike words are staged in LDS, obuf[slot = t % FL][pixel][4 words of the 128-
-// channel block], and flushed with 16-byte stores: no global store sits in the
-// per-timestep loop (vmcnt stays a pure load counter there).
-template <bool POOL>
-struct OutStage {
-  static constexpr int NPIX = POOL ? 16 : 64;   // (pooled) pixels of one patch
-  static constexpr int FL = POOL ? 32 : 8;      // timesteps between flushes
-  static constexpr int BYTES = FL * NPIX * 16;
-};
-
-// patch-pixel index this lane's word of tile `tl` belongs to
-template <bool POOL>
-__device__ __forceinline__ int out_pix(int tl, int lane) {
-  if (POOL) return (tl * 2 + ((lane >> 2) & 1)) * 4 + (lane & 3);
-  const int ty = ((lane >> 2) & 1) | (((lane >> 4) & 1) << 1);
-  const int tx = (lane & 3) | (((lane >> 3) & 1) << 2);
-  return (tl * 4 + ty) * 8 + tx;
-}
-
-// Writes timesteps [t0, t0 + n) of the patch at (y0, x0) (full-resolution
-// coordinates) from obuf to global memory.  All 256 threads take part.
-template <bool POOL>
-__device__ __forceinline__ void flush_out(const uint32_t *obuf, const ConvMfmaArgs &a,
-                                          int t0, int n, int b, int y0, int x0, int tid) {
-  constexpr int NPIX = OutStage<POOL>::NPIX;
-  constexpr int PW = POOL ? 4 : 8;              // patch width in output pixels
-  const int CW = a.Cout >> 5;
-  const int cwb = blockIdx.y * 4;
-  const int nw = min(4, CW - cwb);
-  const int OH = POOL ? a.H >> 1 : a.H, OW = POOL ? a.W >> 1 : a.W;
-  const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
-  for (int i = tid; i < n * NPIX; i += 256) {
-    const int slot = i / NPIX, pix = i % NPIX;
-    const int t = t0 + slot;
-    const uint32_t *src = obuf + ((t % OutStage<POOL>::FL) * NPIX + pix) * 4;
-    uint32_t *dst = a.s_out + ((((int64_t)t * a.B + b) * OH + (oy0 + pix / PW)) * OW +
-                               (ox0 + pix % PW)) * CW + cwb;
-    if (nw == 4 && (CW & 3) == 0) {
-      *(v4i *)dst = *(const v4i *)src;
-    } else {
-      for (int w = 0; w < nw; ++w) dst[w] = src[w];
-    }
-  }
-}
-
-template <bool LOAD>
-__device__ __forceinline__ void u_io(float (&u)[2][16], const ConvMfmaArgs &a,
-                                     int b, int y0, int x0, int cout, int h) {
-  float *uo = a.u_out;
-  const float *ui = a.u0;
-#pragma unroll
-  for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int y = y0 + tl * 4 + (h | ((i >> 3) << 1));
-      const int x = x0 + (i & 7);
-      const int64_t o = (((int64_t)b * a.H + y) * a.W + x) * a.Cout + cout;
-      if (LOAD) u[tl][i] = ui[o];
-      else uo[o] = u[tl][i];
-    }
-}
-
-__device__ __forceinline__ void zero_u(float (&u)[2][16]) {
-#pragma unroll
-  for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) u[tl][i] = 0.0f;
-}
-
-__device__ __forceinline__ v16i splat16(int v) {
-  return v16i{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
-}
 
 #ifdef SNNQP_CLOCK_PROBE
 // Diagnostic build only (python csrc/build.py with SNNQP_PROBE=1): shader-clock
@@ -911,26 +580,6 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   return nullptr;
 }
 
-template <typename K>
-static void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st,
-                              size_t dyn_lds = 0) {
-  int dev = 0, cus = 256, occ = 2;
-  if (hipGetDevice(&dev) == hipSuccess)
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, dyn_lds) != hipSuccess ||
-      occ < 1)
-    occ = 1;
-  if (occ > 8) occ = 8;
-  const int64_t gmax = (int64_t)cus * occ;
-  unsigned gx = (unsigned)(a.npatch < gmax ? a.npatch : gmax);
-  a.xcd_split = 0;
-  if (gx >= 64 && a.B >= 8) {     // whole samples per XCD
-    gx &= ~7u;
-    a.xcd_split = 1;
-  }
-  hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), dyn_lds, st, a);
-}
-
 int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      int32_t T, int32_t B, const snnqp_conv_geom_t *g,
                      const snnqp_weight_t *w, const int8_t *wt,
@@ -978,7 +627,9 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     else if (pl) launch_persistent(KERN<false, true, LUT_NONE>, a, gy, st, LDS);    \
     else launch_persistent(KERN<false, false, LUT_NONE>, a, gy, st, LDS);           \
   } while (0)
-  if (in_type == SNNQP_BITS) {
+  if (in_type == SNNQP_BITS && fast && w->code_max > 0 && w->code_max <= 7) {
+    launch_conv3x3_fp6(a, pl, lut, gy, st);      // codes exact in fp6: f8f6f4 MFMA
+  } else if (in_type == SNNQP_BITS) {
     if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED, 0);
     else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE, 0);
   } else {

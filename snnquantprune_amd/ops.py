@@ -115,10 +115,11 @@ class Weight:
   m: float = 1.0
   wt: Optional[torch.Tensor] = None
   abs_sum_max: int = 0      # max over outputs of sum_k |code| (bounds |acc|)
+  code_max: int = 0         # max |code| (<= 7: exact in fp6)
 
   def struct(self) -> L.WeightT:
     return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
-                     int(self.abs_sum_max))
+                     int(self.abs_sum_max), int(self.code_max))
 
   @property
   def is_int(self):

@@ -64,8 +64,10 @@ class PackedKernel:
                                    want_fq=False, want_codes=True)
     if int(flags.item()) & (L.FLAG_CODE_OVERFLOW | L.FLAG_MASK_NOT_BINARY):
       return None
-    asm = int(codes.reshape(-1, codes.shape[-1]).to(torch.int32).abs().sum(0).max().item())
-    self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=asm)
+    mag = codes.reshape(-1, codes.shape[-1]).to(torch.int32).abs()
+    stats = torch.stack([mag.sum(0).max(), mag.max()]).tolist()     # one readback
+    self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=int(stats[0]),
+                           code_max=int(stats[1]))
     return self._int
 
   def float_weight(self) -> ops.Weight:
@@ -99,7 +101,8 @@ class PackedKernel:
         codes = codes.index_select(0, row_perm)
       codes = codes.contiguous()
       wt = ops.pack_codes_mfma(codes, n_pad) if codes.shape[0] % 32 == 0 else None
-      w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max)
+      w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max,
+                     code_max=base.code_max)
       self._wt[key] = w
     return w
 

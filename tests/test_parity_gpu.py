@@ -505,7 +505,8 @@ def test_conv_block_pipeline_tails(dev, oracle, T):
 
 
 @pytest.mark.parametrize("mode", ["channel", "channel_nobn", "shared_counts", "shared_8bit",
-                                  "none_xmax", "c128_none", "channel_cout160"])
+                                  "none_xmax", "c128_none", "channel_cout160",
+                                  "c128_i8_5bit", "c128_i8_8bit", "c128_fp6_cout160"])
 def test_conv_block_table_modes(dev, oracle, mode):
   """The MFMA kernels dequantise through LDS tables when the accumulator bound
   allows (per-channel tables with BatchNorm folded in, one shared table, or plain
@@ -515,9 +516,13 @@ def test_conv_block_table_modes(dev, oracle, mode):
   cin, hw, bits, cout, lam, x_hint = 2, 16, 4, 128, None, None
   if mode == "shared_8bit":
     bits = 8
-  if mode == "c128_none":
+  if mode.startswith("c128"):
     cin, hw = 128, 8
-  if mode == "channel_cout160":
+  if mode == "c128_i8_5bit":          # codes up to 15: int8 MFMA kernel, shared table
+    bits = 5
+  if mode == "c128_i8_8bit":          # int8 MFMA kernel, arithmetic dequant
+    bits = 8
+  if mode in ("channel_cout160", "c128_fp6_cout160"):
     cout = 160
   c = cases.conv_block_case(T=4, B=3, hw=hw, cin=cin, cout=cout, bits=bits, seed=1201,
                             gain=5.0 if cin > 2 else 4.0, random_bn=mode != "channel_nobn")

@@ -25,11 +25,11 @@ def timeit(fn, n=3):
   b.record(); torch.cuda.synchronize()
   return a.elapsed_time(b) / n
 
-CASES = ((2, 128),) if os.environ.get('ONLY_CONV0') else ((2, 128), (128, 64))
+CASES = ((2, 128),) if os.environ.get('ONLY_CONV0') else ((128, 64),) if os.environ.get('ONLY_CONV1') else ((2, 128), (128, 64))
 for cin, hw in CASES:
   w = weight(cin)
   g = ops.ConvGeom(hw, hw, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
-  for T in ((20,) if os.environ.get('ONLY_CONV0') else (1, 2, 4, 10, 20, 40)):
+  for T in ((20,) if (os.environ.get('ONLY_CONV0') or os.environ.get('ONLY_CONV1')) else (1, 2, 4, 10, 20, 40)):
     if cin == 2:
       x = (torch.rand((T, B, hw, hw, 2), device=dev) < 0.1).to(torch.uint8)
     else:
