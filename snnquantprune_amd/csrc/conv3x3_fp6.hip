@@ -10,15 +10,12 @@
 // integer the int8 kernel accumulates, at half the A bytes per MAC through LDS (the
 // resource the int8 kernel saturates) and a faster matrix rate.
 //
-// A workgroup is 8 waves on one 8x8-pixel patch: wave w owns output channels
-// [32 (w & 3), +32) of tile w >> 2 (4x8 pixels).  The two waves that share a SIMD
-// (w and w + 4 under the observed placement -- a speed assumption only) work in
-// opposite order inside a timestep: waves 0-3 issue the 18 MFMAs of step t and
-// then run its neuron epilogue, waves 4-7 first run the epilogue of step t - 1 and
-// then the MFMAs of step t.  The matrix pipe and the VALU of a SIMD are busy at the
-// same time without interleaving two instruction streams by hand, each wave needs
-// one accumulator set, and one workgroup barrier per step suffices: within step t
-// everybody reads halo(t) and writes halo(t + 1) into the other LDS buffer.
+// A workgroup is 8 waves on one 8x8-pixel patch, two waves per SIMD: wave w owns
+// output channels [32 (w & 3), +32) of tile w >> 2 (4x8 pixels), its 18 B fragments
+// (108 registers) for the whole launch, the tile's membrane potentials and two
+// accumulator sets.  The loop is software-pipelined over t inside each wave: the
+// MFMAs of step t + 1 alternate with the instructions of the neuron epilogue of step
+// t, so the matrix pipe and the VALU run together; one workgroup barrier per step.
 //
 // The halo of step t + 1 (10 x 10 pixels x 128 spike bits) is expanded to fp4 by a
 // byte -> 8-nibble LDS table and written to the other LDS buffer during step t; its
@@ -42,6 +39,9 @@ constexpr int F6_HALO = 2 * F6_PLANE;        // one fp4 halo image (7680 B)
 constexpr int F6_TAB = 1024;                 // byte -> 8 fp4 nibbles
 #ifndef SNNQP_F6_PREFETCH
 #define SNNQP_F6_PREFETCH 4
+#endif
+#ifndef SNNQP_F6_YDIST
+#define SNNQP_F6_YDIST 2
 #endif
 
 // 4 int8 codes (|c| <= 7) -> 4 e2m3 codes, one per byte
@@ -76,8 +76,8 @@ __device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d
 }
 
 #ifdef SNNQP_F6_TRACE
-// Diagnostic build only: shader-clock stamps of one leader and one follower wave of
-// workgroup 0 inside one timestep (tools/f6_trace.py).  Never in the product.
+// Diagnostic build only: clock stamps of waves 0 and 4 of workgroup 0 inside one
+// timestep (tools/f6_trace.py).  Never in the product.
 __device__ unsigned long long snnqp_f6_trace[2][8];
 extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
   return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(snnqp_f6_trace), 128);
@@ -104,13 +104,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
-#ifdef SNNQP_F6_ADJ
-  const int role = wave & 1;
-  const int cg = wave >> 1;
-#else
-  const int role = wave >> 2;                    // 1: runs one phase behind; owns tile 1
+  const int role = wave >> 2;                    // the tile (4x8 pixels) of this wave
   const int cg = wave & 3;
-#endif
   const int cout_base = blockIdx.y * 128 + cg * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
@@ -198,9 +193,6 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     };
     v4i s_exp = {0, 0, 0, 0};
     auto stage_expand = [&]() {                  // table reads; consumed by stage_write
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
-      return;
-#endif
       if (s_task) {
         s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg << 2) & 0x3FCu));
         s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 6) & 0x3FCu));
@@ -211,104 +203,184 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     auto stage_write = [&](int buf) {
       if (s_task) *(v4i *)(s_dst + buf * F6_HALO) = s_exp;
     };
-    // the 18 MFMAs of one step; A fragments are fetched three k-steps ahead
     auto a_read = [&](int buf, int ks) -> v4i {
       const int tap = ks >> 1;
       const uint32_t off = (uint32_t)(buf * F6_HALO + (ks & 1) * F6_PLANE +
                                       ((tap / 3) * F6_PITCH + tap % 3) * 32);
       return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? abase_odd : abase_even) + off);
     };
-    auto mfma_phase = [&](int buf, v16f &acc) {
-      constexpr int PF = SNNQP_F6_PREFETCH;      // A fragments in flight ahead of the MFMA
+    constexpr int PF = SNNQP_F6_PREFETCH;        // A fragments in flight ahead of the MFMA
+    auto mfma_one = [&](int ks, const v4i &av, v16f &acc) {
+      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+          v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
+          v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, acc,
+          4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+    };
+    auto splat_c0 = [&]() -> v16f {              // 16 v_mov per step, not 16 live registers
+      float c = c0;
+      asm volatile("" : "+v"(c));
+      return v16f{c, c, c, c, c, c, c, c, c, c, c, c, c, c, c, c};
+    };
+    auto dequant2 = [&](float a0, float a1) -> v2f {
+      if (LUT) return v2f{lds_read_f32((uint32_t)a0), lds_read_f32((uint32_t)a1)};
+      const v2f af = {a0, a1};       // exact integers: the same division sequence
+      v2f q = af * a.dq.rL;
+      const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
+      q = __builtin_elementwise_fma(e, v2f{a.dq.rL, a.dq.rL}, q);
+      return q * a.dq.m;
+    };
+    // MFMA(0) of a patch: nothing to overlap with
+    auto mfma_only = [&](int buf, v16f &acc) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-      float c = c0;                            // splat per step (16 v_mov in the MFMA
-      asm volatile("" : "+v"(c));              // phase) instead of 16 live registers
-      acc = v16f{c, c, c, c, c, c, c, c, c, c, c, c, c, c, c, c};
+      acc = splat_c0();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < F6_KS; ++ks) {
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1)   // diagnostic build: 2 of 18 MFMAs
-        if (ks >= 2) break;
-#endif
         if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
-        const v4i av = A[ks % (PF + 1)];
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-            v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
-            v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, acc,
-            4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
-        // keep the read PF k-steps ahead of its MFMA: left alone, the scheduler moves
-        // each read next to its use and every MFMA then waits a full LDS round trip
+        mfma_one(ks, A[ks % (PF + 1)], acc);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the MFMAs are register-only, so nothing else stops the compiler from sinking
-      // them past the barrier into the epilogue phase (which serialises the two)
-      asm volatile("" : "+v"(acc));
+    };
+    // One pipelined step in a hand-placed order: 18 slots, each = one A read PF
+    // k-steps ahead, one MFMA of step t + 1 and two quarter-pairs of the epilogue of
+    // step t (8 pairs x 4 pieces = 32 pieces), fenced so the order survives.  An MFMA
+    // that waits at the issue port (matrix pipe busy, or its accumulator not ready)
+    // blocks VALU issue for every wave of the SIMD -- another wave's VALU work does
+    // NOT overlap a back-to-back MFMA chain (tools/ubench/mfma_valu_2waves.hip: time =
+    // sum) -- so each wave spaces its MFMAs with its own epilogue instructions.
+    //   piece 0 (pair j + YD): dequantise (table reads or packed arithmetic), far enough
+    //                          ahead that the LDS round trip is over when piece 1 wants it
+    //   piece 1 (pair j)    : BatchNorm (3 packed ops)
+    //   piece 2 (pair j)    : membrane update (3 packed ops) + threshold compares
+    //   piece 3 (pair j)    : reset + spike word select
+    auto fused_step = [&](int buf, v16f &accN, const v16f &accC, int t) {
+      v4i A[PF + 1];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
+      accN = splat_c0();
+      constexpr int YD = SNNQP_F6_YDIST;         // pairs the table reads run ahead
+      v2f y[YD + 1], x = {0.f, 0.f}, uu = {0.f, 0.f};
+      unsigned long long m0 = 0, m1 = 0;
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < YD; ++j) y[j] = dequant2(accC[2 * j], accC[2 * j + 1]);
       __builtin_amdgcn_sched_barrier(0);
+      auto piece = [&](int p) {
+        const int j = p >> 2, q = p & 3;
+        if (q == 0) {
+          if (j + YD < 8) y[(j + YD) % (YD + 1)] = dequant2(accC[2 * (j + YD)], accC[2 * (j + YD) + 1]);
+        } else if (q == 1) {
+          x = y[j % (YD + 1)] - lc.bmean;
+          x = x * lc.bmul;
+          x = x + lc.bbias;
+        } else if (q == 2) {       // multi_step_LIF, tau = 2^k, v_reset = 0 (:410-414)
+          uu = v2f{u[2 * j], u[2 * j + 1]};
+          const v2f d = x - uu;
+          const v2f dk = d * a.nrn.inv_k;
+          uu = uu + dk;
+          m0 = __ballot(uu.x >= a.nrn.vth);
+          m1 = __ballot(uu.y >= a.nrn.vth);
+        } else {
+          u[2 * j] = reset_where(uu.x, m0);
+          u[2 * j + 1] = reset_where(uu.y, m1);
+          const int i = 2 * j;
+          if (POOL) {
+            const unsigned long long o = m0 | m1;
+            w = writelane_u32((uint32_t)o | (uint32_t)(o >> 32), i >> 1, w);
+          } else {
+            const int r0 = (i & 3) + 8 * (i >> 2);
+            w = writelane_u32((uint32_t)m0, r0, w);
+            w = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, w);
+            w = writelane_u32((uint32_t)m1, r0 + 1, w);
+            w = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, w);
+          }
+        }
+      };
+#pragma unroll
+      for (int ks = 0; ks < F6_KS; ++ks) {
+        if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1)   // diagnostic build: 2 of 18 MFMAs
+        if (ks < 2)
+#endif
+        mfma_one(ks, A[ks % (PF + 1)], accN);
+#if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 2))   // diagnostic build: no epilogue
+        if (2 * ks < 32) piece(2 * ks);
+        if (2 * ks + 1 < 32) piece(2 * ks + 1);
+#endif
+        // pin the slot: everything it produced is an operand of an (empty) volatile
+        // asm, so neither the MFMA nor the pieces can drift to another slot (the
+        // scheduling fence alone does not stop earlier passes from clustering the
+        // MFMAs at the end of the step)
+        // (the table reads stay free: tying them would wait out an LDS round trip)
+        asm volatile("" : "+v"(accN), "+v"(x), "+v"(uu), "+v"(w), "+s"(m0), "+s"(m1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w;
     };
     auto epilogue = [&](const v16f &acc, int t) {
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 2)   // diagnostic build: no epilogue
-      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = (uint32_t)acc[t & 15];
-      return;
-#endif
       v2f y[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (LUT) {
-          y[j] = v2f{lds_read_f32((uint32_t)acc[2 * j]), lds_read_f32((uint32_t)acc[2 * j + 1])};
-        } else {      // the accumulators are exact integers: same division sequence
-          const v2f af = {acc[2 * j], acc[2 * j + 1]};
-          v2f q = af * a.dq.rL;
-          const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
-          q = __builtin_elementwise_fma(e, v2f{a.dq.rL, a.dq.rL}, q);
-          y[j] = q * a.dq.m;
-        }
-      }
+      for (int j = 0; j < 8; ++j) y[j] = dequant2(acc[2 * j], acc[2 * j + 1]);
       const uint32_t w = tile_neurons<true, POOL, false>(y, u, lc, a.nrn);
       if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w;
     };
-
-    // halo(0) complete, halo(1) in flight
-    stage_load(0);
-    stage_expand();
-    stage_write(0);
-    if (a.T > 1) stage_load(1);
-    lds_barrier();
-
-    // One barrier per step.  Within step t every wave reads halo(t) and writes
-    // halo(t + 1) (the other buffer); leaders run MFMA(t) then epilogue(t), followers
-    // epilogue(t - 1) then MFMA(t), so on each SIMD one wave is on the matrix pipe
-    // while the other is on the VALU.  Block [t - 1 - FL, t - 1) of spike words is
-    // complete once the followers' epilogue(t - 2) is behind a barrier.
-    v16f acc;
-    for (int t = 0; t < a.T; ++t) {
-      if (t > FL && (t - 1) % FL == 0)
-        flush_ring<POOL, SLOTS, 512>(obuf, a, t - 1 - FL, FL, b, y0, x0, tid);
-      const bool more = t + 1 < a.T;
+    // staging of halo(t2) into its buffer around a step: the table reads go first, the
+    // word of halo(t2 + 1) is requested as soon as its register is free, the LDS
+    // write comes after the step's MFMAs
+    auto stage_begin = [&](int t2) {
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
+      return;
+#endif
+      if (t2 < a.T) stage_expand();
+      if (t2 + 1 < a.T) stage_load(t2 + 1);
+    };
+    auto stage_end = [&](int t2) {
+      if (t2 < a.T) stage_write(t2 & 1);
+    };
+    // one pipeline step: MFMA(t + 1) || epilogue(t); halo(t + 2) staged meanwhile.
+    // One barrier per step: inside it every wave reads halo(t + 1) and writes
+    // halo(t + 2) into the other buffer.
+    auto step = [&](int t, v16f &accN, const v16f &accC) {
+#if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 8))   // diagnostic build: no flush
+      if (t >= FL && t % FL == 0)                // steps < t are behind a barrier
+        flush_ring<POOL, SLOTS, 512>(obuf, a, t - FL, FL, b, y0, x0, tid);
+#endif
       F6_MARK(0)
-      if (more) stage_expand();
-      // the word of halo(t + 2) has the whole step to arrive (its register is free
-      // again: the expansion above consumed the word of halo(t + 1))
-      if (t + 2 < a.T) stage_load(t + 2);
-      if (!role) {
-        mfma_phase(t & 1, acc);
-        F6_MARK(1)
-        if (more) stage_write((t + 1) & 1);
-        epilogue(acc, t);
-        F6_MARK(2)
-      } else {
-        if (t > 0) epilogue(acc, t - 1);
-        F6_MARK(1)
-        if (more) stage_write((t + 1) & 1);
-        mfma_phase(t & 1, acc);
-        F6_MARK(2)
-      }
+      stage_begin(t + 2);
+      F6_MARK(1)
+      fused_step((t + 1) & 1, accN, accC, t);
+      F6_MARK(2)
+      stage_end(t + 2);
       F6_MARK(3)
       lds_barrier();
       F6_MARK(4)
+    };
+
+    // pipeline prologue: halo(0) staged; MFMA(0) while halo(1) is staged
+    v16f accA, accB;
+    stage_load(0);
+    stage_begin(0);
+    stage_end(0);
+    lds_barrier();
+    stage_begin(1);
+    mfma_only(0, accA);
+    stage_end(1);
+    lds_barrier();
+
+    // steady state, unrolled by two so the accumulator roles alternate
+    int t = 0;
+    for (; t + 2 < a.T; t += 2) {
+      step(t, accB, accA);
+      step(t + 1, accA, accB);
     }
-    if (role) epilogue(acc, a.T - 1);
+    if (t + 1 < a.T) {
+      step(t, accB, accA);
+      epilogue(accB, t + 1);
+    } else {
+      epilogue(accA, t);
+    }
     lds_barrier();
     {
       const int done = a.T >= 2 ? ((a.T - 2) / FL) * FL : 0;

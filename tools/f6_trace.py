@@ -23,6 +23,6 @@ out = (ctypes.c_ulonglong * 16)()
 L.lib().snnqp_debug_read_f6_trace.argtypes = [ctypes.c_void_p]
 print("rc", L.lib().snnqp_debug_read_f6_trace(out))
 t0 = min(out[0], out[8])
-names = ["step start", "after 1st half", "after 2nd half", "before barrier", "after barrier"]
-for r, nm in ((0, "leader  (MFMA, epilogue)"), (1, "follower (epilogue, MFMA)")):
+names = ["start", "staged-begin", "fused", "staged-end", "barrier"]
+for r, nm in ((0, "wave 0"), (1, "wave 4")):
   print(nm, " ".join("%s=%d" % (names[i], out[r * 8 + i] - t0) for i in range(5)))
