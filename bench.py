@@ -28,8 +28,14 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA, 2x the ~2.5 PF bf16 dense peak
-HBM_PEAK_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md)
+# dense peaks, MI355X_MICROARCH.md: int8 MFMA 2x the ~2.5 PF bf16 rate; block-scaled
+# fp6/fp4 MFMA ~10 PF; HBM3E 8 TB/s
+INT8_MFMA_PEAK_TOPS = 5000.0
+FP6_MFMA_PEAK_TOPS = 10000.0
+HBM_PEAK_GBS = 8000.0
+# HBM bytes per launch measured with rocprofv3 --pmc (separate passes of this same
+# command: tools/pmc_profile.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -122,43 +128,67 @@ def main():
     return
   value = world * B * args.steps / dt
 
-  # ---- roofline of the dominant kernel (HIP events inside the timed region) ----
+  # ---- per-kernel rooflines (HIP events on the launch stream, inside the timed region) ----
   kern = {}
   for tag, (n, ms) in prof.items():
     kern[tag] = {"launches": n, "avg_ms": ms / max(n, 1)}
-  dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
-  macs = {"conv3x3[128x128x2->128]": B * T * 128 * 128 * 128 * 18,
-          "conv3x3[64x64x128->128]": B * T * 64 * 64 * 128 * 1152,
-          "conv3x3[32x32x128->128]": B * T * 32 * 32 * 128 * 1152,
-          "dense[32768->110]": B * T * 32768 * 110}
-  # algorithmic HBM bytes per launch, formats the kernels really read / write
-  hbm = {"conv3x3[128x128x2->128]": B * T * (128 * 128 * 2 + 64 * 64 * 16),
-         "conv3x3[64x64x128->128]": B * T * (64 * 64 * 16 + 32 * 32 * 16),
-         "conv3x3[32x32x128->128]": B * T * (32 * 32 * 16 + 16 * 16 * 16),
-         "dense[32768->110]": B * T * (4096 + 16) + 32768 * 128}
-  for tag, k in kern.items():
-    if tag in macs:
-      k["tops"] = 2.0 * macs[tag] / (k["avg_ms"] * 1e-3) / 1e12
-      k["hbm_gbs"] = hbm[tag] / (k["avg_ms"] * 1e-3) / 1e9
-  d = kern[dom]
-  roofline = {"kernel": dom, "bound": "mfma", "achieved": d.get("tops"),
-              "peak": INT8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
-              "frac": (d.get("tops") or 0.0) / INT8_MFMA_PEAK_TOPS, "traffic": None,
-              "avg_launch_ms": d["avg_ms"]}
-  dn = kern.get("dense[32768->110]")
+  fp6 = args.bits <= 4        # codes of magnitude <= 7: fp4 x fp6 MFMA kernel for conv1/conv2
+  conv_peak = FP6_MFMA_PEAK_TOPS if fp6 else INT8_MFMA_PEAK_TOPS
+  # tag: (MACs per launch, algorithmic HBM bytes per launch in the formats the kernels
+  #       really read / write, matrix peak of the instruction the kernel issues)
+  spec = {
+      "conv3x3[128x128x2->128]": (B * T * 128 * 128 * 128 * 18,
+                                  B * T * (128 * 128 * 2 + 64 * 64 * 16), INT8_MFMA_PEAK_TOPS),
+      "conv3x3[64x64x128->128]": (B * T * 64 * 64 * 128 * 1152,
+                                  B * T * (64 * 64 * 16 + 32 * 32 * 16), conv_peak),
+      "conv3x3[32x32x128->128]": (B * T * 32 * 32 * 128 * 1152,
+                                  B * T * (32 * 32 * 16 + 16 * 16 * 16), conv_peak),
+      "dense[32768->110]": (B * T * 32768 * 110, B * T * (4096 + 16) + 32768 * 128,
+                            INT8_MFMA_PEAK_TOPS),
+  }
+  traffic = {}
+  if os.path.exists(PMC_TRAFFIC) and B == 1024 and T == 20:
+    with open(PMC_TRAFFIC) as f:
+      traffic = json.load(f).get("bytes_per_launch", {})
+
+  def roofline_of(tag):
+    k = kern[tag]
+    macs, nbytes, peak = spec[tag]
+    sec = k["avg_ms"] * 1e-3
+    tops, gbs = 2.0 * macs / sec / 1e12, nbytes / sec / 1e9
+    hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tops / peak
+    r = {"kernel": tag, "avg_launch_ms": k["avg_ms"], "traffic": traffic.get(tag),
+         "algorithmic_bytes": nbytes, "hbm_frac": hbm_frac, "mfma_frac": mfma_frac}
+    if mfma_frac >= hbm_frac:
+      r.update(bound="mfma", achieved=tops, peak=peak, unit="TFLOP/s", frac=mfma_frac)
+    else:
+      r.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac)
+    return r
+
+  rooflines = {tag: roofline_of(tag) for tag in kern if tag in spec}
+  for tag, r in rooflines.items():
+    kern[tag]["tops"] = 2.0 * spec[tag][0] / (kern[tag]["avg_ms"] * 1e-3) / 1e12
+    kern[tag]["hbm_gbs"] = spec[tag][1] / (kern[tag]["avg_ms"] * 1e-3) / 1e9
+  dom = max(rooflines, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
+  roofline = dict(rooflines[dom])
+  if dom == "conv3x3[128x128x2->128]":
+    roofline["note"] = ("conv0 does 18 MACs and 0.3 HBM bytes per neuron update; it is bound by "
+                        "VALU issue of the neuron epilogue (DESIGN.md 4.2), neither roofline")
+  dn = rooflines.get("dense[32768->110]")
   roofline_dense = None
   if dn is not None:
-    roofline_dense = {"kernel": "dense[32768->110]", "bound": "hbm",
-                      "achieved": dn["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": dn["hbm_gbs"] / HBM_PEAK_GBS, "traffic": None,
-                      "avg_launch_ms": dn["avg_ms"]}
+    roofline_dense = {"kernel": dn["kernel"], "bound": "hbm",
+                      "achieved": kern[dn["kernel"]]["hbm_gbs"], "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": dn["hbm_frac"], "traffic": dn["traffic"],
+                      "avg_launch_ms": dn["avg_launch_ms"], "mfma_frac": dn["mfma_frac"]}
 
   line = {
       "metric": "samples/sec/node (DVS128 T=20, 4-bit/90%-pruned)",
       "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-      "dtype": "int8 codes x binary spikes -> int32 acc, f32 membrane",
+      "dtype": "conv0/dense: int8 codes x u8/binary -> int32 (i8 MFMA); conv1-2: fp6 codes x "
+               "fp4 spikes -> f32 exact integers (f8f6f4 MFMA); f32 membrane",
       "data": "synthetic Poisson(0.1)>0 spikes, N(0,1/fan_in) weights, random seeds fixed",
       "config": {"workload": "C3: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->110)+LIF + vote, "
                              "DVS128 128x128x2, T=%d, %d-bit, %.0f%% pruned" %
@@ -167,6 +197,7 @@ def main():
                  "parallelism": "dp%d (batch-sharded, all-gather logits)" % world},
       "roofline": roofline,
       "roofline_dense": roofline_dense,
+      "rooflines": [rooflines[k] for k in sorted(rooflines)],
       "kernels": kern,
   }
   if world == 1 and not args.no_cpu_baseline:

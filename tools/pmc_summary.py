@@ -44,3 +44,25 @@ for k in sorted(summary):
 if out_json:
   with open(out_json, "w") as f:
     json.dump(summary, f, indent=1, sort_keys=True)
+
+# HBM bytes per launch of the bench.py kernels, keyed by bench.py's kernel tags:
+# FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts half of the bytes of wide
+# coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section) -> doubled.
+if "--traffic" in sys.argv:
+  tags = {}
+  for k, c in summary.items():
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+      continue
+    tag = None
+    if "conv3x3_u8c2_kernel" in k:
+      tag = "conv3x3[128x128x2->128]"
+    elif "conv3x3_fp6_kernel" in k or "conv3x3_bits_kernel" in k:
+      tag = "conv3x3[64x64x128->128]" if k.endswith("#0") else "conv3x3[32x32x128->128]"
+    elif "dense_mfma_kernel" in k:
+      tag = "dense[32768->110]"
+    if tag:
+      tags[tag] = int(2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024)
+  with open(sys.argv[sys.argv.index("--traffic") + 1], "w") as f:
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py "
+                         "--steps 1 --warmup 1` (tools/pmc_profile.sh), bytes = 2 * FETCH_SIZE "
+                         "KiB + WRITE_SIZE KiB", "bytes_per_launch": tags}, f, indent=1, sort_keys=True)
