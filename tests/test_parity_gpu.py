@@ -563,6 +563,30 @@ def test_conv_block_table_modes(dev, oracle, mode):
     np.testing.assert_array_equal(_np(u), e["u"])
 
 
+def test_conv_fp6_and_int8_mfma_kernels_agree(dev, oracle):
+  """Codes of magnitude <= 7 take the fp4 x fp6 MFMA kernel; the same weights with
+  code_max withheld take the int8 MFMA kernel: identical rasters and potentials
+  (and both equal the oracle), with and without the dequant table."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=7, B=9, hw=16, cin=128, seed=1301, gain=5.0)
+  e = cases.conv_block_expected(oracle, c)
+  w6 = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert 0 < w6.code_max <= 7
+  w8 = dataclasses.replace(w6, code_max=0)
+  geom = ops.ConvGeom(16, 16, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+  bn = _bn(c["bn"], dev)
+  for x_max in (1, 0):
+    for pool, key in ((2, "pooled_bits"), (1, "s_bits")):
+      outs = [ops.conv_lif_forward(xin, geom, w, _mslif(), bn=bn, packed_out=True, pool=pool,
+                                   impl=L.IMPL_MFMA, x_max=x_max) for w in (w6, w8)]
+      for u, s in outs:
+        np.testing.assert_array_equal(_np(s), e[key])
+        np.testing.assert_array_equal(_np(u), e["u"])
+
+
 def test_conv_block_xcd_split_schedule(dev, oracle):
   """Batches of 8 or more samples take the XCD-aware patch schedule (samples
   b = xcd mod 8 per XCD); uneven B = 19 leaves XCDs with different sample counts."""

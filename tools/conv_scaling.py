@@ -34,6 +34,6 @@ for cin, hw in CASES:
       x = (torch.rand((T, B, hw, hw, 2), device=dev) < 0.1).to(torch.uint8)
     else:
       x = ops.pack_bits((torch.rand((T, B, hw, hw, 128), device=dev) < 0.15).to(torch.uint8))
-    ms = timeit(lambda: ops.conv_lif_forward(x, g, w, nrn, packed_out=True, pool=2, want_u=False, x_max=1))
+    ms = timeit(lambda: ops.conv_lif_forward(x, g, w, nrn, packed_out=True, pool=2, want_u=False, x_max=int(os.environ.get('X_MAX', '1'))))
     print("cin %3d hw %3d T %2d: %.3f ms  (%.3f ms/step)" % (cin, hw, T, ms, ms / T))
     del x
