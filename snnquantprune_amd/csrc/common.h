@@ -85,6 +85,7 @@ struct NeuronP {
   int kind;
   float k;       // tau (MULTI_STEP_LIF) or sigmoid(tau_param) (PLIF)
   float inv_k;   // 1/tau when tau is a power of two (exact), else 0
+  int k_log2;    // log2(tau) when inv_k != 0
   float vth, vr;
   const float *decay;
 };
@@ -97,11 +98,15 @@ inline NeuronP make_neuron(const snnqp_neuron_t *n) {
   p.vr = n ? n->v_reset : 0.0f;
   p.decay = n ? n->decay : nullptr;
   p.inv_k = 0.0f;
+  p.k_log2 = 0;
   if (p.kind == SNNQP_NEURON_MULTI_STEP_LIF) {
     int e;
     float mant = frexpf(p.k, &e);
     // x / 2^j == x * 2^-j exactly (same real value, one rounding)
-    if (mant == 0.5f && e > -100 && e < 100) p.inv_k = 1.0f / p.k;
+    if (mant == 0.5f && e > -100 && e < 100) {
+      p.inv_k = 1.0f / p.k;
+      p.k_log2 = e - 1;
+    }
   }
   return p;
 }

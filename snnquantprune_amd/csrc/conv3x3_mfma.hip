@@ -22,6 +22,8 @@
 //  * the loop is software-pipelined over t: the MFMAs of step t+1 and the
 //    dequant/BN/neuron epilogue of step t are independent instruction streams
 //    in one basic block, so the matrix pipe and the VALU overlap inside a wave.
+#include <type_traits>
+
 #include "conv_tile.h"
 
 namespace snnqp {
@@ -384,7 +386,7 @@ typedef __attribute__((address_space(3))) const v2i_a4 lds_cv2i_t;
 
 // LDS bytes of the u8c2 kernel: images | table | spike words
 __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
-  const int b = lutm == LUT_CHANNEL ? 128 * (2 * bound + 1) * 4
+  const int b = lutm == LUT_CHANNEL ? 128 * lut_channel_stride(bound) * 4
                 : lutm == LUT_SHARED ? (2 * bound + 2) * 4 : 0;
   return (b + 15) & ~15;
 }
@@ -403,11 +405,20 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
+  // smallest non-zero |input current| of this workgroup's channels (per-channel tables
+  // only): decides whether the membrane update may be one fused multiply-add
+  uint32_t *wgmin = obuf + OutStage<POOL>::BYTES / 4;
+  if (LUTM == LUT_CHANNEL) {
+    if (tid == 0) *wgmin = 0x7F800000u;
+    lds_barrier();
+  }
   // tables and constants become visible with the first staging barrier
   if (LUTM == LUT_SHARED) build_lut((float *)(lds + lut_off), a.lut_bound, a.dq, tid);
-  if (LUTM == LUT_CHANNEL)
-    build_lut_channel((float *)(lds + lut_off), a.lut_bound, a.dq, a.bn, blockIdx.y * 128,
-                      a.Cout, tid);
+  if (LUTM == LUT_CHANNEL) {
+    const uint32_t mb = build_lut_channel((float *)(lds + lut_off), a.lut_bound, a.dq, a.bn,
+                                          blockIdx.y * 128, a.Cout, tid);
+    atomicMin(wgmin, mb);
+  }
   if (tid < tc) {
     *(uint32_t *)(lds + tid * HIMG2 + HCONST2) = 0x7F7F7F7Fu;
     *(uint32_t *)(lds + tid * HIMG2 + HCONST2 + 4) = 0x00000001u;
@@ -421,7 +432,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     if (LUTM == LUT_SHARED) bias = (int)lds_addr(lds) + lut_off + 4 * a.lut_bound;
     if (LUTM == LUT_CHANNEL)
       bias = (int)lds_addr(lds) + lut_off +
-             4 * ((wave * 32 + n) * (2 * a.lut_bound + 1) + a.lut_bound);
+             4 * ((wave * 32 + n) * lut_channel_stride(a.lut_bound) + a.lut_bound);
     int q = bias / 127;
     const int r = bias - 127 * q;
     int v[4];
@@ -511,6 +522,10 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       }
       lds_barrier();
       PHASE_MARK(0)
+      // the FL-step blocks of the chunk, with the membrane update as a fused
+      // multiply-add where that is proven bit-identical for this launch
+      auto run_chunk = [&](auto fma_tag) {
+      constexpr bool FMA = decltype(fma_tag)::value;
       for (int tf = 0; tf < nt; tf += FL) {          // FL steps, then flush
         const int nf = min(FL, nt - tf);
 #pragma unroll SNNQP_U8C2_UNROLL
@@ -528,7 +543,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bf, acc,
                                                         0, 0, 0);
 #endif
-            words[tl] = tile_epilogue<FAST, POOL, LUTM>(acc, u[tl], a.dq, lc, a.nrn, lane);
+            words[tl] = tile_epilogue<FAST, POOL, LUTM, FMA>(acc, u[tl], a.dq, lc, a.nrn, lane);
           }
           if (store_lane) {
             uint32_t *o = obuf + ((t0 + tt) % FL) * (OutStage<POOL>::NPIX * 4);
@@ -542,6 +557,12 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         lds_barrier();
         PHASE_MARK(2)
       }
+      };
+      bool fma_ok = false;
+      if (FAST && LUTM == LUT_CHANNEL)
+        fma_ok = lif_fma_is_exact(*wgmin, a.nrn.k_log2, a.T, a.u0 != nullptr);
+      if (FAST && LUTM == LUT_CHANNEL && fma_ok) run_chunk(std::true_type{});
+      else run_chunk(std::false_type{});
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
   }
@@ -616,7 +637,8 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const bool lut = fast && w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
   a.lut_bound = lut ? (int32_t)bound : 0;
   a.tchunk = T >= TCHUNK ? TCHUNK : (T + 7) & ~7;
-  const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
+  const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 +
+                           (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
   // per-channel tables (BatchNorm folded in) while the workgroup stays within 64 KiB of LDS
   const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP &&
                     lds_fixed + u8c2_table_bytes(LUT_CHANNEL, (int)bound) <= 65536;

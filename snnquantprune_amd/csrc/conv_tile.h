@@ -168,20 +168,45 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
   for (int i = tid; i <= 2 * bound; i += nthreads) lut[i] = dequant_acc_nb(i - bound, dq);
 }
 
+// Row stride (entries) of the per-channel tables.  Odd, so the 32 channels of a wave
+// fall on 32 different LDS banks when their accumulators are equal (a stride of
+// +-2 mod 64 measured 16 % slower, +-4 58 %: tools/abl_conv0.sh history in DESIGN.md).
+__host__ __device__ inline int lut_channel_stride(int bound) { return 2 * bound + 1; }
+
 // Per-channel tables of the workgroup's 128 output channels, row stride
-// 2 * bound + 1: entry = BatchNorm_c(dequant(acc)), the same op sequence the
+// lut_channel_stride(bound): entry = BatchNorm_c(dequant(acc)), the same op sequence the
 // epilogue would run (bn_apply on dequant_acc_nb), so folding changes no bit.
-__device__ __forceinline__ void build_lut_channel(float *lut, int bound, const Dequant &dq,
-                                                  const BnP &bn, int cout0, int Cout,
-                                                  int tid) {
-  const int stride = 2 * bound + 1;
+// Returns the bits of the smallest non-zero |entry| this thread wrote (+inf if none).
+__device__ __forceinline__ uint32_t build_lut_channel(float *lut, int bound, const Dequant &dq,
+                                                      const BnP &bn, int cout0, int Cout,
+                                                      int tid) {
+  const int stride = lut_channel_stride(bound);
+  uint32_t minbits = 0x7F800000u;
   for (int i = tid; i < 128 * stride; i += 256) {
     const int c = i / stride, v = i - c * stride - bound;
     const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
     float y = dequant_acc_nb(v, dq);
     y = bn.mean ? bn_apply(y, bn.mean[co], bn.mul[co], bn.bias[co]) : bn_apply(y, 0.f, 1.f, 0.f);
     lut[i] = y;
+    const uint32_t mag = __float_as_uint(y) & 0x7FFFFFFFu;
+    if (mag != 0u && mag < minbits) minbits = mag;
   }
+  return minbits;
+}
+
+// fma(d, 2^-j, u) == fl(u + fl(d * 2^-j)) for all T steps of a launch that starts from
+// u = 0 when every input current x is 0 or has |x| >= 2^(j (T + 1) - 126):
+// all x are then multiples of q = 2^(e_min - 23); by induction u_t and d_t = fl(x - u_t)
+// are multiples of q 2^(-j t) (rounding a multiple of a power of two to 24 bits keeps
+// it one), so d_t 2^-j is a multiple of q 2^(-j (t + 1)) >= 2^-149 with the significand
+// of d_t: representable, the product rounds nothing away.  `min_x_bits` = bits of the
+// smallest non-zero |x| the launch can see.
+__device__ __forceinline__ bool lif_fma_is_exact(uint32_t min_x_bits, int j, int T, bool has_u0) {
+  if (has_u0 || j < 0) return false;
+  const long long e = (long long)j * (T + 1) - 126;     // needed exponent of min |x|
+  if (e > 100) return false;
+  const uint32_t need = e <= -126 ? 0x00800000u : (uint32_t)(e + 127) << 23;
+  return min_x_bits >= need;
 }
 
 // Dequantised currents of two accumulator registers (two pixels, same channel).
@@ -199,7 +224,10 @@ __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq) {
 
 // BatchNorm (unless the table already applied it) + neuron for two dequantised
 // currents (two pixels, same channel).
-template <bool FAST, bool BNDONE>
+// FMA: u + d / tau as one fused multiply-add.  Identical to the two-step form whenever
+// d / tau is exact, i.e. never a subnormal with bits shifted out; the caller proves
+// that for the launch (lif_fma_is_exact) before taking this variant.
+template <bool FAST, bool BNDONE, bool FMA = false>
 __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
                                             const LaneConsts &lc, const NeuronP &nrn,
                                             unsigned long long &m0,
@@ -221,8 +249,12 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
     // subnormals kept (hipcc default) (u - v_th) >= 0  <=>  u >= v_th.
     v2f uu = {u0, u1};
     const v2f d = x - uu;
-    const v2f dk = d * nrn.inv_k;
-    uu = uu + dk;
+    if (FMA) {
+      uu = __builtin_elementwise_fma(d, v2f{nrn.inv_k, nrn.inv_k}, uu);
+    } else {
+      const v2f dk = d * nrn.inv_k;
+      uu = uu + dk;
+    }
     m0 = __ballot(uu.x >= nrn.vth);
     m1 = __ballot(uu.y >= nrn.vth);
     u0 = reset_where(uu.x, m0);
@@ -238,14 +270,14 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
 // and (ty + 1, tx) in its high half.  Returns the word this lane stores:
 //   POOL : lanes 0..7  = pooled pixel (pty = lane >> 2, ptx = lane & 3)
 //   !POOL: lanes 0..31 = pixel row `lane` of the tile
-template <bool FAST, bool POOL, bool BNDONE>
+template <bool FAST, bool POOL, bool BNDONE, bool FMA = false>
 __device__ __forceinline__ uint32_t tile_neurons(const v2f (&y)[8], float (&u)[16],
                                                  const LaneConsts &lc, const NeuronP &nrn) {
   uint32_t myw = 0;
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
     unsigned long long m0, m1;
-    neuron_pair<FAST, BNDONE>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
+    neuron_pair<FAST, BNDONE, FMA>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
     // the masks are wave-uniform: v_writelane drops each word into the lane that
     // stores it (no per-lane compare masks to keep in SGPRs)
     if (POOL) {
@@ -265,7 +297,7 @@ __device__ __forceinline__ uint32_t tile_neurons(const v2f (&y)[8], float (&u)[1
 
 // Whole-tile epilogue (used where no MFMA stream runs beside it): all table
 // reads are issued first, then the pairs are processed.
-template <bool FAST, bool POOL, int LUTM>
+template <bool FAST, bool POOL, int LUTM, bool FMA = false>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
@@ -273,7 +305,7 @@ __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16
   v2f y[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM>(acc[2 * j], acc[2 * j + 1], dq);
-  return tile_neurons<FAST, POOL, LUTM == LUT_CHANNEL>(y, u, lc, nrn);
+  return tile_neurons<FAST, POOL, LUTM == LUT_CHANNEL, FMA>(y, u, lc, nrn);
 }
 
 // Spike words are staged in LDS, obuf[slot = t % FL][pixel][4 words of the 128-
