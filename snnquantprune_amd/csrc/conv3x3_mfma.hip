@@ -386,7 +386,7 @@ typedef __attribute__((address_space(3))) const v2i_a4 lds_cv2i_t;
 
 // LDS bytes of the u8c2 kernel: images | table | spike words
 __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
-  const int b = lutm == LUT_CHANNEL ? 128 * lut_channel_stride(bound) * 4
+  const int b = lutm == LUT_CHANNEL ? 128 * lut_channel_rows(bound) * 4
                 : lutm == LUT_SHARED ? (2 * bound + 2) * 4 : 0;
   return (b + 15) & ~15;
 }
@@ -430,9 +430,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     // constant k rows: rows 24..27 take q in parts of at most 127, row 28 takes r
     int bias = 0;
     if (LUTM == LUT_SHARED) bias = (int)lds_addr(lds) + lut_off + 4 * a.lut_bound;
-    if (LUTM == LUT_CHANNEL)
+    if (LUTM == LUT_CHANNEL)     // the wave's block, row of acc = 0, this lane's channel
       bias = (int)lds_addr(lds) + lut_off +
-             4 * ((wave * 32 + n) * lut_channel_stride(a.lut_bound) + a.lut_bound);
+             4 * ((wave * lut_channel_rows(a.lut_bound) + a.lut_bound) * 32 + n);
     int q = bias / 127;
     const int r = bias - 127 * q;
     int v[4];
@@ -445,8 +445,10 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         uint32_t bv = 0;
         if (k < 24) {
           const int dy = k >> 3, b = k & 7;
-          if (b < 6 && wave_on)      // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
-            bv = (uint8_t)a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
+          if (b < 6 && wave_on) {    // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
+            const int code = a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
+            bv = (uint8_t)(LUTM == LUT_CHANNEL ? code * 8 : code);   // see build_lut_channel
+          }
         } else if (k < 28) {
           const int part = q < 127 ? q : 127;
           q -= part;
@@ -512,8 +514,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         for (int k = 0; k < 8; ++k) {
           const int task = tb + tid + k * 256;
           const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
-          if (tt < nt) {    // table modes: counts <= 31, both bytes scale without a carry
-            const uint16_t val = LUTM != LUT_NONE ? (uint16_t)(v[k] << 2) : v[k];
+          if (tt < nt) {    // table modes: both bytes scale without a carry (counts <= 31 / 7)
+            const uint16_t val = LUTM == LUT_CHANNEL  ? (uint16_t)(v[k] << 4)
+                                 : LUTM == LUT_SHARED ? (uint16_t)(v[k] << 2) : v[k];
             uint8_t *p = lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2;
             *(uint16_t *)p = val;
             *(uint16_t *)(p + HCOPY2 + 2) = val;
@@ -640,7 +643,9 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 +
                            (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
   // per-channel tables (BatchNorm folded in) while the workgroup stays within 64 KiB of LDS
-  const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP &&
+  // (there the accumulator counts table rows of 128 B: A = 16 x input, B = 8 x code)
+  const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP && xm <= 7 &&
+                    w->code_max > 0 && w->code_max <= 15 &&
                     lds_fixed + u8c2_table_bytes(LUT_CHANNEL, (int)bound) <= 65536;
 #define SNNQP_CONV_LAUNCH(KERN, LM, LDS)                                           \
   do {                                                                             \

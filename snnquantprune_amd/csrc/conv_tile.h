@@ -168,22 +168,23 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
   for (int i = tid; i <= 2 * bound; i += nthreads) lut[i] = dequant_acc_nb(i - bound, dq);
 }
 
-// Row stride (entries) of the per-channel tables.  Odd, so the 32 channels of a wave
-// fall on 32 different LDS banks when their accumulators are equal (a stride of
-// +-2 mod 64 measured 16 % slower, +-4 58 %: tools/abl_conv0.sh history in DESIGN.md).
-__host__ __device__ inline int lut_channel_stride(int bound) { return 2 * bound + 1; }
-
-// Per-channel tables of the workgroup's 128 output channels, row stride
-// lut_channel_stride(bound): entry = BatchNorm_c(dequant(acc)), the same op sequence the
-// epilogue would run (bn_apply on dequant_acc_nb), so folding changes no bit.
+// Per-channel tables of the workgroup's 128 output channels: one block per wave,
+// [acc + bound][32 channels] (rows of 128 B), entry = BatchNorm_c(dequant(acc)), the
+// same op sequence the epilogue would run (bn_apply on dequant_acc_nb), so folding
+// changes no bit.  With this order lane (channel c) reads LDS bank c whatever its
+// accumulator is: the table reads of a wave never conflict (the channel-major order
+// [channel][acc] lost half of its LDS cycles to conflicts of the lanes with acc != 0).
+// The accumulator must then count 128 B per unit: A carries 16 x input, B 8 x code.
+__host__ __device__ inline int lut_channel_rows(int bound) { return 2 * bound + 1; }
 // Returns the bits of the smallest non-zero |entry| this thread wrote (+inf if none).
 __device__ __forceinline__ uint32_t build_lut_channel(float *lut, int bound, const Dequant &dq,
                                                       const BnP &bn, int cout0, int Cout,
                                                       int tid) {
-  const int stride = lut_channel_stride(bound);
+  const int rows = lut_channel_rows(bound);
   uint32_t minbits = 0x7F800000u;
-  for (int i = tid; i < 128 * stride; i += 256) {
-    const int c = i / stride, v = i - c * stride - bound;
+  for (int i = tid; i < 128 * rows; i += 256) {
+    const int wv = i / (rows * 32), rem = i - wv * rows * 32;
+    const int v = (rem >> 5) - bound, c = wv * 32 + (rem & 31);
     const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
     float y = dequant_acc_nb(v, dq);
     y = bn.mean ? bn_apply(y, bn.mean[co], bn.mul[co], bn.bias[co]) : bn_apply(y, 0.f, 1.f, 0.f);
