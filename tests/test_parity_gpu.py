@@ -833,6 +833,35 @@ def test_full_size_c3_layers_against_oracle(dev, oracle):
     np.testing.assert_array_equal(_np(lb)[i:i + 1], _np(li))
 
 
+def test_full_batch_c3_properties(dev, oracle):
+  """BASELINE config 3 at the bench size (B = 1024, T = 20, 128x128x2), through
+  size-independent properties: a sample's logits do not depend on the batch it is in
+  (persistent patch schedule, XCD split, every table mode), permuting the batch
+  permutes the logits, and a repeated run is bit-identical."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  B, T = 1024, 20
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(syn.conv_net_variables(prune_p=0.9), dev)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(20261003)
+  x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < 0.095).to(torch.uint8)
+  (full, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
+  full = _np(full)
+  assert full.shape == (B, 11) and np.isfinite(full).all() and full.std() > 0
+  (again, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(again), full)
+  for b in (0, 7, 513, 1023):
+    (one, _) = model.apply(variables, x[b:b + 1], trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(one), full[b:b + 1])
+  perm = torch.randperm(B, device=dev, generator=gen)
+  (pl, _) = model.apply(variables, x[perm].contiguous(), trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(pl), full[perm.cpu().numpy()])
+  # a sub-batch that is not a multiple of 8 samples (uneven XCD shares)
+  (sub, _) = model.apply(variables, x[100:137].contiguous(), trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(sub), full[100:137])
+
+
 def test_eval_step_metrics(dev, oracle):
   from snnquantprune_amd import linen as nn
   from snnquantprune_amd import models, synthetic as syn, train_utils
