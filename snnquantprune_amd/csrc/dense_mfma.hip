@@ -4,8 +4,11 @@
 //
 // The connection is stateless across t, so the contraction is one GEMM over
 // rows m = (sample, t); only the neuron is sequential:
-//  * a workgroup (4 waves) owns SB samples x all T steps (<= RT*32 rows) and a
-//    block of 128 output features (32 per wave);
+//  * a workgroup owns SB samples x all T steps (<= RT*32 rows) and a block of 128
+//    output features; it is 8 waves = two groups of 4 (32 features per wave) that
+//    split K: group g walks the chunks c = g (mod 2) with its own LDS buffers, so
+//    twice the global loads are in flight (the K loop is latency-bound: one chunk
+//    of prefetch per wave) and the int32 partial tiles are added once at the end;
 //  * K is walked in chunks of 256: the rows' spike bits are expanded to {0,1}
 //    bytes in LDS (row stride 256 B, 16-byte chunks XOR-swizzled by row so the
 //    ds_read_b128 of an A fragment is conflict-free); the B fragments stream
@@ -59,27 +62,31 @@ __device__ __forceinline__ int a_addr(int row, int c16) {
   return row * BK + ((c16 ^ (row & 15)) << 4);
 }
 
+constexpr int KGROUPS = 2;       // wave groups splitting K
+
 template <int RT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256 * KGROUPS)
 dense_mfma_kernel(DenseMfmaArgs a) {
   constexpr int ROWS = RT * 32;
   constexpr int WPR = BK / 32;                    // words per row per chunk
   constexpr int NTASK = ROWS * WPR;
   constexpr int TPT = (NTASK + 255) / 256;
-  // two A buffers; the epilogue tile (ROWS x 128 int32) overlays them
+  // two A buffers per group; the epilogue tile (ROWS x 128 int32) overlays them
   constexpr int ABYTES = ROWS * BK;
   constexpr int EBYTES = ROWS * 128 * 4;
-  constexpr int LDSB = (2 * ABYTES > EBYTES) ? 2 * ABYTES : EBYTES;
+  constexpr int LDSB = (2 * KGROUPS * ABYTES > EBYTES) ? 2 * KGROUPS * ABYTES : EBYTES;
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDSB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = threadIdx.x >> 8;              // K group of this wave
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  uint8_t *abuf = lds + grp * 2 * ABYTES;
   const int n = lane & 31, h = lane >> 5;
   const int b0 = blockIdx.x * a.SB;
   const int nsamp = min(a.SB, a.B - b0);
   const int rows = nsamp * a.T;                   // live rows of this workgroup
   const int nb = blockIdx.y * 4 + wave;           // 32-column block of this wave
   const bool wave_on = nb * 32 < a.N;
-  const int nchunks = (a.KS + KSC - 1) / KSC;
+  const int nchunks = (a.KS + KSC - 1) / KSC;      // chunk j of this group = 2 j + grp
 
   v16i acc[RT];
 #pragma unroll
@@ -93,7 +100,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
       const int task = tid + k * 256;
       const int row = task / WPR, wi = task % WPR;
       uint32_t wv = 0;
-      const int kw = chunk * WPR + wi;
+      const int kw = (chunk * KGROUPS + grp) * WPR + wi;
       if (task < NTASK && row < rows && kw < a.KS) {
         const int bl = row / a.T, t = row - bl * a.T;
         wv = a.x[(int64_t)t * a.xs_t + (int64_t)(b0 + bl) * a.xs_b + kw];
@@ -102,7 +109,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     }
   };
   auto stage_store = [&](int buf) {
-    uint8_t *base = lds + buf * ABYTES;
+    uint8_t *base = abuf + buf * ABYTES;
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
       const int task = tid + k * 256;
@@ -122,7 +129,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   auto load_b = [&](v4i (&bf)[KSC], int chunk) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
-      const int kg = chunk * KSC + ks;
+      const int kg = (chunk * KGROUPS + grp) * KSC + ks;
       bf[ks] = kg < a.KS ? wtile[(int64_t)kg * 64] : v4i{0, 0, 0, 0};
     }
   };
@@ -144,37 +151,43 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   lds_barrier();
   // chunks beyond K contribute zero B fragments and zero A bytes, so the loop
   // runs over pairs of chunks without a tail case
-  for (int c = 0; c < nchunks; c += 2) {
+  const int ngc = (nchunks + KGROUPS - 1) / KGROUPS;     // chunks per group
+  for (int c = 0; c < ngc; c += 2) {
     stage_load(c + 1);
     load_b(bfB, c + 1);
-    compute(lds, bfA);
+    compute(abuf, bfA);
     stage_store(1);
     lds_barrier();
     stage_load(c + 2);
     load_b(bfA, c + 2);
-    compute(lds + ABYTES, bfB);
+    compute(abuf + ABYTES, bfB);
     stage_store(0);
     lds_barrier();
   }
 
   // int32 tile -> LDS [row][128]; C/D layout: col = lane & 31,
   // row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+  // (group 1 stores its partial sums, group 0 adds its own on top: exact int32)
   int *et = (int *)lds;
-  if (wave_on) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
+  for (int g = KGROUPS - 1; g >= 0; --g) {
+    if (wave_on && grp == g) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = r * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        et[row * 128 + wave * 32 + n] = acc[r][i];
-      }
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = r * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          int *e = et + row * 128 + wave * 32 + n;
+          *e = (g == KGROUPS - 1) ? acc[r][i] : *e + acc[r][i];
+        }
+    }
+    lds_barrier();
   }
-  lds_barrier();
 
   // one (sample, feature) pair per thread and pass; 64 consecutive features of
   // one sample per wave, so a ballot is two output words
   const int CW = (a.N + 31) >> 5;
-  for (int p = tid; p < a.SB * 128; p += 256) {
+  for (int p = threadIdx.x; p < a.SB * 128; p += 256 * KGROUPS) {
     const int bl = p >> 7, col = p & 127;
     const int feat = blockIdx.y * 128 + col;
     const bool live = bl < nsamp && feat < a.N;
@@ -217,7 +230,7 @@ const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
 
 template <int RT>
 static void launch_dense(const DenseMfmaArgs &a, unsigned gx, unsigned gy, hipStream_t st) {
-  hipLaunchKernelGGL((dense_mfma_kernel<RT>), dim3(gx, gy), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((dense_mfma_kernel<RT>), dim3(gx, gy), dim3(256 * KGROUPS), 0, st, a);
 }
 
 int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
