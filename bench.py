@@ -47,6 +47,8 @@ def parse():
   ap.add_argument("--frames", type=int, default=20)
   ap.add_argument("--bits", type=int, default=4)
   ap.add_argument("--prune", type=float, default=0.9)
+  ap.add_argument("--lam", type=float, default=0.1,
+                  help="Poisson rate of the synthetic events; spikes are (Poisson(lam) > 0)")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   return ap.parse_args()
@@ -64,7 +66,7 @@ def cpu_baseline(args, variables_np):
   bns = [bn_of(variables_np, i) for i in range(3)]
   dq = qweight_of(o, p["QuantDense_0"], args.bits)
   n = max(1, args.cpu_samples)
-  x = syn.poisson_spikes((n, args.frames, 128, 128, 2), 0.1, seed=4242).astype(np.float32)
+  x = syn.poisson_spikes((n, args.frames, 128, 128, 2), args.lam, seed=4242).astype(np.float32)
   o.conv3_dense_forward(x[:1, :2], cq, bns, dq, mode="float")      # warm-up, discarded
   t0 = time.perf_counter()
   o.conv3_dense_forward(x, cq, bns, dq, mode="float")
@@ -95,7 +97,7 @@ def main():
   # synthetic Poisson-spike DVS frames, resident in HBM before the timed region
   gen = torch.Generator(device=dev)
   gen.manual_seed(8627169 + rank)
-  p_spike = 1.0 - float(np.exp(-0.1))            # P(Poisson(0.1) > 0)
+  p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
   x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
 
   def step():
@@ -189,7 +191,7 @@ def main():
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
       "dtype": "conv0/dense: int8 codes x u8/binary -> int32 (i8 MFMA); conv1-2: fp6 codes x "
                "fp4 spikes -> f32 exact integers (f8f6f4 MFMA); f32 membrane",
-      "data": "synthetic Poisson(0.1)>0 spikes, N(0,1/fan_in) weights, random seeds fixed",
+      "data": "synthetic Poisson(%g)>0 spikes, N(0,1/fan_in) weights, random seeds fixed" % args.lam,
       "config": {"workload": "C3: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->110)+LIF + vote, "
                              "DVS128 128x128x2, T=%d, %d-bit, %.0f%% pruned" %
                              (T, args.bits, args.prune * 100),
