@@ -171,11 +171,38 @@ def main():
   for tag, r in rooflines.items():
     kern[tag]["tops"] = 2.0 * spec[tag][0] / (kern[tag]["avg_ms"] * 1e-3) / 1e12
     kern[tag]["hbm_gbs"] = spec[tag][1] / (kern[tag]["avg_ms"] * 1e-3) / 1e9
-  dom = max(rooflines, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
-  roofline = dict(rooflines[dom])
-  if dom == "conv3x3[128x128x2->128]":
-    roofline["note"] = ("conv0 does 18 MACs and 0.3 HBM bytes per neuron update; it is bound by "
-                        "VALU issue of the neuron epilogue (DESIGN.md 4.2), neither roofline")
+  # dominant KERNEL = the device function with the largest share of the step, as
+  # rocprofv3 --stats groups it (conv1 and conv2 are two launches of one kernel):
+  # achieved = algorithmic ops (bytes) per launch / average launch duration
+  conv_kernel = "conv3x3_fp6_kernel" if fp6 else "conv3x3_bits_kernel"
+  groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
+            "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
+            "dense_mfma_kernel": ["dense[32768->110]"]}
+  gtime = {g: sum(kern[t]["avg_ms"] * kern[t]["launches"] for t in tags if t in kern)
+           for g, tags in groups.items()}
+  dom = max(gtime, key=gtime.get)
+  tags = [t for t in groups[dom] if t in kern]
+  nl = sum(kern[t]["launches"] for t in tags)
+  avg_ms = gtime[dom] / nl
+  ops = sum(2.0 * spec[t][0] * kern[t]["launches"] for t in tags) / nl
+  nbytes = sum(spec[t][1] * kern[t]["launches"] for t in tags) / nl
+  peak = spec[tags[0]][2]
+  tops, gbs = ops / (avg_ms * 1e-3) / 1e12, nbytes / (avg_ms * 1e-3) / 1e9
+  tr = [traffic.get(t) for t in tags]
+  roofline = {"kernel": dom, "launches_per_step": len(tags), "layers": tags,
+              "avg_launch_ms": avg_ms, "algorithmic_bytes": nbytes,
+              "traffic": (sum(tr) / len(tr)) if all(v is not None for v in tr) else None,
+              "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_frac": tops / peak,
+              "share_of_step": gtime[dom] / sum(gtime.values())}
+  if tops / peak >= gbs / HBM_PEAK_GBS:
+    roofline.update(bound="mfma", achieved=tops, peak=peak, unit="TFLOP/s", frac=tops / peak)
+  else:
+    roofline.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=gbs / HBM_PEAK_GBS)
+  if "conv3x3[128x128x2->128]" in rooflines:
+    rooflines["conv3x3[128x128x2->128]"]["note"] = (
+        "conv0 does 18 MACs and 0.3 HBM bytes per neuron update; it is bound by VALU issue of "
+        "the neuron epilogue (DESIGN.md 4.2: 78 % of that bound), neither roofline")
   dn = rooflines.get("dense[32768->110]")
   roofline_dense = None
   if dn is not None:
