@@ -210,19 +210,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? abase_odd : abase_even) + off);
     };
     constexpr int PF = SNNQP_F6_PREFETCH;        // A fragments in flight ahead of the MFMA
-#ifdef SNNQP_F6_CBLIVE
-    const v16f cbv = {c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0};
-#endif
     auto mfma_one = [&](int ks, const v4i &av, v16f &acc) {
-#ifdef SNNQP_F6_CBLIVE
-      if (ks == 0) {       // the chain starts from the live bias vector: D != C, no copy
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-            v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
-            v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, cbv,
-            4, 2, 0, SCALE_A, 0, 127);
-        return;
-      }
-#endif
       acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
           v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
           v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, acc,
@@ -246,9 +234,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-#ifndef SNNQP_F6_CBLIVE
       acc = splat_c0();
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < F6_KS; ++ks) {
@@ -273,9 +259,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-#ifndef SNNQP_F6_CBLIVE
       accN = splat_c0();
-#endif
       constexpr int YD = SNNQP_F6_YDIST;         // pairs the table reads run ahead
       v2f y[YD + 1], x = {0.f, 0.f}, uu = {0.f, 0.f};
       unsigned long long m0 = 0, m1 = 0;
