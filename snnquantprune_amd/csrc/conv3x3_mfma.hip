@@ -115,18 +115,15 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
   const int tx = (n & 3) | (((n >> 3) & 1) << 2);
-  // LDS byte offset of this lane's A fragment for (tap, kk), tile 0; tile 1 is
-  // 4 halo rows further.  (kk*2 + h) ^ g == (kk*2) ^ (h ^ g) since h is bit 0.
-  int aoff[9][KK];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int hy = ty + tap / 3, hx = tx + tap % 3;
-    const int g = ((hy & 3) << 1) | ((hx >> 1) & 1);
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-      aoff[tap][kk] = (hy * HALO + hx) * PIXB + (((kk * 2) ^ (h ^ g)) << 4);
-  }
-  constexpr int TILE1 = 4 * HALO * PIXB;
+  // A fragment of (tap, kk), tile tl: pixel (4 tl + ty + dy, tx + dx) of plane kk; the
+  // lane halves are swapped on odd halo rows, so dy = 1 uses the other base
+  const int pixb = (ty * HPITCH + tx) * 32;
+  const int abase_even = pixb + ((h ^ (ty & 1)) << 4);
+  const int abase_odd = pixb + ((h ^ (ty & 1) ^ 1) << 4);
+  auto aoff = [&](int tap, int kk, int tl) -> int {
+    return ((tap / 3) & 1 ? abase_odd : abase_even) + kk * HPLANE +
+           ((tap / 3 + 4 * tl) * HPITCH + tap % 3) * 32;
+  };
   const uint32_t *xb = (const uint32_t *)a.x;
   // LDS word index of this lane's spike word (tile 0 / 1) inside one obuf slot
   const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
@@ -167,8 +164,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         if (task < NTASK) {
           const int pix = task / KK, wi = task % KK;
           const int hy = pix / HALO, hx = pix % HALO;
-          *(v4i *)(base + halo_addr(hy, hx, wi * 2)) = expand16<LUTM != LUT_NONE>(stg[k] & 0xFFFFu);
-          *(v4i *)(base + halo_addr(hy, hx, wi * 2 + 1)) = expand16<LUTM != LUT_NONE>(stg[k] >> 16);
+          *(v4i *)(base + halo_addr(hy, hx, wi, 0)) = expand16<LUTM != LUT_NONE>(stg[k] & 0xFFFFu);
+          *(v4i *)(base + halo_addr(hy, hx, wi, 1)) = expand16<LUTM != LUT_NONE>(stg[k] >> 16);
         }
       }
     };
@@ -177,8 +174,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       v4i A[2][2 * KK];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        A[0][kk] = *(const v4i *)(base + aoff[0][kk]);
-        A[0][KK + kk] = *(const v4i *)(base + aoff[0][kk] + TILE1);
+        A[0][kk] = *(const v4i *)(base + aoff(0, kk, 0));
+        A[0][KK + kk] = *(const v4i *)(base + aoff(0, kk, 1));
       }
       acc0 = cb;
       acc1 = cb;
@@ -187,8 +184,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         if (tap + 1 < 9) {
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) {
-            A[(tap + 1) & 1][kk] = *(const v4i *)(base + aoff[tap + 1][kk]);
-            A[(tap + 1) & 1][KK + kk] = *(const v4i *)(base + aoff[tap + 1][kk] + TILE1);
+            A[(tap + 1) & 1][kk] = *(const v4i *)(base + aoff(tap + 1, kk, 0));
+            A[(tap + 1) & 1][KK + kk] = *(const v4i *)(base + aoff(tap + 1, kk, 1));
           }
         }
 #pragma unroll
@@ -225,8 +222,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       v4i A[2][2 * KK];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        A[0][2 * kk] = *(const v4i *)(base + aoff[0][kk]);
-        A[0][2 * kk + 1] = *(const v4i *)(base + aoff[0][kk] + TILE1);
+        A[0][2 * kk] = *(const v4i *)(base + aoff(0, kk, 0));
+        A[0][2 * kk + 1] = *(const v4i *)(base + aoff(0, kk, 1));
       }
       accN0 = cb;
       accN1 = cb;
@@ -245,7 +242,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         const int tap = slot >> 3, m = slot & 7, kk = m >> 1, tl = m & 1;
         // A fragment for the same position of the next tap
         if (tap + 1 < 9)
-          A[(tap + 1) & 1][m] = *(const v4i *)(base + aoff[tap + 1][kk] + tl * TILE1);
+          A[(tap + 1) & 1][m] = *(const v4i *)(base + aoff(tap + 1, kk, tl));
         if (tl == 0)
           accN0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN0, 0, 0, 0);
         else

@@ -40,8 +40,15 @@ struct LutBytes {
 };
 
 constexpr int HALO = 10;
-constexpr int PIXB = 128;                       // LDS bytes per halo pixel
-constexpr int HALO_BYTES = HALO * HALO * PIXB;  // one expanded halo image
+// LDS image of one timestep's halo for the int8 kernels: four planes (the 32-channel
+// k-steps kk of a tap), rows of HPITCH pixels, 32 B per pixel = the two 16-byte lane
+// halves, swapped on odd halo rows.  Every tap / k-step / tile offset of an A fragment
+// is then an instruction immediate on one of two lane bases, and the wave's
+// ds_read_b128 are bank-conflict free (tools/ubench/lds_conv_patterns.hip: 222
+// B/clk/CU; the earlier pixel-major image with an XOR swizzle measured 63).
+constexpr int HPITCH = 12;
+constexpr int HPLANE = HALO * HPITCH * 32;      // one k-step plane
+constexpr int HALO_BYTES = 4 * HPLANE;          // one expanded halo image (Cin = 128)
 
 struct ConvMfmaArgs {
   const void *x;
@@ -63,12 +70,9 @@ struct ConvMfmaArgs {
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
 };
 
-// 16-byte chunk c16 of halo pixel (hy, hx).  Two pixels share a 256-byte bank
-// row; the XOR makes the 16 lanes of every ds_read_b128 lane group (4 pixel
-// rows x 4 consecutive pixel columns, one chunk index) hit 16 distinct slots.
-__device__ __forceinline__ int halo_addr(int hy, int hx, int c16) {
-  const int g = ((hy & 3) << 1) | ((hx >> 1) & 1);
-  return (hy * HALO + hx) * PIXB + ((c16 ^ g) << 4);
+// byte offset of half `hh` (0/1) of k-step kk of halo pixel (hy, hx)
+__device__ __forceinline__ int halo_addr(int hy, int hx, int kk, int hh) {
+  return kk * HPLANE + (hy * HPITCH + hx) * 32 + ((hh ^ (hy & 1)) << 4);
 }
 
 // 16 spike bits -> 16 bytes {0, 1} (or {0, 4} when the accumulator indexes a table)
