@@ -1,0 +1,181 @@
+// Float32 connection (no neuron) on the f32 MFMA: the `fseq` contract of the layer API
+// -- y[m][n] = fmaf chain over k ascending of x[m][k] * w[k][n], k = (kh, kw, cin) for
+// convolutions -- for the real-valued activations of the reference's TCJA blocks
+// (gate * spikes into conv_t and dense1, examples/tcja/models.py:149-187, 200-208).
+// Replaces lax.conv_general_dilated (flax_qconv.py:158-168) / lax.dot_general
+// (flax_qdense.py:87-89) for float32 inputs and fake-quantised float32 kernels.
+//
+// v_mfma_f32_32x32x2_f32 accumulates its two k products into C in ascending k order with
+// one rounding each -- a chain of these MFMAs IS the fmaf chain (tools/ubench/
+// mfma_f32_order.hip: 0 mismatches of 1024 against the host fmaf chain, ~70 % against any
+// other order), so the matrix cores run the contract bit for bit.
+//
+// GEMM M x N x K with M = images x OH x OW output pixels, N = Cout, K = KH KW Cin.  A
+// workgroup (4 waves) owns a 128 x 128 tile, wave w the 64 x 64 quadrant (w >> 1, w & 1)
+// = 2 x 2 MFMA tiles.  K is walked in chunks of 16: the A chunk is gathered from the NHWC
+// input (a chunk lies inside one tap because Cin % 16 == 0: one 64-byte run per row, zero
+// for padding) and kept k-major in LDS, the B chunk is 16 rows of the [K][N] kernel;
+// register-staged one chunk ahead.  Shapes: 3x3 / stride 1 / pad 1 convolutions and dense
+// layers (1x1 on a 1x1 image); everything else stays on the direct-form kernel.
+#include "kernels.h"
+
+namespace snnqp {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int FG_BM = 128, FG_BN = 128, FG_KC = 16;
+constexpr int FG_LD = 160;      // LDS row stride (floats) of one k: 128 + 32, so the two lane
+                                // halves (k, k + 1) of an MFMA operand read disjoint banks
+
+struct FseqGemmArgs {
+  const float *x;       // [NB][H][W][Cin]
+  const float *w;       // [K][N]
+  float *y;             // [M][N]
+  int64_t M;
+  int32_t N, K, H, W, Cin, KH, KW, pad_h, pad_w;
+};
+
+__global__ void __launch_bounds__(256)
+fseq_gemm_kernel(FseqGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][FG_KC * FG_LD];   // [buf][A|B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * FG_BM;
+  const int n0 = blockIdx.y * FG_BN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  // staging tasks.  A: row ar of the tile, 8 consecutive k (two float4); B: k row bk,
+  // 8 consecutive columns
+  const int ar = tid >> 1, ak = (tid & 1) * 8;
+  const int64_t am = m0 + ar;
+  const bool arow = am < a.M;
+  int oy = 0, ox = 0;
+  int64_t img = 0;
+  if (arow) {
+    const int64_t hw = (int64_t)a.H * a.W;
+    img = am / hw;
+    const int p = (int)(am - img * hw);
+    oy = p / a.W;
+    ox = p - oy * a.W;
+  }
+  const int bk = tid >> 4, bc = (tid & 15) * 8;
+  v4f ra[2], rb[2];
+  auto load_chunk = [&](int kc) {          // global -> registers
+    const int k0 = kc * FG_KC;
+    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
+    const bool ok = arow && k0 < a.K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float *src = a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0 + ak;
+    ra[0] = ok ? *(const v4f *)src : v4f{0.f, 0.f, 0.f, 0.f};
+    ra[1] = ok ? *(const v4f *)(src + 4) : v4f{0.f, 0.f, 0.f, 0.f};
+    const int kb = k0 + bk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + bc + 4 * j;
+      v4f v = {0.f, 0.f, 0.f, 0.f};
+      if (kb < a.K) {
+        const float *wr = a.w + (int64_t)kb * a.N + col;
+        if (col + 3 < a.N && (a.N & 3) == 0) {
+          v = *(const v4f *)wr;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < a.N) v[e] = wr[e];
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {        // registers -> LDS (A transposed to k-major)
+    float *la = lds[buf][0], *lb = lds[buf][1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) la[(ak + 4 * j + e) * FG_LD + ar] = ra[j][e];
+    *(v4f *)(lb + bk * FG_LD + bc) = rb[0];
+    *(v4f *)(lb + bk * FG_LD + bc + 4) = rb[1];
+  };
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int nchunks = (a.K + FG_KC - 1) / FG_KC;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nchunks) load_chunk(kc + 1);
+    const float *la = lds[buf][0], *lb = lds[buf][1];
+#pragma unroll
+    for (int s = 0; s < FG_KC / 2; ++s) {          // k pairs, ascending
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = la[(2 * s + h) * FG_LD + wm + 32 * i + r];
+        bv[i] = lb[(2 * s + h) * FG_LD + wn + 32 * i + r];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + 32 * j + r;
+      if (col >= a.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < a.M) a.y[row * a.N + col] = acc[i][j][e];
+      }
+    }
+}
+
+// nullptr when the kernel serves the request, else the reason
+const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,
+                                  const snnqp_weight_t *w) {
+  if (in_type != SNNQP_F32 || w->wtype != SNNQP_W_F32) return "not float32 x float32";
+  if (g->groups != 1) return "grouped";
+  if (g->stride_h != 1 || g->stride_w != 1) return "strided";
+  if (g->in_dil_h != 1 || g->in_dil_w != 1 || g->k_dil_h != 1 || g->k_dil_w != 1) return "dilated";
+  if (g->Cin % FG_KC) return "Cin % 16";
+  const bool same = g->pad_h_lo == g->pad_h_hi && g->pad_w_lo == g->pad_w_hi &&
+                    g->KH == 2 * g->pad_h_lo + 1 && g->KW == 2 * g->pad_w_lo + 1;
+  if (!same) return "not a same-size odd kernel";
+  return nullptr;
+}
+
+int run_fseq_gemm(const float *x, int64_t NB, const snnqp_conv_geom_t *g,
+                  const snnqp_weight_t *w, float *y, hipStream_t st) {
+  FseqGemmArgs a;
+  a.x = x; a.w = (const float *)w->w; a.y = y;
+  a.M = NB * g->H * g->W;
+  a.N = g->Cout; a.K = g->KH * g->KW * g->Cin;
+  a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.KH = g->KH; a.KW = g->KW;
+  a.pad_h = g->pad_h_lo; a.pad_w = g->pad_w_lo;
+  if (a.M == 0 || a.N == 0) return SNNQP_OK;
+  const int64_t gx = ceil_div64(a.M, FG_BM);
+  SNNQP_REQUIRE(gx < (1ll << 31), SNNQP_EINVAL, "fseq gemm: grid too large");
+  hipLaunchKernelGGL(fseq_gemm_kernel, dim3((unsigned)gx, (unsigned)((a.N + FG_BN - 1) / FG_BN)),
+                     dim3(256), 0, st, a);
+  SNNQP_CHECK_LAUNCH("fseq_gemm_kernel");
+  return SNNQP_OK;
+}
+
+}  // namespace snnqp

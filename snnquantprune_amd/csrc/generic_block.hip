@@ -7,7 +7,7 @@
 //   INT   int8 codes x integer input (u8 counts or spike bits): exact int32
 //         accumulator, current = fl(fl(acc / L) * m)
 //   FSEQ  float32 weights x any input: fmaf chain over (kh, kw, cin) ascending
-#include "common.h"
+#include "kernels.h"
 
 namespace snnqp {
 
@@ -220,6 +220,13 @@ extern "C" int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
   SNNQP_REQUIRE(NB >= 0 && NB < (1ll << 31), SNNQP_EINVAL, "conv_forward: bad NB");
   const int64_t pix = (in_type == SNNQP_BITS) ? (g->Cin + 31) / 32 : g->Cin;
   const int64_t img = (int64_t)g->H * g->W * pix;
+  // float32 inputs and kernels of the common shapes: the same fmaf chain on the f32 MFMA
+  if (x && w && w->w && y && !acc && !fseq_gemm_unsupported(in_type, g, w)) {
+    int32_t OH, OW;
+    const int rc = check_geom(g, &OH, &OW);
+    if (rc) return rc;
+    return run_fseq_gemm((const float *)x, NB, g, w, y, (hipStream_t)stream);
+  }
   // the NB images are the "batch"; T = 1
   return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr,
                      nullptr, nullptr, y, SNNQP_F32, acc, (hipStream_t)stream);

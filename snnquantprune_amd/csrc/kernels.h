@@ -21,6 +21,12 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
                      int x_max, hipStream_t st);
 
+// float32 x float32 connection on the f32 MFMA (fseq_gemm.hip)
+const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,
+                                  const snnqp_weight_t *w);
+int run_fseq_gemm(const float *x, int64_t NB, const snnqp_conv_geom_t *g,
+                  const snnqp_weight_t *w, float *y, hipStream_t st);
+
 const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
                                    const snnqp_weight_t *w, const int8_t *wt,
                                    const snnqp_neuron_t *nrn, int s_type);

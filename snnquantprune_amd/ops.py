@@ -171,6 +171,9 @@ class ConvGeom:
                        self.in_dil[0], self.in_dil[1], self.k_dil[0],
                        self.k_dil[1], self.groups)
 
+  def tag(self) -> str:
+    return "%dx%dx%d->%d" % (self.H, self.W, self.Cin, self.Cout)
+
   def out_hw(self) -> Tuple[int, int]:
     oh, ow = ctypes.c_int32(), ctypes.c_int32()
     g = self.struct()
@@ -303,6 +306,15 @@ def unpack_bits(s: PackedSpikes) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # connection only
 # ---------------------------------------------------------------------------
+
+
+def fseq_gemm_supported(geom: ConvGeom) -> bool:
+  """Shapes the float32-MFMA connection kernel serves (fseq_gemm.hip): same-size odd
+  kernels, stride 1, no dilation or groups, Cin % 16 == 0 (dense = 1x1 on a 1x1 image)."""
+  (pt, pb), (pl, pr) = geom.pad
+  return (geom.groups == 1 and tuple(geom.stride) == (1, 1) and tuple(geom.in_dil) == (1, 1)
+          and tuple(geom.k_dil) == (1, 1) and geom.Cin % 16 == 0 and pt == pb and pl == pr
+          and geom.KH == 2 * pt + 1 and geom.KW == 2 * pl + 1)
 
 
 def conv_forward(x, geom: ConvGeom, weight: Weight, want_acc: bool = False):

@@ -264,6 +264,29 @@ class SpikingBlock(nn.Module):
     nrn = self.neural_dynamics.neuron(conn.features)
     bn = norm.coeffs(conn.features) if norm is not None else None
 
+    # real-valued activations (the TCJA-gated blocks): the connection runs on the f32
+    # MFMA (same fmaf chain as the direct-form kernel), then BatchNorm + neuron scan
+    if (not integer and tm and self.impl == L.IMPL_AUTO and w.wtype == L.W_F32
+        and isinstance(x, torch.Tensor) and x.dtype == torch.float32):
+      geom = None
+      if is_dense and x.ndim == 3:
+        geom = ops.ConvGeom(1, 1, cin, conn.features, 1, 1)
+      elif not is_dense and len(conn._ksize()) == 2 and x.ndim == 5:
+        geom = conn.geometry(tuple(x.shape[2:-1]), cin)
+      if geom is not None and ops.fseq_gemm_supported(geom):
+        T, B = x.shape[0], x.shape[1]
+        xi = x.reshape((T * B,) + ((1, 1, cin) if is_dense else tuple(x.shape[2:])))
+        with ops._timed("%s[f32 %s]" % ("dense" if is_dense else "conv", geom.tag())):
+          y = ops.conv_forward(xi, geom, w)
+        y = y.reshape((T, B) + ((conn.features,) if is_dense else tuple(y.shape[1:])))
+        u_out, s = ops.lif_forward(y, nrn, bn=bn, u0=u0, want_u=self.return_state,
+                                   packed_out=packed_out)
+        if self.pool == 2:
+          if is_dense:
+            raise ValueError("pool=2 needs a convolutional block")
+          s = ops.maxpool2x2(s)
+        return u_out, s
+
     if is_dense:
       if x.ndim != 3:
         raise ValueError("QuantDense block expects [T, B, K] inputs, got %s" % (x.shape,))
