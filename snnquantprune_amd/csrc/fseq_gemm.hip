@@ -13,10 +13,12 @@
 // GEMM M x N x K with M = images x OH x OW output pixels, N = Cout, K = KH KW Cin.  A
 // workgroup (4 waves) owns a 128 x 128 tile, wave w the 64 x 64 quadrant (w >> 1, w & 1)
 // = 2 x 2 MFMA tiles.  K is walked in chunks of 16: the A chunk is gathered from the NHWC
-// input (a chunk lies inside one tap because Cin % 16 == 0: one 64-byte run per row, zero
-// for padding) and kept k-major in LDS, the B chunk is 16 rows of the [K][N] kernel;
-// register-staged one chunk ahead.  Shapes: 3x3 / stride 1 / pad 1 convolutions and dense
-// layers (1x1 on a 1x1 image); everything else stays on the direct-form kernel.
+// input (runs of 4 consecutive channels never straddle a tap because Cin % 4 == 0; zero for
+// padding) and kept k-major in LDS, the B chunk is 16 rows of the [K][N] kernel;
+// register-staged one chunk ahead.  Shapes: stride-1, undilated, ungrouped convolutions
+// whose output has the input's size (3x3 pad 1, the 1-D k = 4 SAME convolutions of the
+// TCJA gate, ...) and dense layers (1x1 on a 1x1 image); everything else stays on the
+// direct-form kernel.
 #include "kernels.h"
 
 namespace snnqp {
@@ -36,6 +38,8 @@ struct FseqGemmArgs {
   int32_t N, K, H, W, Cin, KH, KW, pad_h, pad_w;
 };
 
+// CHUNK_IN_TAP: Cin % 16 == 0, a k chunk never straddles a tap (one address computation)
+template <bool CHUNK_IN_TAP>
 __global__ void __launch_bounds__(256)
 fseq_gemm_kernel(FseqGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][FG_KC * FG_LD];   // [buf][A|B]
@@ -63,13 +67,25 @@ fseq_gemm_kernel(FseqGemmArgs a) {
   v4f ra[2], rb[2];
   auto load_chunk = [&](int kc) {          // global -> registers
     const int k0 = kc * FG_KC;
-    const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
-    const bool ok = arow && k0 < a.K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    const float *src = a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0 + ak;
-    ra[0] = ok ? *(const v4f *)src : v4f{0.f, 0.f, 0.f, 0.f};
-    ra[1] = ok ? *(const v4f *)(src + 4) : v4f{0.f, 0.f, 0.f, 0.f};
+    if (CHUNK_IN_TAP) {
+      const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
+      const bool ok = arow && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float *src = a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0 + ak;
+      ra[0] = ok ? *(const v4f *)src : v4f{0.f, 0.f, 0.f, 0.f};
+      ra[1] = ok ? *(const v4f *)(src + 4) : v4f{0.f, 0.f, 0.f, 0.f};
+    } else
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = k0 + ak + 4 * j;          // 4 consecutive k = 4 channels of one tap
+      const int tap = kk / a.Cin, c0 = kk - tap * a.Cin;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
+      const bool ok = arow && kk < a.K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      ra[j] = ok ? *(const v4f *)(a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0)
+                 : v4f{0.f, 0.f, 0.f, 0.f};
+    }
     const int kb = k0 + bk;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -154,10 +170,9 @@ const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,
   if (g->groups != 1) return "grouped";
   if (g->stride_h != 1 || g->stride_w != 1) return "strided";
   if (g->in_dil_h != 1 || g->in_dil_w != 1 || g->k_dil_h != 1 || g->k_dil_w != 1) return "dilated";
-  if (g->Cin % FG_KC) return "Cin % 16";
-  const bool same = g->pad_h_lo == g->pad_h_hi && g->pad_w_lo == g->pad_w_hi &&
-                    g->KH == 2 * g->pad_h_lo + 1 && g->KW == 2 * g->pad_w_lo + 1;
-  if (!same) return "not a same-size odd kernel";
+  if (g->Cin % 4) return "Cin % 4";
+  if (g->pad_h_lo + g->pad_h_hi != g->KH - 1 || g->pad_w_lo + g->pad_w_hi != g->KW - 1)
+    return "output size differs from input size";
   return nullptr;
 }
 
@@ -172,8 +187,9 @@ int run_fseq_gemm(const float *x, int64_t NB, const snnqp_conv_geom_t *g,
   if (a.M == 0 || a.N == 0) return SNNQP_OK;
   const int64_t gx = ceil_div64(a.M, FG_BM);
   SNNQP_REQUIRE(gx < (1ll << 31), SNNQP_EINVAL, "fseq gemm: grid too large");
-  hipLaunchKernelGGL(fseq_gemm_kernel, dim3((unsigned)gx, (unsigned)((a.N + FG_BN - 1) / FG_BN)),
-                     dim3(256), 0, st, a);
+  const dim3 grid((unsigned)gx, (unsigned)((a.N + FG_BN - 1) / FG_BN));
+  if (a.Cin % FG_KC == 0) hipLaunchKernelGGL(fseq_gemm_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(fseq_gemm_kernel<false>, grid, dim3(256), 0, st, a);
   SNNQP_CHECK_LAUNCH("fseq_gemm_kernel");
   return SNNQP_OK;
 }

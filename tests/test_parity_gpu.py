@@ -597,6 +597,39 @@ def test_conv_fp6_and_int8_mfma_kernels_agree(dev, oracle):
         np.testing.assert_array_equal(_np(u), e["u"])
 
 
+@pytest.mark.parametrize("shape", ["dense_2048_512", "dense_odd", "conv3x3_c128", "conv3x3_c16",
+                                   "conv5x5", "conv1d_k4_same", "conv_1x1"])
+def test_float_connection_f32_mfma(dev, oracle, shape):
+  """float32 activations x float32 (fake-quantised) kernels run on the f32 MFMA
+  (fseq_gemm.hip); the result is the oracle's k-ascending fmaf chain bit for bit,
+  for sizes that are not multiples of the 128 x 128 tile as well."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(4401))
+  mixed = lambda shp: (rng.standard_normal(shp) * np.exp2(rng.integers(-6, 7, shp))).astype(F32)
+  if shape.startswith("dense"):
+    M, K, N = (1280, 2048, 512) if shape == "dense_2048_512" else (37, 20, 7)
+    x, k = mixed((M, K)), mixed((K, N))
+    geom = ops.ConvGeom(1, 1, K, N, 1, 1)
+    assert ops.fseq_gemm_supported(geom)
+    y = ops.conv_forward(_t(x.reshape(M, 1, 1, K), dev), geom, ops.Weight(L.W_F32, _t(k, dev)))
+    np.testing.assert_array_equal(_np(y).reshape(M, N), oracle.fseq_matmul(x, k))
+    return
+  NB, H, W, Cin, Cout, KH, KW, pad = {
+      "conv3x3_c128": (5, 8, 8, 128, 128, 3, 3, ((1, 1), (1, 1))),
+      "conv3x3_c16": (3, 7, 9, 16, 40, 3, 3, ((1, 1), (1, 1))),
+      "conv5x5": (2, 6, 5, 8, 33, 5, 5, ((2, 2), (2, 2))),
+      "conv1d_k4_same": (4, 1, 20, 128, 20, 1, 4, ((0, 0), (1, 2))),
+      "conv_1x1": (3, 4, 4, 12, 130, 1, 1, ((0, 0), (0, 0))),
+  }[shape]
+  x, k = mixed((NB, H, W, Cin)), mixed((KH, KW, Cin, Cout))
+  geom = ops.ConvGeom(H, W, Cin, Cout, KH, KW, (1, 1), pad)
+  assert ops.fseq_gemm_supported(geom)
+  y = ops.conv_forward(_t(x, dev), geom, ops.Weight(L.W_F32, _t(k, dev)))
+  e = oracle.quant_conv(x, oracle.QWeight(k), None, pad, mode="fseq")
+  np.testing.assert_array_equal(_np(y), e)
+
+
 def test_conv_block_xcd_split_schedule(dev, oracle):
   """Batches of 8 or more samples take the XCD-aware patch schedule (samples
   b = xcd mod 8 per XCD); uneven B = 19 leaves XCDs with different sample counts."""
