@@ -49,6 +49,9 @@ def parse():
   ap.add_argument("--prune", type=float, default=0.9)
   ap.add_argument("--lam", type=float, default=0.1,
                   help="Poisson rate of the synthetic events; spikes are (Poisson(lam) > 0)")
+  ap.add_argument("--model", choices=("c3", "cextnet"), default="c3",
+                  help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
+                       "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   return ap.parse_args()
@@ -90,8 +93,12 @@ def main():
 
   B, T = args.batch, args.frames
   cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune)
-  model = models.ConvDenseSNN(num_classes=11, config=cfg)
-  variables_np = syn.conv_net_variables(prune_p=args.prune)
+  if args.model == "cextnet":
+    model = models.CextNet(num_classes=11, config=cfg)
+    variables_np = syn.cextnet_variables(prune_p=args.prune)
+  else:
+    model = models.ConvDenseSNN(num_classes=11, config=cfg)
+    variables_np = syn.conv_net_variables(prune_p=args.prune)
   variables = nn.tree_from_numpy(variables_np, dev)
 
   # synthetic Poisson-spike DVS frames, resident in HBM before the timed region
@@ -219,7 +226,9 @@ def main():
       "dtype": "conv0/dense: int8 codes x u8/binary -> int32 (i8 MFMA); conv1-2: fp6 codes x "
                "fp4 spikes -> f32 exact integers (f8f6f4 MFMA); f32 membrane",
       "data": "synthetic Poisson(%g)>0 spikes, N(0,1/fan_in) weights, random seeds fixed" % args.lam,
-      "config": {"workload": "C3: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->110)+LIF + vote, "
+      "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
+                              "qdense(2048->512->110) + vote, " if args.model == "cextnet" else
+                              "C3: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->110)+LIF + vote, ") +
                              "DVS128 128x128x2, T=%d, %d-bit, %.0f%% pruned" %
                              (T, args.bits, args.prune * 100),
                  "batch_per_gpu": B, "global_batch": world * B, "frames": T,
@@ -229,7 +238,7 @@ def main():
       "rooflines": [rooflines[k] for k in sorted(rooflines)],
       "kernels": kern,
   }
-  if world == 1 and not args.no_cpu_baseline:
+  if world == 1 and not args.no_cpu_baseline and args.model == "c3":
     line["cpu_baseline"] = cpu_baseline(args, variables_np)
   print(json.dumps(line))
 
