@@ -264,6 +264,24 @@ class SpikingBlock(nn.Module):
     nrn = self.neural_dynamics.neuron(conn.features)
     bn = norm.coeffs(conn.features) if norm is not None else None
 
+    # binary uint8 activations into a dense block (config C2's first layer): pack the bits
+    # once so the int8-MFMA dense kernel serves it (it reads bit-packed rows)
+    if (is_dense and integer and w.wtype == L.W_I8 and isinstance(x, torch.Tensor)
+        and x.dtype == torch.uint8 and self.impl == L.IMPL_AUTO and ops.input_max_bound(x) == 1):
+      x = ops.pack_bits(x)
+    # unquantised kernels (config C1) fed by spikes: the float32 kernel wants float32
+    # activations -- widen them when that stays small, and take the f32-MFMA route below
+    if (w.wtype == L.W_F32 and self.impl == L.IMPL_AUTO and flat is None
+        and (isinstance(x, ops.PackedSpikes) or x.dtype == torch.uint8)):
+      numel = 1
+      for d in x.shape:
+        numel *= int(d)
+      if numel <= (1 << 26):
+        x = x.to_dense() if isinstance(x, ops.PackedSpikes) else x.to(torch.float32)
+        if not tm:                     # [B, T, ...] -> time-major (small tensor)
+          x = x.transpose(0, 1).contiguous()
+          tm = True
+        integer = False
     # real-valued activations (the TCJA-gated blocks): the connection runs on the f32
     # MFMA (same fmaf chain as the direct-form kernel), then BatchNorm + neuron scan
     if (not integer and tm and self.impl == L.IMPL_AUTO and w.wtype == L.W_F32
