@@ -84,8 +84,10 @@ __device__ __forceinline__ float dequant_acc(int acc, const Dequant &d) {
 struct NeuronP {
   int kind;
   float k;       // tau (MULTI_STEP_LIF) or sigmoid(tau_param) (PLIF)
-  float inv_k;   // 1/tau when tau is a power of two (exact), else 0
-  int k_log2;    // log2(tau) when inv_k != 0
+  float inv_k;   // multiplier m of the update u += (x - (u - v_reset)) * m when the neuron
+                 // has that form: 1/tau for MULTI_STEP_LIF with tau a power of two (the
+                 // division is then exact), sigmoid(tau) for PLIF; else 0
+  int k_log2;    // log2(1 / inv_k) when that is an integer (MULTI_STEP_LIF), else -1
   float vth, vr;
   const float *decay;
 };
@@ -98,7 +100,8 @@ inline NeuronP make_neuron(const snnqp_neuron_t *n) {
   p.vr = n ? n->v_reset : 0.0f;
   p.decay = n ? n->decay : nullptr;
   p.inv_k = 0.0f;
-  p.k_log2 = 0;
+  p.k_log2 = -1;
+  if (p.kind == SNNQP_NEURON_PARAMETRIC_LEAKY_IF) p.inv_k = p.k;   // :381 multiplies
   if (p.kind == SNNQP_NEURON_MULTI_STEP_LIF) {
     int e;
     float mant = frexpf(p.k, &e);

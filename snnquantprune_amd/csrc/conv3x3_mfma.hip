@@ -626,8 +626,11 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
   a.tiles_y = g->H / 8; a.tiles_x = g->W / 8;
   a.npatch = (int64_t)B * a.tiles_y * a.tiles_x;
-  const bool fast = a.nrn.kind == SNNQP_NEURON_MULTI_STEP_LIF && a.nrn.inv_k != 0.0f &&
-                    a.nrn.vr == 0.0f;
+  // straight-line epilogue: u += (x - u) * m with hard reset to 0 (multi_step_LIF with a
+  // power-of-two tau, parametric_leaky_IF), spiking_learning.py:381, 410-414
+  const bool fast = (a.nrn.kind == SNNQP_NEURON_MULTI_STEP_LIF ||
+                     a.nrn.kind == SNNQP_NEURON_PARAMETRIC_LEAKY_IF) &&
+                    a.nrn.inv_k != 0.0f && a.nrn.vr == 0.0f;
   const bool pl = pool == 2;
   const unsigned gy = (unsigned)((g->Cout + 127) / 128);
   // |acc| <= abs_sum_max * x_max; small enough -> dequantise through an LDS table

@@ -630,6 +630,37 @@ def test_float_connection_f32_mfma(dev, oracle, shape):
   np.testing.assert_array_equal(_np(y), e)
 
 
+@pytest.mark.parametrize("cin", [128, 2])
+def test_conv_block_plif_takes_fast_epilogue(dev, oracle, cin):
+  """parametric_leaky_IF (u += (x - u) * sigmoid(tau), spiking_learning.py:381) has the
+  form of the straight-line epilogue: the fp6 / conv0 MFMA kernels serve it, bit-exact
+  with the oracle and with the direct-form kernel."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  hw = 8 if cin == 128 else 16
+  c = cases.conv_block_case(T=6, B=4, hw=hw, cin=cin, seed=1501, gain=5.0 if cin > 2 else 4.0)
+  if cin == 2:
+    c["x"] = np.minimum(c["x"], 1).astype(np.uint8)
+  tau_param = F32(-0.35)
+  k = float((1.0 / (1.0 + np.exp(-np.float64(tau_param)))).astype(F32))
+  nrn = ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, k, 1.0, 0.0)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  eu, es = oracle.conv_block(c["x"], qw, c["bn"],
+                             {"kind": "parametric_leaky_IF", "tau_param": tau_param}, "int")
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  geom = ops.ConvGeom(hw, hw, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xt = _t(c["x"], dev)
+  xin = xt if cin == 2 else ops.pack_bits(xt)
+  for impl in (L.IMPL_MFMA, L.IMPL_GENERIC):
+    u, s = ops.conv_lif_forward(xin, geom, w, nrn, bn=_bn(c["bn"], dev), packed_out=True,
+                                impl=impl, x_max=1)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="impl %d" % impl)
+    np.testing.assert_array_equal(_np(u), eu)
+  _, sp = ops.conv_lif_forward(xin, geom, w, nrn, bn=_bn(c["bn"], dev), packed_out=True, pool=2,
+                               impl=L.IMPL_MFMA, want_u=False, x_max=1)
+  np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
+
+
 def test_conv_block_xcd_split_schedule(dev, oracle):
   """Batches of 8 or more samples take the XCD-aware patch schedule (samples
   b = xcd mod 8 per XCD); uneven B = 19 leaves XCDs with different sample counts."""
