@@ -52,6 +52,7 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
   SNNQP_REQUIRE(impl >= SNNQP_IMPL_AUTO && impl <= SNNQP_IMPL_MFMA, SNNQP_EINVAL,
                 "dense_lif_forward: unknown impl %d", impl);
   const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
+  if (!why && T > 160) why = "more than 160 timesteps (one sample must fit a row tile)";
   if (impl == SNNQP_IMPL_MFMA)
     SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "dense_lif_forward: MFMA kernel: %s", why);
   if (!why && impl != SNNQP_IMPL_GENERIC)

@@ -326,6 +326,24 @@ def test_dense_block_mfma(dev, oracle, shape):
     np.testing.assert_array_equal(_np(ua), _np(ub))
 
 
+def test_dense_block_long_T_falls_back(dev, oracle):
+  """More timesteps than the MFMA dense kernel's row tile holds (T > 160): the block
+  runs on the direct-form kernel instead of failing."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(77))
+  T, B, K, N = 170, 2, 64, 32
+  leaf = {"kernel": (rng.standard_normal((K, N)) * 0.6).astype(F32),
+          "DuQ_0": {"a": F32([1.0]), "c": F32([0.9])},
+          "prune_0": {"mask": (rng.random((K, N)) > 0.5).astype(F32)}}
+  x = (rng.random((T, B, K)) < 0.2).astype(np.uint8)
+  w = _weight(leaf, 4, dev, transposed=True)
+  u, s = ops.dense_lif_forward(ops.pack_bits(_t(x, dev)), w, K, N, _mslif(), packed_out=True)
+  eu, es = oracle.dense_block(x, qweight_of(oracle, leaf, 4), None, "int")
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+
+
 def test_dense_block_fseq_path(dev, oracle, golden_dir):
   """Unquantised float32 weights, real-valued input: k-ascending fmaf chain,
   bit-exact vs the oracle's fseq mode and within 1e-5 relative of float64."""
