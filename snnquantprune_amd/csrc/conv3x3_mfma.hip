@@ -421,6 +421,11 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     *(uint32_t *)(lds + tid * HIMG2 + HCONST2 + 4) = 0x00000001u;
   }
 
+  // without a table the input is taken as x - 128 (a signed int8 for every count up to
+  // 255; padding pixels are x = 0 like any other) and 128 * sum_k w[k] is added back to
+  // the accumulator in the epilogue (an integer below 2^24: exact in float32)
+  constexpr bool OFFS = LUTM == LUT_NONE;
+  float acc_off = 0.0f;
   v4i bf;
   {
     // byte address of this lane's table entry of acc = 0, as 127 * q + r over the
@@ -432,6 +437,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
              4 * ((wave * lut_channel_rows(a.lut_bound) + a.lut_bound) * 32 + n);
     int q = bias / 127;
     const int r = bias - 127 * q;
+    int wsum = 0;
     int v[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -444,6 +450,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
           const int dy = k >> 3, b = k & 7;
           if (b < 6 && wave_on) {    // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
             const int code = a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
+            wsum += code;
             bv = (uint8_t)(LUTM == LUT_CHANNEL ? code * 8 : code);   // see build_lut_channel
           }
         } else if (k < 28) {
@@ -458,6 +465,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       v[d] = (int)pk;
     }
     bf = v4i{v[0], v[1], v[2], v[3]};
+    // the two lane halves hold k 0..15 and 16..23 of the same channel
+    if (OFFS) acc_off = 128.0f * (float)(wsum + __shfl_xor(wsum, 32));
   }
 
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f};
@@ -513,7 +522,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
           const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
           if (tt < nt) {    // table modes: both bytes scale without a carry (counts <= 31 / 7)
             const uint16_t val = LUTM == LUT_CHANNEL  ? (uint16_t)(v[k] << 4)
-                                 : LUTM == LUT_SHARED ? (uint16_t)(v[k] << 2) : v[k];
+                                 : LUTM == LUT_SHARED ? (uint16_t)(v[k] << 2)
+                                                      : (uint16_t)(v[k] ^ 0x8080u);   // x - 128
             uint8_t *p = lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2;
             *(uint16_t *)p = val;
             *(uint16_t *)(p + HCOPY2 + 2) = val;
@@ -543,7 +553,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bf, acc,
                                                         0, 0, 0);
 #endif
-            words[tl] = tile_epilogue<FAST, POOL, LUTM, FMA>(acc, u[tl], a.dq, lc, a.nrn, lane);
+            words[tl] = tile_epilogue<FAST, POOL, LUTM, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
+                                                                   lane, acc_off);
           }
           if (store_lane) {
             uint32_t *o = obuf + ((t0 + tt) % FL) * (OutStage<POOL>::NPIX * 4);
@@ -592,7 +603,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
   if (in_type == SNNQP_BITS) {
     if (g->Cin != 128) return "bit input needs Cin == 128";
-  } else if (in_type == SNNQP_U8) {
+  } else if (in_type == SNNQP_U8) {     // any count 0..255 (taken as x - 128 without a table)
     if (g->Cin != 2) return "u8 input needs Cin == 2";
   } else {
     return "input must be BITS or U8";

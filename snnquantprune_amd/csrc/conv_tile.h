@@ -217,10 +217,14 @@ __device__ __forceinline__ bool lif_fma_is_exact(uint32_t min_x_bits, int j, int
 // Dequantised currents of two accumulator registers (two pixels, same channel).
 // Table modes: the register is the LDS address of its entry.  Otherwise packed
 // float32 ops (v_pk_*_f32 keep every rounding of the scalar sequence).
-template <int LUTM>
-__device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq) {
+// `off` (an integer < 2^24 as float, exact): constant added to the accumulator first --
+// the u8 kernel accumulates (x - 128) * w so that counts up to 255 are int8 operands,
+// and adds 128 * sum(w) back here.
+template <int LUTM, bool OFFS = false>
+__device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq, float off = 0.0f) {
   if (LUTM != LUT_NONE) return v2f{lds_read_f32((uint32_t)a0), lds_read_f32((uint32_t)a1)};
-  const v2f a = {(float)a0, (float)a1};
+  v2f a = {(float)a0, (float)a1};
+  if (OFFS) a = a + off;
   v2f q = a * dq.rL;
   const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
   q = __builtin_elementwise_fma(e, v2f{dq.rL, dq.rL}, q);
@@ -302,14 +306,15 @@ __device__ __forceinline__ uint32_t tile_neurons(const v2f (&y)[8], float (&u)[1
 
 // Whole-tile epilogue (used where no MFMA stream runs beside it): all table
 // reads are issued first, then the pairs are processed.
-template <bool FAST, bool POOL, int LUTM, bool FMA = false>
+template <bool FAST, bool POOL, int LUTM, bool FMA = false, bool OFFS = false>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
-                                                  const NeuronP &nrn, int lane) {
+                                                  const NeuronP &nrn, int lane,
+                                                  float off = 0.0f) {
   v2f y[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM>(acc[2 * j], acc[2 * j + 1], dq);
+  for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM, OFFS>(acc[2 * j], acc[2 * j + 1], dq, off);
   return tile_neurons<FAST, POOL, LUTM == LUT_CHANNEL, FMA>(y, u, lc, nrn);
 }
 

@@ -322,8 +322,8 @@ class SpikingBlock(nn.Module):
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
     x_max = ops.input_max_bound(x) if integer else 0
     impl = self.impl
-    if x_max > 127 and impl == L.IMPL_AUTO:
-      impl = L.IMPL_GENERIC            # counts above 127 are not int8 MFMA operands
+    if x_max > 127 and impl == L.IMPL_AUTO and cin != 2:
+      impl = L.IMPL_GENERIC            # only the 2-channel event kernel takes counts > 127
     T, B = (x.shape[0], x.shape[1]) if tm else (x.shape[1], x.shape[0])
     if nsp == 1 and not tm:
       raise NotImplementedError("batch-major input for 1-D convolution blocks")

@@ -525,7 +525,7 @@ def test_conv_block_pipeline_tails(dev, oracle, T):
 @pytest.mark.parametrize("mode", ["channel", "channel_nobn", "shared_counts", "shared_8bit",
                                   "none_xmax", "c128_none", "channel_cout160",
                                   "c128_i8_5bit", "c128_i8_8bit", "c128_fp6_cout160",
-                                  "channel_tiny_currents", "channel_T40"])
+                                  "channel_tiny_currents", "channel_T40", "none_u8_255"])
 def test_conv_block_table_modes(dev, oracle, mode):
   """The MFMA kernels dequantise through LDS tables when the accumulator bound
   allows (per-channel tables with BatchNorm folded in, one shared table, or plain
@@ -560,6 +560,8 @@ def test_conv_block_table_modes(dev, oracle, mode):
       x = (x * 5).astype(np.uint8)                        # counts up to ~20
     elif mode == "none_xmax":
       x = (x * 30).astype(np.uint8)                       # counts > 31: no table
+    elif mode == "none_u8_255":
+      x = np.minimum(x.astype(np.int32) * 85, 255).astype(np.uint8)   # counts up to 255
     c["x"] = x
   e = cases.conv_block_expected(oracle, c)
   w = _weight(c["leaf"], c["bits"], dev, transposed=True)
@@ -574,6 +576,8 @@ def test_conv_block_table_modes(dev, oracle, mode):
     assert 40 < bound <= 2047 and x_max <= 31, (bound, x_max)
   elif mode == "none_xmax":
     assert 31 < x_max <= 127
+  elif mode == "none_u8_255":
+    assert x_max == 255
   if mode == "c128_none":
     x_max = 0                                             # no bound given: arithmetic dequant
   bn = _bn(c["bn"], dev) if mode != "channel_nobn" else None
