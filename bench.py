@@ -108,6 +108,7 @@ def main():
   x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
 
   def step():
+    ops.forget_inputs()       # a new batch: its inspection pass (max count) is timed too
     (logits, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
     return parallel.all_gather_rows(logits)
 

@@ -19,16 +19,51 @@ inspect_f32_kernel(const float *__restrict__ x, int64_t n,
   if (f) atomicOr(flags, f);
 }
 
+// Maximum of a u8 tensor: 16 bytes per lane and step; the bytes of a word are reduced
+// as two packed u16 pairs (v_pk_max_u16), so the pass stays HBM-bound.
 __global__ void __launch_bounds__(256)
 inspect_u8_kernel(const uint8_t *__restrict__ x, int64_t n, int32_t *__restrict__ flags) {
-  int32_t m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
-    m = max(m, (int32_t)x[i]);
+  typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  v2u16 m0 = {0, 0}, m1 = {0, 0};
+  // aligned body
+  const uintptr_t addr = (uintptr_t)x;
+  const int64_t head = (int64_t)(((addr + 15) & ~(uintptr_t)15) - addr) < n
+                           ? (int64_t)(((addr + 15) & ~(uintptr_t)15) - addr) : n;
+  const int64_t nvec = (n - head) / 16;
+  const v4u *xv = (const v4u *)(x + head);
+  auto fold = [&](const v4u &w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = w[j] & 0x00FF00FFu, hi = (w[j] >> 8) & 0x00FF00FFu;
+      m0 = __builtin_elementwise_max(m0, __builtin_bit_cast(v2u16, lo));
+      m1 = __builtin_elementwise_max(m1, __builtin_bit_cast(v2u16, hi));
+    }
+  };
+  int64_t i = tid;
+  for (; i + 3 * nthreads < nvec; i += 4 * nthreads) {      // four loads in flight
+    const v4u w0 = xv[i], w1 = xv[i + nthreads], w2 = xv[i + 2 * nthreads],
+              w3 = xv[i + 3 * nthreads];
+    fold(w0); fold(w1); fold(w2); fold(w3);
+  }
+  for (; i < nvec; i += nthreads) fold(xv[i]);
+  int32_t m = max(max((int)m0.x, (int)m0.y), max((int)m1.x, (int)m1.y));
+  // unaligned head and tail bytes
+  for (int64_t k = tid; k < head; k += nthreads) m = max(m, (int32_t)x[k]);
+  for (int64_t k = head + nvec * 16 + tid; k < n; k += nthreads) m = max(m, (int32_t)x[k]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  // word = (max << 8) | flags(max) grows with max, so one atomicMax keeps both
-  int32_t f = (m > 1 ? SNNQP_FLAG_GT_ONE : 0) | (m > 127 ? SNNQP_FLAG_GT_127 : 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(flags, (m << 8) | f);
+  // one atomic per workgroup (they serialise on the single word)
+  __shared__ int32_t wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    // word = (max << 8) | flags(max) grows with max, so one atomicMax keeps both
+    const int32_t f = (m > 1 ? SNNQP_FLAG_GT_ONE : 0) | (m > 127 ? SNNQP_FLAG_GT_127 : 0);
+    if (m) atomicMax(flags, (m << 8) | f);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -273,7 +308,8 @@ int snnqp_inspect_u8(const uint8_t *x, int64_t n, int32_t *flags,
   SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "inspect_u8: negative size");
   if (n == 0) return SNNQP_OK;
   SNNQP_REQUIRE(x && flags, SNNQP_EINVAL, "inspect_u8: null argument");
-  hipLaunchKernelGGL(inspect_u8_kernel, dim3(grid_for(n)), dim3(256), 0,
+  hipLaunchKernelGGL(inspect_u8_kernel, dim3(grid_for(n / 64 + 1) < 2048 ? grid_for(n / 64 + 1) : 2048),
+                     dim3(256), 0,
                      (hipStream_t)stream, x, n, flags);
   SNNQP_CHECK_LAUNCH("inspect_u8_kernel");
   return SNNQP_OK;

@@ -249,6 +249,14 @@ def inspect_f32(x: torch.Tensor) -> int:
 _u8_flag_cache = None
 
 
+def forget_inputs():
+  """Drops the cached facts about activation tensors (their maxima), as if every
+  tensor were new: bench.py calls it each step so that the per-batch inspection
+  pass of a fresh input is inside the timed region."""
+  global _u8_flag_cache
+  _u8_flag_cache = None
+
+
 def input_max_bound(x) -> int:
   """Upper bound of an integer-typed activation: 1 for spikes; for uint8 tensors
   the maximum (at least 1) from one device pass (cached per tensor version)."""
