@@ -1,9 +1,13 @@
 // Fused SpikingBlock for the 3x3 / stride 1 / pad 1 QuantConv layers of the
 // DVS128 topology (examples/tcja/models.py:111-147): implicit-GEMM int8 MFMA
 // (v_mfma_i32_32x32x32_i8) + dequantisation + eval BatchNorm + neuron update +
-// optional 2x2 max-pool, with the T loop inside the kernel.
+// optional 2x2 max-pool, with the T loop inside the kernel.  Two kernels:
+//   conv3x3_bits_kernel  bit-packed input, Cin = 128, any int8 codes and neuron kind
+//                        (codes of magnitude <= 7 with the fast neuron form go to
+//                        conv3x3_fp6.hip instead)
+//   conv3x3_u8c2_kernel  uint8 event counts, Cin = 2 (the first layer)
 //
-// Mapping (one 256-thread workgroup = 4 waves, persistent over patches):
+// Mapping of the bits kernel (one 256-thread workgroup = 4 waves, persistent over patches):
 //  * a patch is 8x8 output pixels of one sample = two 32-row MFMA tiles (4x8
 //    pixels each); wave w owns output channels [32w, 32w+32) of a 128-channel
 //    block (blockIdx.y);
@@ -11,8 +15,8 @@
 //    registers for the whole launch (the B operand; 144 registers at Cin = 128),
 //    loaded once from the MFMA-tiled codes (snnqp_pack_codes_mfma);
 //  * per timestep the 10x10 halo of input spikes is expanded from bits to
-//    {0,1} bytes into LDS once (XOR-swizzled 16-byte chunks) and every tap's A
-//    fragment is one ds_read_b128 at a shifted pixel, fetched one tap ahead of
+//    {0,1} bytes into LDS once (one plane per k-step, conv_tile.h) and every tap's A
+//    fragment is one ds_read_b128 at an immediate offset, fetched one tap ahead of
 //    the MFMAs that consume it;
 //  * C/D layout: lane = output channel, register = pixel, so the per-channel
 //    dequant/BatchNorm constants are per-lane registers, the membrane potential
@@ -20,8 +24,8 @@
 //    register *is* the packed spike word of two pixels (64-bit lane mask);
 //    pooling is an OR of those scalar masks;
 //  * the loop is software-pipelined over t: the MFMAs of step t+1 and the
-//    dequant/BN/neuron epilogue of step t are independent instruction streams
-//    in one basic block, so the matrix pipe and the VALU overlap inside a wave.
+//    dequant/BN/neuron epilogue of step t alternate in one basic block, so the
+//    matrix pipe and the VALU overlap inside the single wave each SIMD holds.
 #include <type_traits>
 
 #include "conv_tile.h"
