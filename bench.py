@@ -52,6 +52,10 @@ def parse():
   ap.add_argument("--model", choices=("c3", "cextnet"), default="c3",
                   help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
                        "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
+  ap.add_argument("--input", choices=("u8", "f32"), default="u8",
+                  help="resident input dtype: uint8 event frames (default) or the float32 "
+                       "frames the reference's pipeline hands over (inspected and narrowed "
+                       "on device inside the step)")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   return ap.parse_args()
@@ -106,6 +110,8 @@ def main():
   gen.manual_seed(8627169 + rank)
   p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
   x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
+  if args.input == "f32":
+    x = x.to(torch.float32)
 
   def step():
     ops.forget_inputs()       # a new batch: its inspection pass (max count) is timed too

@@ -154,6 +154,11 @@ int snnqp_inspect_u8(const uint8_t *x, int64_t n, int32_t *flags,
                      snnqp_stream_t stream);
 int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
                     snnqp_stream_t stream);
+/* narrow_f32: inspect_f32 + f32_to_u8 + inspect_u8 in one pass over x.  flags[0]
+ * (zeroed by the caller) = (max << 8) | SNNQP_FLAG_GT_*, flags[1] = SNNQP_FLAG_NOT_INTEGER
+ * or 0; y is the uint8 copy, meaningful when flags[1] == 0. */
+int snnqp_narrow_f32(const float *x, uint8_t *y, int64_t n, int32_t *flags,
+                     snnqp_stream_t stream);
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
                     uint32_t *bits, snnqp_stream_t stream);
 int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,

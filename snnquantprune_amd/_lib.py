@@ -59,6 +59,7 @@ _PROTOTYPES = {
     "snnqp_inspect_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_inspect_u8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_f32_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "snnqp_narrow_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_pack_bits": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p,
                                 c_void_p]),
     "snnqp_unpack_bits": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -66,6 +66,45 @@ inspect_u8_kernel(const uint8_t *__restrict__ x, int64_t n, int32_t *__restrict_
   }
 }
 
+// One pass over a float32 activation tensor: the uint8 copy (meaningful when no
+// element is flagged NOT_INTEGER) and the word (max << 8) | flags of inspect_f32 /
+// inspect_u8 at once -- a float32 frame batch is read once instead of three times.
+__global__ void __launch_bounds__(256)
+narrow_f32_kernel(const float *__restrict__ x, uint8_t *__restrict__ y, int64_t n,
+                  int32_t *__restrict__ flags) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 3) == 0);
+  const int64_t nvec = vec ? n / 4 : 0;
+  int32_t m = 0, bad = 0;
+  auto one = [&](float v) -> uint32_t {
+    if (!(v >= 0.0f && v <= 255.0f) || v != rintf(v)) bad = 1;
+    const int iv = (int)v;
+    m = max(m, iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+    return (uint32_t)(uint8_t)v;
+  };
+  for (int64_t i = tid; i < nvec; i += nthreads) {
+    const v4f w = ((const v4f *)x)[i];
+    ((uint32_t *)y)[i] = one(w.x) | (one(w.y) << 8) | (one(w.z) << 16) | (one(w.w) << 24);
+  }
+  for (int64_t i = nvec * 4 + tid; i < n; i += nthreads) y[i] = (uint8_t)one(x[i]);
+  for (int o = 32; o > 0; o >>= 1) {
+    m = max(m, __shfl_xor(m, o));
+    bad |= __shfl_xor(bad, o);
+  }
+  __shared__ int32_t wm[4], wb[4];
+  if ((threadIdx.x & 63) == 0) { wm[threadIdx.x >> 6] = m; wb[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    bad = wb[0] | wb[1] | wb[2] | wb[3];
+    const int32_t f = (m > 1 ? SNNQP_FLAG_GT_ONE : 0) | (m > 127 ? SNNQP_FLAG_GT_127 : 0);
+    if (m) atomicMax(flags, (m << 8) | f);      // grows with max: one word keeps both
+    if (bad) atomicOr(flags + 1, SNNQP_FLAG_NOT_INTEGER);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 f32_to_u8_kernel(const float *__restrict__ x, uint8_t *__restrict__ y,
                  int64_t n) {
@@ -312,6 +351,19 @@ int snnqp_inspect_u8(const uint8_t *x, int64_t n, int32_t *flags,
                      dim3(256), 0,
                      (hipStream_t)stream, x, n, flags);
   SNNQP_CHECK_LAUNCH("inspect_u8_kernel");
+  return SNNQP_OK;
+}
+
+int snnqp_narrow_f32(const float *x, uint8_t *y, int64_t n, int32_t *flags,
+                     snnqp_stream_t stream) {
+  SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "narrow_f32: negative size");
+  if (n == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && y && flags, SNNQP_EINVAL, "narrow_f32: null argument");
+  const int64_t work = n / 4 + 1;
+  const int grid = grid_for(work) < 4096 ? grid_for(work) : 4096;
+  hipLaunchKernelGGL(narrow_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, n,
+                     flags);
+  SNNQP_CHECK_LAUNCH("narrow_f32_kernel");
   return SNNQP_OK;
 }
 

@@ -288,6 +288,26 @@ def f32_to_u8(x: torch.Tensor) -> torch.Tensor:
   return y
 
 
+def narrow_f32(x: torch.Tensor):
+  """float32 activations -> (uint8 copy | None, max value): one device pass that
+  inspects and narrows; None when some element is not an integer in [0, 255]."""
+  global _u8_flag_cache
+  x = _f32c(x)
+  _require_gpu(x)
+  y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+  flags = torch.zeros(2, dtype=torch.int32, device=x.device)
+  L.check(L.lib().snnqp_narrow_f32(_ptr(x), _ptr(y), x.numel(), _ptr(flags), _stream()))
+  f0, f1 = flags.tolist()
+  if f1 & L.FLAG_NOT_INTEGER:
+    return None, 0
+  vmax = max(1, f0 >> 8)
+  if _u8_flag_cache is None:
+    from ._cache import TensorCache
+    _u8_flag_cache = TensorCache(16)
+  _u8_flag_cache.put((y,), None, vmax)         # input_max_bound(y) needs no second pass
+  return y, vmax
+
+
 def pack_bits(x: torch.Tensor) -> PackedSpikes:
   """float32 / uint8 [..., C] (nonzero = spike) -> PackedSpikes."""
   _require_gpu(x)

@@ -140,12 +140,14 @@ def prepare_input(x, prefer_bits: Optional[bool] = None):
     x = x.to(torch.float32)
   if not AUTO_INTEGER_INPUTS or x.numel() == 0:
     return x, False
+  if prefer_bits is None:
+    prefer_bits = x.shape[-1] >= 32
+  if not prefer_bits:            # e.g. the 2-channel event frames: one pass narrows + inspects
+    y, _ = ops.narrow_f32(x)
+    return (x, False) if y is None else (y, True)
   flags = ops.inspect_f32(x)
   if flags & L.FLAG_NOT_INTEGER:
     return x, False
-  binary = not (flags & L.FLAG_GT_ONE)
-  if prefer_bits is None:
-    prefer_bits = x.shape[-1] >= 32
-  if binary and prefer_bits:
+  if not (flags & L.FLAG_GT_ONE):
     return ops.pack_bits(x), True
   return ops.f32_to_u8(x), True

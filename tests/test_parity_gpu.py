@@ -173,6 +173,16 @@ def test_inspect_and_u8(dev):
   assert ops.inspect_f32(torch.tensor([-1.0], device=dev)) & L.FLAG_NOT_INTEGER
   assert ops.inspect_f32(torch.tensor([200.0], device=dev)) & L.FLAG_GT_127
   np.testing.assert_array_equal(_np(ops.f32_to_u8(x)), [0, 1, 3, 127])
+  # one pass: narrow float32 -> uint8 with the maximum, or refuse non-integer data
+  xf = torch.zeros(100007, dtype=torch.float32, device=dev)
+  xf[3], xf[99990], xf[100006] = 7.0, 201.0, 3.0
+  y, vmax = ops.narrow_f32(xf)
+  assert vmax == 201 and y.dtype == torch.uint8 and ops.input_max_bound(y) == 201
+  np.testing.assert_array_equal(_np(y), _np(xf).astype(np.uint8))
+  for bad in (0.5, -1.0, 256.0, float("nan")):
+    xb = xf.clone()
+    xb[5] = bad
+    assert ops.narrow_f32(xb)[0] is None
   for vmax in (0, 1, 2, 19, 127, 128, 255):            # exact maximum of a u8 tensor
     xu = torch.zeros(100003, dtype=torch.uint8, device=dev)
     xu[70001] = vmax
