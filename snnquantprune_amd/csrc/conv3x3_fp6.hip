@@ -88,7 +88,7 @@ extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
 #define F6_MARK(i)
 #endif
 
-template <bool POOL, bool LUT>
+template <int NF, bool POOL, bool LUT>
 __global__ void __launch_bounds__(512, 1)
 conv3x3_fp6_kernel(ConvMfmaArgs a) {
   constexpr int FL = POOL ? 16 : 4;              // timesteps per flush block
@@ -136,8 +136,9 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     }
   }
 
-  LaneConsts lc = {0.f, 1.f, 0.f, 0.f};
+  LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
   if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
+  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cout];
 
   // table mode: spikes count 4 (block scale 2^2 on A) and the chain starts from the
   // address of the entry of acc = 0, so the f32 accumulator is the table address
@@ -275,16 +276,13 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
           x = y[j % (YD + 1)] - lc.bmean;
           x = x * lc.bmul;
           x = x + lc.bbias;
-        } else if (q == 2) {       // multi_step_LIF, tau = 2^k, v_reset = 0 (:410-414)
-          uu = v2f{u[2 * j], u[2 * j + 1]};
-          const v2f d = x - uu;
-          const v2f dk = d * a.nrn.inv_k;
-          uu = uu + dk;
+        } else if (q == 2) {       // membrane update of the neuron form (conv_tile.h)
+          uu = neuron_update<NF>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
           m0 = __ballot(uu.x >= a.nrn.vth);
           m1 = __ballot(uu.y >= a.nrn.vth);
         } else {
-          u[2 * j] = reset_where(uu.x, m0);
-          u[2 * j + 1] = reset_where(uu.y, m1);
+          u[2 * j] = neuron_reset<NF>(uu.x, m0, lc);
+          u[2 * j + 1] = neuron_reset<NF>(uu.y, m1, lc);
           const int i = 2 * j;
           if (POOL) {
             const unsigned long long o = m0 | m1;
@@ -323,7 +321,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       v2f y[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = dequant2(acc[2 * j], acc[2 * j + 1]);
-      const uint32_t w = tile_neurons<true, POOL, false>(y, u, lc, a.nrn);
+      const uint32_t w = tile_neurons<NF, POOL, false>(y, u, lc, a.nrn);
       if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w;
     };
     // staging of halo(t2) into its buffer around a step: the table reads go first, the
@@ -390,12 +388,21 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   }
 }
 
-void launch_conv3x3_fp6(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
+template <int NF>
+static void launch_fp6_nf(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
+                          hipStream_t st) {
+  if (pool && lut) launch_persistent(conv3x3_fp6_kernel<NF, true, true>, a, gy, st, 0, 512);
+  else if (pool) launch_persistent(conv3x3_fp6_kernel<NF, true, false>, a, gy, st, 0, 512);
+  else if (lut) launch_persistent(conv3x3_fp6_kernel<NF, false, true>, a, gy, st, 0, 512);
+  else launch_persistent(conv3x3_fp6_kernel<NF, false, false>, a, gy, st, 0, 512);
+}
+
+void launch_conv3x3_fp6(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
                         hipStream_t st) {
-  if (pool && lut) launch_persistent(conv3x3_fp6_kernel<true, true>, a, gy, st, 0, 512);
-  else if (pool) launch_persistent(conv3x3_fp6_kernel<true, false>, a, gy, st, 0, 512);
-  else if (lut) launch_persistent(conv3x3_fp6_kernel<false, true>, a, gy, st, 0, 512);
-  else launch_persistent(conv3x3_fp6_kernel<false, false>, a, gy, st, 0, 512);
+  if (nf == NF_MUL0) launch_fp6_nf<NF_MUL0>(a, pool, lut, gy, st);
+  else if (nf == NF_MUL) launch_fp6_nf<NF_MUL>(a, pool, lut, gy, st);
+  else if (nf == NF_DIV) launch_fp6_nf<NF_DIV>(a, pool, lut, gy, st);
+  else launch_fp6_nf<NF_DECAY>(a, pool, lut, gy, st);
 }
 
 }  // namespace snnqp

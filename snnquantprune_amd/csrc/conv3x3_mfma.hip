@@ -3,8 +3,7 @@
 // (v_mfma_i32_32x32x32_i8) + dequantisation + eval BatchNorm + neuron update +
 // optional 2x2 max-pool, with the T loop inside the kernel.  Two kernels:
 //   conv3x3_bits_kernel  bit-packed input, Cin = 128, any int8 codes and neuron kind
-//                        (codes of magnitude <= 7 with the fast neuron form go to
-//                        conv3x3_fp6.hip instead)
+//                        (codes of magnitude <= 7 go to conv3x3_fp6.hip instead)
 //   conv3x3_u8c2_kernel  uint8 event counts, Cin = 2 (the first layer)
 //
 // Mapping of the bits kernel (one 256-thread workgroup = 4 waves, persistent over patches):
@@ -77,7 +76,7 @@ extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
 // ---------------------------------------------------------------------------
 // Bit-packed input, Cin = 128.
 // ---------------------------------------------------------------------------
-template <bool FAST, bool POOL, int LUTM>
+template <int NF, bool POOL, int LUTM>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(LUTM != LUT_CHANNEL, "per-channel tables of K = 1152 do not fit LDS");
@@ -113,7 +112,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         bf[tap][kk] = wave_on ? wtile[(tap * KK + kk) * 64] : v4i{0, 0, 0, 0};
   }
 
-  LaneConsts lc = {0.f, 1.f, 0.f, 0.f};
+  LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
   if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
   if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cout];
 
@@ -212,17 +211,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     //   piece 4 (pair j)  : reset + spike word select
     auto fused_step = [&](const uint8_t *base, v16i &accN0, v16i &accN1,
                           const v16i &accC0, const v16i &accC1, int t) {
-      if (!FAST) {     // general neuron kinds: branchy update, keep the two phases apart
-        mfma_step(base, accN0, accN1);
-        const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(accC0, u[0], a.dq, lc, a.nrn, lane);
-        const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(accC1, u[1], a.dq, lc, a.nrn, lane);
-        if (store_lane) {
-          uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
-          o[ob0] = w0;
-          o[ob1] = w1;
-        }
-        return;
-      }
       v4i A[2][2 * KK];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
@@ -261,22 +249,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
             x = x * lc.bmul;
             x = x + lc.bbias;
           } else if (piece == 2) {
-            if (FAST) {
-              uu = v2f{up[0], up[1]};
-              const v2f d = x - uu;
-              const v2f dk = d * a.nrn.inv_k;
-              uu = uu + dk;
-              m0 = __ballot(uu.x >= a.nrn.vth);
-              m1 = __ballot(uu.y >= a.nrn.vth);
-            } else {
-              m0 = __ballot(neuron_step(up[0], x.x, a.nrn, lc.dec));
-              m1 = __ballot(neuron_step(up[1], x.y, a.nrn, lc.dec));
-            }
+            uu = neuron_update<NF>(x, v2f{up[0], up[1]}, lc, a.nrn);
+            m0 = __ballot(uu.x >= a.nrn.vth);
+            m1 = __ballot(uu.y >= a.nrn.vth);
           } else {
-            if (FAST) {
-              up[0] = reset_where(uu.x, m0);
-              up[1] = reset_where(uu.y, m1);
-            }
+            up[0] = neuron_reset<NF>(uu.x, m0, lc);
+            up[1] = neuron_reset<NF>(uu.y, m1, lc);
             uint32_t &w = (j < 8) ? w0 : w1;
             const int i = (j & 7) * 2;
             if (POOL) {
@@ -301,8 +279,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       }
     };
     auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
-      const uint32_t w0 = tile_epilogue<FAST, POOL, LUTM>(acc0, u[0], a.dq, lc, a.nrn, lane);
-      const uint32_t w1 = tile_epilogue<FAST, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane);
+      const uint32_t w0 = tile_epilogue<NF, POOL, LUTM>(acc0, u[0], a.dq, lc, a.nrn, lane);
+      const uint32_t w1 = tile_epilogue<NF, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane);
       if (store_lane) {
         uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
         o[ob0] = w0;
@@ -392,7 +370,7 @@ __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
   return (b + 15) & ~15;
 }
 
-template <bool FAST, bool POOL, int LUTM>
+template <int NF, bool POOL, int LUTM>
 __global__ void __launch_bounds__(256, SNNQP_U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
@@ -473,7 +451,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     if (OFFS) acc_off = 128.0f * (float)(wsum + __shfl_xor(wsum, 32));
   }
 
-  LaneConsts lc = {0.f, 1.f, 0.f, 0.f};
+  LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
   if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
   if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cout];
 
@@ -557,7 +535,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bf, acc,
                                                         0, 0, 0);
 #endif
-            words[tl] = tile_epilogue<FAST, POOL, LUTM, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
+            words[tl] = tile_epilogue<NF, POOL, LUTM, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
                                                                    lane, acc_off);
           }
           if (store_lane) {
@@ -574,9 +552,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       }
       };
       bool fma_ok = false;
-      if (FAST && LUTM == LUT_CHANNEL)
+      if (NF == NF_MUL0 && LUTM == LUT_CHANNEL)
         fma_ok = lif_fma_is_exact(*wgmin, a.nrn.k_log2, a.T, a.u0 != nullptr);
-      if (FAST && LUTM == LUT_CHANNEL && fma_ok) run_chunk(std::true_type{});
+      if (NF == NF_MUL0 && LUTM == LUT_CHANNEL && fma_ok) run_chunk(std::true_type{});
       else run_chunk(std::false_type{});
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
@@ -641,18 +619,14 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
   a.tiles_y = g->H / 8; a.tiles_x = g->W / 8;
   a.npatch = (int64_t)B * a.tiles_y * a.tiles_x;
-  // straight-line epilogue: u += (x - u) * m with hard reset to 0 (multi_step_LIF with a
-  // power-of-two tau, parametric_leaky_IF), spiking_learning.py:381, 410-414
-  const bool fast = (a.nrn.kind == SNNQP_NEURON_MULTI_STEP_LIF ||
-                     a.nrn.kind == SNNQP_NEURON_PARAMETRIC_LEAKY_IF) &&
-                    a.nrn.inv_k != 0.0f && a.nrn.vr == 0.0f;
+  const int nf = neuron_form(a.nrn);          // which straight-line epilogue (conv_tile.h)
   const bool pl = pool == 2;
   const unsigned gy = (unsigned)((g->Cout + 127) / 128);
   // |acc| <= abs_sum_max * x_max; small enough -> dequantise through an LDS table
   // (the A operand then carries 4 * x, which must stay an int8)
   const int64_t xm = in_type == SNNQP_BITS ? 1 : x_max;
   const int64_t bound = (int64_t)w->abs_sum_max * xm;
-  const bool lut = fast && w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
+  const bool lut = w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
   a.lut_bound = lut ? (int32_t)bound : 0;
   a.tchunk = T >= TCHUNK ? TCHUNK : (T + 7) & ~7;
   const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 +
@@ -662,15 +636,20 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP && xm <= 7 &&
                     w->code_max > 0 && w->code_max <= 15 &&
                     lds_fixed + u8c2_table_bytes(LUT_CHANNEL, (int)bound) <= 65536;
+#define SNNQP_CONV_LAUNCH_NF(KERN, NFV, LM, LDS)                                   \
+  do {                                                                             \
+    if (pl) launch_persistent(KERN<NFV, true, LM>, a, gy, st, LDS);                 \
+    else launch_persistent(KERN<NFV, false, LM>, a, gy, st, LDS);                   \
+  } while (0)
 #define SNNQP_CONV_LAUNCH(KERN, LM, LDS)                                           \
   do {                                                                             \
-    if (fast && pl) launch_persistent(KERN<true, true, LM>, a, gy, st, LDS);        \
-    else if (fast) launch_persistent(KERN<true, false, LM>, a, gy, st, LDS);        \
-    else if (pl) launch_persistent(KERN<false, true, LUT_NONE>, a, gy, st, LDS);    \
-    else launch_persistent(KERN<false, false, LUT_NONE>, a, gy, st, LDS);           \
+    if (nf == NF_MUL0) SNNQP_CONV_LAUNCH_NF(KERN, NF_MUL0, LM, LDS);                \
+    else if (nf == NF_MUL) SNNQP_CONV_LAUNCH_NF(KERN, NF_MUL, LM, LDS);             \
+    else if (nf == NF_DIV) SNNQP_CONV_LAUNCH_NF(KERN, NF_DIV, LM, LDS);             \
+    else SNNQP_CONV_LAUNCH_NF(KERN, NF_DECAY, LM, LDS);                             \
   } while (0)
-  if (in_type == SNNQP_BITS && fast && w->code_max > 0 && w->code_max <= 7) {
-    launch_conv3x3_fp6(a, pl, lut, gy, st);      // codes exact in fp6: f8f6f4 MFMA
+  if (in_type == SNNQP_BITS && w->code_max > 0 && w->code_max <= 7) {
+    launch_conv3x3_fp6(a, nf, pl, lut, gy, st);  // codes exact in fp6: f8f6f4 MFMA
   } else if (in_type == SNNQP_BITS) {
     if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED, 0);
     else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE, 0);
@@ -682,6 +661,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_NONE, ldsb);
   }
 #undef SNNQP_CONV_LAUNCH
+#undef SNNQP_CONV_LAUNCH_NF
   SNNQP_CHECK_LAUNCH("conv3x3 mfma kernel");
   return SNNQP_OK;
 }

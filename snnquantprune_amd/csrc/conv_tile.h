@@ -152,7 +152,25 @@ __device__ __forceinline__ float reset_where(float u, unsigned long long mask) {
 
 struct LaneConsts {
   float bmean, bmul, bbias, dec;
+  float vr;      // v_reset (a VGPR operand of the reset select when it is not 0)
 };
+
+// The neuron update forms of spiking_learning.py, one straight-line epilogue each
+// (template parameter NF of the conv kernels):
+//   NF_MUL0   u += (x - u) * m, reset to 0        multi_step_LIF with tau = 2^j (m = 1/tau,
+//                                                 exact) and parametric_leaky_IF (m =
+//                                                 sigmoid(tau)), v_reset = 0     :381,410
+//   NF_MUL    u += (x - (u - v_reset)) * m        the same neurons, v_reset != 0
+//   NF_DIV    u += (x - (u - v_reset)) / tau      multi_step_LIF, any other tau    :410
+//   NF_DECAY  u = u * decay[c] + x                LIF (per-feature sigmoid(tau))   :432
+// all followed by s = (u >= v_th) and the hard reset u = s ? v_reset : u (:412-414).
+enum { NF_MUL0 = 1, NF_MUL = 2, NF_DIV = 3, NF_DECAY = 4 };
+
+__host__ inline int neuron_form(const NeuronP &n) {
+  if (n.kind == SNNQP_NEURON_LIF) return NF_DECAY;
+  if (n.inv_k == 0.0f) return NF_DIV;               // multi_step_LIF, tau not a power of two
+  return n.vr == 0.0f ? NF_MUL0 : NF_MUL;
+}
 
 // LDS accesses by absolute 32-bit LDS address (address space 3): the table reads
 // take the MFMA result itself as the address, with no per-read base add.
@@ -231,12 +249,39 @@ __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq, f
   return q * dq.m;
 }
 
+// u -> u' for two pixels of one channel (before threshold and reset).
+// FMA (NF_MUL0 only): u + d * m as one fused multiply-add.  Identical to the two-step
+// form whenever d * m is exact, i.e. never a subnormal with bits shifted out; the
+// caller proves that for the launch (lif_fma_is_exact) before taking this variant.
+template <int NF, bool FMA = false>
+__device__ __forceinline__ v2f neuron_update(v2f x, v2f u, const LaneConsts &lc,
+                                             const NeuronP &nrn) {
+  if (NF == NF_DECAY) {
+    const v2f ud = u * lc.dec;
+    return ud + x;
+  }
+  // u - 0 == u exactly, so NF_MUL0 skips the subtraction
+  const v2f d = NF == NF_MUL0 ? x - u : x - (u - lc.vr);
+  if (NF == NF_DIV) return u + v2f{d.x / nrn.k, d.y / nrn.k};
+  if (FMA) return __builtin_elementwise_fma(d, v2f{nrn.inv_k, nrn.inv_k}, u);
+  const v2f dk = d * nrn.inv_k;
+  return u + dk;
+}
+
+// hard reset of the lanes in `mask`
+template <int NF>
+__device__ __forceinline__ float neuron_reset(float u, unsigned long long mask,
+                                              const LaneConsts &lc) {
+  if (NF == NF_MUL0) return reset_where(u, mask);
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(lc.vr), "s"(mask));
+  return r;
+}
+
 // BatchNorm (unless the table already applied it) + neuron for two dequantised
-// currents (two pixels, same channel).
-// FMA: u + d / tau as one fused multiply-add.  Identical to the two-step form whenever
-// d / tau is exact, i.e. never a subnormal with bits shifted out; the caller proves
-// that for the launch (lif_fma_is_exact) before taking this variant.
-template <bool FAST, bool BNDONE, bool FMA = false>
+// currents (two pixels, same channel).  With float32 subnormals kept (hipcc default)
+// (u - v_th) >= 0  <=>  u >= v_th.
+template <int NF, bool BNDONE, bool FMA = false>
 __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
                                             const LaneConsts &lc, const NeuronP &nrn,
                                             unsigned long long &m0,
@@ -252,26 +297,11 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
     x = x * lc.bmul;
     x = x + lc.bbias;
   }
-  if (FAST) {
-    // multi_step_LIF with tau a power of two and v_reset == 0
-    // (spiking_learning.py:410-414): u - 0 == u exactly, and with float32
-    // subnormals kept (hipcc default) (u - v_th) >= 0  <=>  u >= v_th.
-    v2f uu = {u0, u1};
-    const v2f d = x - uu;
-    if (FMA) {
-      uu = __builtin_elementwise_fma(d, v2f{nrn.inv_k, nrn.inv_k}, uu);
-    } else {
-      const v2f dk = d * nrn.inv_k;
-      uu = uu + dk;
-    }
-    m0 = __ballot(uu.x >= nrn.vth);
-    m1 = __ballot(uu.y >= nrn.vth);
-    u0 = reset_where(uu.x, m0);
-    u1 = reset_where(uu.y, m1);
-  } else {
-    m0 = __ballot(neuron_step(u0, x.x, nrn, lc.dec));
-    m1 = __ballot(neuron_step(u1, x.y, nrn, lc.dec));
-  }
+  const v2f uu = neuron_update<NF, FMA>(x, v2f{u0, u1}, lc, nrn);
+  m0 = __ballot(uu.x >= nrn.vth);
+  m1 = __ballot(uu.y >= nrn.vth);
+  u0 = neuron_reset<NF>(uu.x, m0, lc);
+  u1 = neuron_reset<NF>(uu.y, m1, lc);
 }
 
 // BatchNorm + neuron + spike words of one 32x32 tile from its 8 dequantised pairs.
@@ -279,14 +309,14 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
 // and (ty + 1, tx) in its high half.  Returns the word this lane stores:
 //   POOL : lanes 0..7  = pooled pixel (pty = lane >> 2, ptx = lane & 3)
 //   !POOL: lanes 0..31 = pixel row `lane` of the tile
-template <bool FAST, bool POOL, bool BNDONE, bool FMA = false>
+template <int NF, bool POOL, bool BNDONE, bool FMA = false>
 __device__ __forceinline__ uint32_t tile_neurons(const v2f (&y)[8], float (&u)[16],
                                                  const LaneConsts &lc, const NeuronP &nrn) {
   uint32_t myw = 0;
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {     // masks are consumed pair by pair
     unsigned long long m0, m1;
-    neuron_pair<FAST, BNDONE, FMA>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
+    neuron_pair<NF, BNDONE, FMA>(y[i >> 1], u[i], u[i + 1], lc, nrn, m0, m1);
     // the masks are wave-uniform: v_writelane drops each word into the lane that
     // stores it (no per-lane compare masks to keep in SGPRs)
     if (POOL) {
@@ -306,7 +336,7 @@ __device__ __forceinline__ uint32_t tile_neurons(const v2f (&y)[8], float (&u)[1
 
 // Whole-tile epilogue (used where no MFMA stream runs beside it): all table
 // reads are issued first, then the pairs are processed.
-template <bool FAST, bool POOL, int LUTM, bool FMA = false, bool OFFS = false>
+template <int NF, bool POOL, int LUTM, bool FMA = false, bool OFFS = false>
 __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16],
                                                   const Dequant &dq,
                                                   const LaneConsts &lc,
@@ -315,7 +345,7 @@ __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16
   v2f y[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) y[j] = dequant_pair<LUTM, OFFS>(acc[2 * j], acc[2 * j + 1], dq, off);
-  return tile_neurons<FAST, POOL, LUTM == LUT_CHANNEL, FMA>(y, u, lc, nrn);
+  return tile_neurons<NF, POOL, LUTM == LUT_CHANNEL, FMA>(y, u, lc, nrn);
 }
 
 // Spike words are staged in LDS, obuf[slot = t % FL][pixel][4 words of the 128-
@@ -435,6 +465,7 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
 }
 
 // conv3x3_fp6.hip: bit-packed input, Cin = 128, codes of magnitude <= 7, fast neuron
-void launch_conv3x3_fp6(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy, hipStream_t st);
+void launch_conv3x3_fp6(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
+                        hipStream_t st);
 
 }  // namespace snnqp

@@ -663,34 +663,56 @@ def test_float_connection_f32_mfma(dev, oracle, shape):
 
 
 @pytest.mark.parametrize("cin", [128, 2])
-def test_conv_block_plif_takes_fast_epilogue(dev, oracle, cin):
-  """parametric_leaky_IF (u += (x - u) * sigmoid(tau), spiking_learning.py:381) has the
-  form of the straight-line epilogue: the fp6 / conv0 MFMA kernels serve it, bit-exact
-  with the oracle and with the direct-form kernel."""
+@pytest.mark.parametrize("kind", ["plif", "plif_vr", "lif", "lif_vr", "mslif_tau3", "mslif_tau4_vr"])
+def test_conv_block_neuron_forms(dev, oracle, cin, kind):
+  """Every neuron of spiking_learning.py has a straight-line epilogue on the MFMA conv
+  kernels (fp6 / conv0): parametric_leaky_IF (:381), LIF with per-feature decay (:432),
+  multi_step_LIF with a non-power-of-two tau (a true division, :410) and non-zero
+  v_reset -- bit-exact with the oracle and with the direct-form kernel."""
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
   hw = 8 if cin == 128 else 16
   c = cases.conv_block_case(T=6, B=4, hw=hw, cin=cin, seed=1501, gain=5.0 if cin > 2 else 4.0)
   if cin == 2:
     c["x"] = np.minimum(c["x"], 1).astype(np.uint8)
-  tau_param = F32(-0.35)
-  k = float((1.0 / (1.0 + np.exp(-np.float64(tau_param)))).astype(F32))
-  nrn = ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, k, 1.0, 0.0)
+  vr = 0.15 if kind.endswith("_vr") else 0.0
+  sig = lambda v: (1.0 / (1.0 + np.exp(-np.asarray(v, np.float64)))).astype(F32)
+  if kind.startswith("plif"):
+    tau_param = F32(-0.35)
+    nrn = ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, float(sig(tau_param)), 1.0, vr)
+    ocfg = {"kind": "parametric_leaky_IF", "tau_param": tau_param}
+  elif kind.startswith("lif"):
+    tau_vec = np.random.Generator(np.random.PCG64(9)).uniform(-1.0, 2.0, 128).astype(F32)
+    nrn = ops.Neuron(L.NEURON_LIF, 1.0, 1.0, vr, decay=_t(sig(tau_vec), dev))
+    ocfg = {"kind": "LIF", "tau_vec": tau_vec}
+  else:
+    tau = 3.0 if "tau3" in kind else 4.0
+    nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, tau, 1.0, vr)
+    ocfg = {"kind": "multi_step_LIF", "tau": tau}
+  ocfg.update(v_threshold=1.0, v_reset=vr)
   qw = qweight_of(oracle, c["leaf"], c["bits"])
-  eu, es = oracle.conv_block(c["x"], qw, c["bn"],
-                             {"kind": "parametric_leaky_IF", "tau_param": tau_param}, "int")
+  eu, es = oracle.conv_block(c["x"], qw, c["bn"], ocfg, "int")
+  assert 0.01 < es.mean() < 0.6, es.mean()
   w = _weight(c["leaf"], c["bits"], dev, transposed=True)
   geom = ops.ConvGeom(hw, hw, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
   xt = _t(c["x"], dev)
   xin = xt if cin == 2 else ops.pack_bits(xt)
   for impl in (L.IMPL_MFMA, L.IMPL_GENERIC):
-    u, s = ops.conv_lif_forward(xin, geom, w, nrn, bn=_bn(c["bn"], dev), packed_out=True,
-                                impl=impl, x_max=1)
-    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="impl %d" % impl)
-    np.testing.assert_array_equal(_np(u), eu)
+    for x_max in (1, 0):                  # with and without the dequant tables
+      u, s = ops.conv_lif_forward(xin, geom, w, nrn, bn=_bn(c["bn"], dev), packed_out=True,
+                                  impl=impl, x_max=x_max)
+      np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="impl %d" % impl)
+      np.testing.assert_array_equal(_np(u), eu)
   _, sp = ops.conv_lif_forward(xin, geom, w, nrn, bn=_bn(c["bn"], dev), packed_out=True, pool=2,
                                impl=L.IMPL_MFMA, want_u=False, x_max=1)
   np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
+  if cin == 128:                          # the int8 kernel (codes wider than fp6 holds)
+    import dataclasses
+    w8 = dataclasses.replace(w, code_max=0)
+    u, s = ops.conv_lif_forward(xin, geom, w8, nrn, bn=_bn(c["bn"], dev), packed_out=True,
+                                impl=L.IMPL_MFMA, x_max=1)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(u), eu)
 
 
 def test_conv_block_xcd_split_schedule(dev, oracle):
