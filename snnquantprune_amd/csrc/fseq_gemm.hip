@@ -31,15 +31,27 @@ constexpr int FG_LD = 160;      // LDS row stride (floats) of one k: 128 + 32, s
                                 // halves (k, k + 1) of an MFMA operand read disjoint banks
 
 struct FseqGemmArgs {
-  const float *x;       // [NB][H][W][Cin]
+  const void *x;        // [NB][H][W][Cin] float32 / uint8, or [NB][H][W][Cin/32] spike words
   const float *w;       // [K][N]
   float *y;             // [M][N]
   int64_t M;
   int32_t N, K, H, W, Cin, KH, KW, pad_h, pad_w;
 };
 
-// CHUNK_IN_TAP: Cin % 16 == 0, a k chunk never straddles a tap (one address computation)
-template <bool CHUNK_IN_TAP>
+// Input element types: float32, or integer-typed activations (uint8 counts, bit-packed
+// spikes) widened to float32 on the fly -- an unquantised (float32) kernel fed by spikes
+// runs the same fmaf chain, with x in {0, 1, 2, ...} exactly.
+// MODE 0: float32, Cin % 16 == 0 (a k chunk lies in one tap: one address computation)
+//      1: float32, Cin % 4 == 0 (runs of 4 channels)
+//      2: any type and Cin, element by element (the 2-channel event input; uint8; bits)
+template <int IN> __device__ __forceinline__ float fg_load(const void *x, int64_t pix, int c, int Cin) {
+  if (IN == SNNQP_F32) return ((const float *)x)[pix * Cin + c];
+  if (IN == SNNQP_U8) return (float)((const uint8_t *)x)[pix * Cin + c];
+  const uint32_t w = ((const uint32_t *)x)[pix * ((Cin + 31) >> 5) + (c >> 5)];
+  return (float)((w >> (c & 31)) & 1u);
+}
+
+template <int MODE, int IN>
 __global__ void __launch_bounds__(256)
 fseq_gemm_kernel(FseqGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][FG_KC * FG_LD];   // [buf][A|B]
@@ -67,14 +79,26 @@ fseq_gemm_kernel(FseqGemmArgs a) {
   v4f ra[2], rb[2];
   auto load_chunk = [&](int kc) {          // global -> registers
     const int k0 = kc * FG_KC;
-    if (CHUNK_IN_TAP) {
+    if (MODE == 0) {
       const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
       const int kh = tap / a.KW, kw = tap - kh * a.KW;
       const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
       const bool ok = arow && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float *src = a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0 + ak;
+      const float *src = (const float *)a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0 + ak;
       ra[0] = ok ? *(const v4f *)src : v4f{0.f, 0.f, 0.f, 0.f};
       ra[1] = ok ? *(const v4f *)(src + 4) : v4f{0.f, 0.f, 0.f, 0.f};
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = k0 + ak + 4 * j + e;
+          const int tap = kk / a.Cin, c = kk - tap * a.Cin;
+          const int kh = tap / a.KW, kw = tap - kh * a.KW;
+          const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
+          const bool ok = arow && kk < a.K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          ra[j][e] = ok ? fg_load<IN>(a.x, (img * a.H + iy) * a.W + ix, c, a.Cin) : 0.0f;
+        }
     } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -83,7 +107,7 @@ fseq_gemm_kernel(FseqGemmArgs a) {
       const int kh = tap / a.KW, kw = tap - kh * a.KW;
       const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
       const bool ok = arow && kk < a.K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      ra[j] = ok ? *(const v4f *)(a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0)
+      ra[j] = ok ? *(const v4f *)((const float *)a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0)
                  : v4f{0.f, 0.f, 0.f, 0.f};
     }
     const int kb = k0 + bk;
@@ -166,17 +190,17 @@ fseq_gemm_kernel(FseqGemmArgs a) {
 // nullptr when the kernel serves the request, else the reason
 const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                   const snnqp_weight_t *w) {
-  if (in_type != SNNQP_F32 || w->wtype != SNNQP_W_F32) return "not float32 x float32";
+  if (w->wtype != SNNQP_W_F32) return "kernel is not float32";
+  if (in_type != SNNQP_F32 && in_type != SNNQP_U8 && in_type != SNNQP_BITS) return "input type";
   if (g->groups != 1) return "grouped";
   if (g->stride_h != 1 || g->stride_w != 1) return "strided";
   if (g->in_dil_h != 1 || g->in_dil_w != 1 || g->k_dil_h != 1 || g->k_dil_w != 1) return "dilated";
-  if (g->Cin % 4) return "Cin % 4";
   if (g->pad_h_lo + g->pad_h_hi != g->KH - 1 || g->pad_w_lo + g->pad_w_hi != g->KW - 1)
     return "output size differs from input size";
   return nullptr;
 }
 
-int run_fseq_gemm(const float *x, int64_t NB, const snnqp_conv_geom_t *g,
+int run_fseq_gemm(const void *x, int in_type, int64_t NB, const snnqp_conv_geom_t *g,
                   const snnqp_weight_t *w, float *y, hipStream_t st) {
   FseqGemmArgs a;
   a.x = x; a.w = (const float *)w->w; a.y = y;
@@ -188,8 +212,16 @@ int run_fseq_gemm(const float *x, int64_t NB, const snnqp_conv_geom_t *g,
   const int64_t gx = ceil_div64(a.M, FG_BM);
   SNNQP_REQUIRE(gx < (1ll << 31), SNNQP_EINVAL, "fseq gemm: grid too large");
   const dim3 grid((unsigned)gx, (unsigned)((a.N + FG_BN - 1) / FG_BN));
-  if (a.Cin % FG_KC == 0) hipLaunchKernelGGL(fseq_gemm_kernel<true>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(fseq_gemm_kernel<false>, grid, dim3(256), 0, st, a);
+  if (in_type == SNNQP_U8)
+    hipLaunchKernelGGL((fseq_gemm_kernel<2, SNNQP_U8>), grid, dim3(256), 0, st, a);
+  else if (in_type == SNNQP_BITS)
+    hipLaunchKernelGGL((fseq_gemm_kernel<2, SNNQP_BITS>), grid, dim3(256), 0, st, a);
+  else if (a.Cin % FG_KC == 0)
+    hipLaunchKernelGGL((fseq_gemm_kernel<0, SNNQP_F32>), grid, dim3(256), 0, st, a);
+  else if (a.Cin % 4 == 0)
+    hipLaunchKernelGGL((fseq_gemm_kernel<1, SNNQP_F32>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((fseq_gemm_kernel<2, SNNQP_F32>), grid, dim3(256), 0, st, a);
   SNNQP_CHECK_LAUNCH("fseq_gemm_kernel");
   return SNNQP_OK;
 }

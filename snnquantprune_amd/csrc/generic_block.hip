@@ -225,7 +225,7 @@ extern "C" int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
     int32_t OH, OW;
     const int rc = check_geom(g, &OH, &OW);
     if (rc) return rc;
-    return run_fseq_gemm((const float *)x, NB, g, w, y, (hipStream_t)stream);
+    return run_fseq_gemm(x, in_type, NB, g, w, y, (hipStream_t)stream);
   }
   // the NB images are the "batch"; T = 1
   return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr,

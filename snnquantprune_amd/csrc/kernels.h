@@ -24,7 +24,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
 // float32 x float32 connection on the f32 MFMA (fseq_gemm.hip)
 const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                   const snnqp_weight_t *w);
-int run_fseq_gemm(const float *x, int64_t NB, const snnqp_conv_geom_t *g,
+int run_fseq_gemm(const void *x, int in_type, int64_t NB, const snnqp_conv_geom_t *g,
                   const snnqp_weight_t *w, float *y, hipStream_t st);
 
 const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,

@@ -338,10 +338,10 @@ def unpack_bits(s: PackedSpikes) -> torch.Tensor:
 
 def fseq_gemm_supported(geom: ConvGeom) -> bool:
   """Shapes the float32-MFMA connection kernel serves (fseq_gemm.hip): stride 1, no
-  dilation or groups, output size == input size, Cin % 4 == 0 (dense = 1x1 on 1x1)."""
+  dilation or groups, output size == input size (dense = 1x1 on a 1x1 image)."""
   (pt, pb), (pl, pr) = geom.pad
   return (geom.groups == 1 and tuple(geom.stride) == (1, 1) and tuple(geom.in_dil) == (1, 1)
-          and tuple(geom.k_dil) == (1, 1) and geom.Cin % 4 == 0
+          and tuple(geom.k_dil) == (1, 1)
           and pt + pb == geom.KH - 1 and pl + pr == geom.KW - 1)
 
 

@@ -269,41 +269,22 @@ class SpikingBlock(nn.Module):
     if (is_dense and integer and w.wtype == L.W_I8 and isinstance(x, torch.Tensor)
         and x.dtype == torch.uint8 and self.impl == L.IMPL_AUTO and ops.input_max_bound(x) == 1):
       x = ops.pack_bits(x)
-    # unquantised kernels (config C1) fed by spikes: the float32 kernel wants float32
-    # activations -- widen them when that stays small, and take the f32-MFMA route below
-    if (w.wtype == L.W_F32 and self.impl == L.IMPL_AUTO and flat is None
-        and (isinstance(x, ops.PackedSpikes) or x.dtype == torch.uint8)):
-      numel = 1
-      for d in x.shape:
-        numel *= int(d)
-      if numel <= (1 << 26):
-        x = x.to_dense() if isinstance(x, ops.PackedSpikes) else x.to(torch.float32)
-        if not tm:                     # [B, T, ...] -> time-major (small tensor)
-          x = x.transpose(0, 1).contiguous()
-          tm = True
-        integer = False
-    # real-valued activations (the TCJA-gated blocks): the connection runs on the f32
-    # MFMA (same fmaf chain as the direct-form kernel), then BatchNorm + neuron scan
-    if (not integer and tm and self.impl == L.IMPL_AUTO and w.wtype == L.W_F32
-        and isinstance(x, torch.Tensor) and x.dtype == torch.float32):
+    # float32 kernels -- the real-valued TCJA-gated blocks, and unquantised layers whatever
+    # feeds them (float32, uint8 counts or packed spikes: widened on the fly) -- run the
+    # connection on the f32 MFMA (the same fmaf chain as the direct-form kernel), then the
+    # BatchNorm + neuron scan.  The float32 currents go through HBM, so the batch is
+    # walked in slices that keep them under ~1 GiB.
+    if w.wtype == L.W_F32 and self.impl == L.IMPL_AUTO and (
+        isinstance(x, ops.PackedSpikes) or x.dtype in (torch.float32, torch.uint8)):
       geom = None
       if is_dense and x.ndim == 3:
         geom = ops.ConvGeom(1, 1, cin, conn.features, 1, 1)
       elif not is_dense and len(conn._ksize()) == 2 and x.ndim == 5:
         geom = conn.geometry(tuple(x.shape[2:-1]), cin)
       if geom is not None and ops.fseq_gemm_supported(geom):
-        T, B = x.shape[0], x.shape[1]
-        xi = x.reshape((T * B,) + ((1, 1, cin) if is_dense else tuple(x.shape[2:])))
-        with ops._timed("%s[f32 %s]" % ("dense" if is_dense else "conv", geom.tag())):
-          y = ops.conv_forward(xi, geom, w)
-        y = y.reshape((T, B) + ((conn.features,) if is_dense else tuple(y.shape[1:])))
-        u_out, s = ops.lif_forward(y, nrn, bn=bn, u0=u0, want_u=self.return_state,
-                                   packed_out=packed_out)
-        if self.pool == 2:
-          if is_dense:
-            raise ValueError("pool=2 needs a convolutional block")
-          s = ops.maxpool2x2(s)
-        return u_out, s
+        if self.pool == 2 and is_dense:
+          raise ValueError("pool=2 needs a convolutional block")
+        return self._float_block(x, tm, is_dense, geom, w, nrn, bn, u0, packed_out)
 
     if is_dense:
       if x.ndim != 3:
@@ -353,6 +334,51 @@ class SpikingBlock(nn.Module):
         s = s.reshape(T, B, s.shape[3], s.shape[4])
       if u_out is not None:
         u_out = u_out.squeeze(1)
+    return u_out, s
+
+  # -- float32 kernel: f32-MFMA connection + neuron scan, batch slice by batch slice ----
+  def _float_block(self, x, tm, is_dense, geom, w, nrn, bn, u0, packed_out):
+    T, B = (x.shape[0], x.shape[1]) if tm else (x.shape[1], x.shape[0])
+    N = geom.Cout
+    per_sample = 4 * T * geom.H * geom.W * N              # bytes of float32 currents
+    step = max(1, min(B, (1 << 30) // max(per_sample, 1)))
+    tag = "%s[f32 %s]" % ("dense" if is_dense else "conv", geom.tag())
+    us, ss = [], []
+    for b0 in range(0, B, step):
+      b1 = min(B, b0 + step)
+      if tm:
+        xs = x[(slice(None), slice(b0, b1))]
+      else:                                               # [B, T, ...] -> time-major slice
+        xs = x[b0:b1]
+        if isinstance(xs, ops.PackedSpikes):
+          xs = ops.PackedSpikes(xs.bits.transpose(0, 1).contiguous(), xs.channels)
+        else:
+          xs = xs.transpose(0, 1)
+      if isinstance(xs, torch.Tensor):
+        xs = xs.contiguous()
+      nb = b1 - b0
+      if isinstance(xs, ops.PackedSpikes):
+        xi = xs.reshape_leading(*((T * nb, 1, 1) if is_dense else (T * nb, geom.H, geom.W)))
+      else:
+        xi = xs.reshape((T * nb,) + ((1, 1, geom.Cin) if is_dense else (geom.H, geom.W, geom.Cin)))
+      with ops._timed(tag):
+        y = ops.conv_forward(xi, geom, w)
+      y = y.reshape((T, nb) + ((N,) if is_dense else (geom.H, geom.W, N)))
+      u0s = None if u0 is None else u0[b0:b1]
+      u_out, s = ops.lif_forward(y, nrn, bn=bn, u0=u0s, want_u=self.return_state,
+                                 packed_out=packed_out)
+      del y
+      if self.pool == 2:
+        s = ops.maxpool2x2(s)
+      us.append(u_out)
+      ss.append(s)
+    if len(ss) == 1:
+      return us[0], ss[0]
+    if isinstance(ss[0], ops.PackedSpikes):
+      s = ops.PackedSpikes(torch.cat([p.bits for p in ss], 1), ss[0].channels)
+    else:
+      s = torch.cat(ss, 1)
+    u_out = None if us[0] is None else torch.cat(us, 0)
     return u_out, s
 
   # -- arbitrary connection / norm / neuron: compose the stand-alone ops -----------

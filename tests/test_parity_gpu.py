@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from tests import cases
-from tests.helpers import packbits_lastaxis, qweight_of
+from tests.helpers import bn_of, packbits_lastaxis, qweight_of
 
 pytestmark = pytest.mark.gpu
 F32 = np.float32
@@ -713,6 +713,43 @@ def test_conv_block_neuron_forms(dev, oracle, cin, kind):
                                 impl=L.IMPL_MFMA, x_max=1)
     np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
     np.testing.assert_array_equal(_np(u), eu)
+
+
+def test_unquantised_conv_net_on_f32_mfma(dev, oracle):
+  """A network whose kernels pass through unquantised (DuQ a = -1: float32 kernels),
+  fed by event counts / spikes: every block takes the f32-MFMA connection (inputs
+  widened on the fly, the batch walked in slices) and equals the oracle's fseq mode bit
+  for bit, logits included."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  from snnquantprune_amd import spiking_learning as sl
+  v = syn.conv_net_variables(hw=16, quantized=False, prune_p=0.5, random_bn=True,
+                             gains=(5.0, 7.0, 8.0, 12.0))
+  x = syn.poisson_counts((5, 4, 16, 16, 2), 0.25, seed=977)          # [B, T, H, W, 2] counts
+  p = v["params"]
+  r = oracle.conv3_dense_forward(
+      x, [qweight_of(oracle, p["QuantConv_%d" % i], 4) for i in range(3)],
+      [bn_of(v, i) for i in range(3)], qweight_of(oracle, p["QuantDense_0"], 4), mode="fseq")
+  rates = [r["pool%d" % i].mean() for i in range(3)]
+  assert all(0.01 < q < 0.7 for q in rates), rates
+  cfg = syn.make_config(bits=4, prune_percentage=0.5)
+  model = models.ConvDenseSNN(num_classes=11, config=cfg)
+  old = sl.SpikingBlock._float_block
+  slices = []
+  def spy(self, x_, tm, is_dense, geom, *a, **k):       # the route really is taken
+    slices.append(geom.tag())
+    return old(self, x_, tm, is_dense, geom, *a, **k)
+  sl.SpikingBlock._float_block = spy
+  try:
+    (logits, _), mut = model.apply(nn.tree_from_numpy(v, dev), _t(x, dev), trgt=None,
+                                   train=False, rng=None, mutable=["intermediates"])
+  finally:
+    sl.SpikingBlock._float_block = old
+  assert len(slices) == 4, slices
+  for i in range(3):
+    np.testing.assert_array_equal(_np(mut["intermediates"]["pool%d" % i][0]),
+                                  packbits_lastaxis(r["pool%d" % i]))
+  np.testing.assert_array_equal(_np(logits), r["logits"])
 
 
 def test_conv_block_xcd_split_schedule(dev, oracle):
