@@ -579,8 +579,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   if (g->in_dil_h != 1 || g->in_dil_w != 1 || g->k_dil_h != 1 || g->k_dil_w != 1)
     return "dilated convolution";
   if (g->groups != 1) return "grouped convolution";
-  if (g->H <= 0 || g->W <= 0 || (g->H & 7) || (g->W & 7))
-    return "H and W must be positive multiples of 8";
+  if (g->H <= 0 || g->W <= 0) return "empty image";    // any size: edge patches are clipped
   if (g->Cout & 31) return "Cout must be a multiple of 32";
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
   if (in_type == SNNQP_BITS) {
@@ -617,7 +616,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.bn = make_bn(bn);
   a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
-  a.tiles_y = g->H / 8; a.tiles_x = g->W / 8;
+  a.tiles_y = (g->H + 7) / 8; a.tiles_x = (g->W + 7) / 8;
   a.npatch = (int64_t)B * a.tiles_y * a.tiles_x;
   const int nf = neuron_form(a.nrn);          // which straight-line epilogue (conv_tile.h)
   const bool pl = pool == 2;

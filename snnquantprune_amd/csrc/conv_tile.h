@@ -384,8 +384,9 @@ __device__ __forceinline__ void flush_ring(const uint32_t *obuf, const ConvMfmaA
     const int slot = i / NPIX, pix = i % NPIX;
     const int t = t0 + slot;
     const uint32_t *src = obuf + ((t % SLOTS) * NPIX + pix) * 4;
-    uint32_t *dst = a.s_out + ((((int64_t)t * a.B + b) * OH + (oy0 + pix / PW)) * OW +
-                               (ox0 + pix % PW)) * CW + cwb;
+    const int oy = oy0 + pix / PW, ox = ox0 + pix % PW;
+    if (oy >= OH || ox >= OW) continue;          // edge patch of an image not 8-aligned
+    uint32_t *dst = a.s_out + ((((int64_t)t * a.B + b) * OH + oy) * OW + ox) * CW + cwb;
     if (nw == 4 && (CW & 3) == 0) {
       *(v4i *)dst = *(const v4i *)src;
     } else {
@@ -411,8 +412,9 @@ __device__ __forceinline__ void u_io_tile(float (&u)[16], const ConvMfmaArgs &a,
     const int y = y0 + tl * 4 + (h | ((i >> 3) << 1));
     const int x = x0 + (i & 7);
     const int64_t o = (((int64_t)b * a.H + y) * a.W + x) * a.Cout + cout;
-    if (LOAD) u[i] = ui[o];
-    else uo[o] = u[i];
+    const bool in = y < a.H && x < a.W;
+    if (LOAD) u[i] = in ? ui[o] : 0.0f;
+    else if (in) uo[o] = u[i];
   }
 }
 
@@ -428,8 +430,9 @@ __device__ __forceinline__ void u_io(float (&u)[2][16], const ConvMfmaArgs &a,
       const int y = y0 + tl * 4 + (h | ((i >> 3) << 1));
       const int x = x0 + (i & 7);
       const int64_t o = (((int64_t)b * a.H + y) * a.W + x) * a.Cout + cout;
-      if (LOAD) u[tl][i] = ui[o];
-      else uo[o] = u[tl][i];
+      const bool in = y < a.H && x < a.W;
+      if (LOAD) u[tl][i] = in ? ui[o] : 0.0f;
+      else if (in) uo[o] = u[tl][i];
     }
 }
 

@@ -770,6 +770,47 @@ def test_conv_block_xcd_split_schedule(dev, oracle):
     np.testing.assert_array_equal(_np(u), e["u"])
 
 
+@pytest.mark.parametrize("shape", ["c128_34x34", "c128_17x17", "c128_12x20", "c2_34x34", "c2_28x28",
+                                   "c2_5x3"])
+def test_conv_block_any_image_size(dev, oracle, shape):
+  """Image sizes that are not multiples of the 8x8 patch (N-MNIST 34x34, MNIST 28x28,
+  the 17x17 a pooled 34x34 leaves, odd sizes): the MFMA kernels clip the edge patches;
+  rasters, pooled rasters (VALID 2x2: the odd last row / column is dropped), potentials
+  and the carry-in path bit-exact."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  cin = 128 if shape.startswith("c128") else 2
+  H, W = [int(v) for v in shape.split("_")[1].split("x")]
+  rng = np.random.Generator(np.random.PCG64(3000 + H * 64 + W))
+  c = cases.conv_block_case(T=4, B=3, hw=8, cin=cin, seed=1601, gain=5.0 if cin > 2 else 4.0)
+  if cin == 2:
+    x = np.minimum(rng.poisson(0.3, (4, 3, H, W, 2)), 3).astype(np.uint8)
+  else:
+    x = (rng.random((4, 3, H, W, 128)) < 0.15).astype(np.uint8)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  eu, es = oracle.conv_block(x, qw, c["bn"], None, "int")
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  geom = ops.ConvGeom(H, W, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xt = _t(x, dev)
+  xin = xt if cin == 2 else ops.pack_bits(xt)
+  x_max = ops.input_max_bound(xin)
+  u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                              impl=L.IMPL_MFMA, x_max=x_max)
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+  if H >= 2 and W >= 2:
+    _, sp = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                 pool=2, impl=L.IMPL_MFMA, want_u=False, x_max=x_max)
+    np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
+  # carry-in: two halves of T
+  u1, s1 = ops.conv_lif_forward(xin[:2], geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                impl=L.IMPL_MFMA, x_max=x_max)
+  u2, s2 = ops.conv_lif_forward(xin[2:], geom, w, _mslif(), bn=_bn(c["bn"], dev), u0=u1,
+                                packed_out=True, impl=L.IMPL_MFMA, x_max=x_max)
+  np.testing.assert_array_equal(np.concatenate([_np(s1), _np(s2)]), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u2), eu)
+
+
 def test_mfma_kernel_refuses_unsupported_shapes(dev):
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
