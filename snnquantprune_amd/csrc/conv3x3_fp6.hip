@@ -32,10 +32,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) const v4i lds_cv4i_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
 
-constexpr int F6_KS = 18;                    // k-steps of 64: (tap, 64-channel half)
+// k-steps of 64: (tap, 64-channel group); Cin = 64 or 128 (template parameter CIN)
 constexpr int F6_PITCH = 12;                 // pixels per LDS halo row (10 used)
 constexpr int F6_PLANE = HALO * F6_PITCH * 32;   // one 64-channel half of a halo image
-constexpr int F6_HALO = 2 * F6_PLANE;        // one fp4 halo image (7680 B)
 constexpr int F6_TAB = 1024;                 // byte -> 8 fp4 nibbles
 #ifndef SNNQP_F6_PREFETCH
 #define SNNQP_F6_PREFETCH 4
@@ -88,9 +87,15 @@ extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
 #define F6_MARK(i)
 #endif
 
-template <int NF, bool POOL, bool LUT>
+template <int CIN, int NF, bool POOL, bool LUT>
 __global__ void __launch_bounds__(512, 1)
 conv3x3_fp6_kernel(ConvMfmaArgs a) {
+  static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
+  constexpr int NP = CIN / 64;                   // planes of the halo image
+  constexpr int WPP = CIN / 32;                  // spike words per pixel
+  constexpr int F6_KS = 9 * NP;
+  constexpr int F6_HALO = NP * F6_PLANE;         // one fp4 halo image
+  constexpr int PPS = (32 + F6_KS - 1) / F6_KS;  // epilogue pieces per MFMA slot
   constexpr int FL = POOL ? 16 : 4;              // timesteps per flush block
   constexpr int SLOTS = 2 * FL;                  // ring of staged spike words
   constexpr int NPIX = OutStage<POOL>::NPIX;
@@ -119,14 +124,14 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   }
   if (LUT) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid, 512);
 
-  // B operand: k-step ks = 2 tap + kk covers channels 64 kk .. +63 of the tap; lane
-  // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile 4 tap + 2 kk + h
+  // B operand: k-step ks = NP tap + kk covers channels 64 kk .. +63 of the tap; lane
+  // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile WPP tap + 2 kk + h
   int bf[F6_KS][6];
   {
-    const v4i *wtile = (const v4i *)a.wt + (int64_t)(cout_base >> 5) * 36 * 64;
+    const v4i *wtile = (const v4i *)a.wt + (int64_t)(cout_base >> 5) * (9 * WPP) * 64;
 #pragma unroll
     for (int ks = 0; ks < F6_KS; ++ks) {
-      const int ks8 = (ks >> 1) * 4 + (ks & 1) * 2 + h;
+      const int ks8 = (ks / NP) * WPP + (ks % NP) * 2 + h;
       v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
       if (wave_on) {
         lo = wtile[ks8 * 64 + n];
@@ -156,8 +161,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   const uint32_t abase_odd = pixb + (uint32_t)((h ^ (ty & 1) ^ 1) * 16);    // dy = 1
 
   // staging task of this thread: word wi of halo pixel pix
-  const int s_pix = tid >> 2, s_wi = tid & 3;
-  const bool s_task = tid < HALO * HALO * 4;
+  const int s_pix = tid / WPP, s_wi = tid % WPP;
+  const bool s_task = tid < HALO * HALO * WPP;
   const int s_hy = s_pix / HALO, s_hx = s_pix % HALO;
   uint8_t *s_dst = lds + (s_wi >> 1) * F6_PLANE + (s_hy * F6_PITCH + s_hx) * 32 +
                    (((s_wi & 1) ^ (s_hy & 1)) * 16);
@@ -187,7 +192,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
 
     const int gy = y0 + s_hy - 1, gx = x0 + s_hx - 1;
     const bool s_valid = s_task && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * 4 + s_wi;
+    const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * WPP + s_wi;
     uint32_t stg = 0;
     auto stage_load = [&](int t) {
       stg = s_valid ? xb[(int64_t)t * a.xs_t + s_goff] : 0u;
@@ -205,8 +210,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       if (s_task) *(v4i *)(s_dst + buf * F6_HALO) = s_exp;
     };
     auto a_read = [&](int buf, int ks) -> v4i {
-      const int tap = ks >> 1;
-      const uint32_t off = (uint32_t)(buf * F6_HALO + (ks & 1) * F6_PLANE +
+      const int tap = ks / NP;
+      const uint32_t off = (uint32_t)(buf * F6_HALO + (ks % NP) * F6_PLANE +
                                       ((tap / 3) * F6_PITCH + tap % 3) * 32);
       return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? abase_odd : abase_even) + off);
     };
@@ -244,7 +249,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // One pipelined step in a hand-placed order: 18 slots, each = one A read PF
+    // One pipelined step in a hand-placed order: 9 NP slots, each = one A read PF
     // k-steps ahead, one MFMA of step t + 1 and two quarter-pairs of the epilogue of
     // step t (8 pairs x 4 pieces = 32 pieces), fenced so the order survives.  An MFMA
     // that waits at the issue port (matrix pipe busy, or its accumulator not ready)
@@ -304,8 +309,9 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
 #endif
         mfma_one(ks, A[ks % (PF + 1)], accN);
 #if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 2))   // diagnostic build: no epilogue
-        if (2 * ks < 32) piece(2 * ks);
-        if (2 * ks + 1 < 32) piece(2 * ks + 1);
+#pragma unroll
+        for (int q = 0; q < PPS; ++q)
+          if (ks * PPS + q < 32) piece(ks * PPS + q);
 #endif
         // pin the slot: everything it produced is an operand of an (empty) volatile
         // asm, so neither the MFMA nor the pieces can drift to another slot (the
@@ -388,21 +394,28 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   }
 }
 
-template <int NF>
+template <int CIN, int NF>
 static void launch_fp6_nf(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
                           hipStream_t st) {
-  if (pool && lut) launch_persistent(conv3x3_fp6_kernel<NF, true, true>, a, gy, st, 0, 512);
-  else if (pool) launch_persistent(conv3x3_fp6_kernel<NF, true, false>, a, gy, st, 0, 512);
-  else if (lut) launch_persistent(conv3x3_fp6_kernel<NF, false, true>, a, gy, st, 0, 512);
-  else launch_persistent(conv3x3_fp6_kernel<NF, false, false>, a, gy, st, 0, 512);
+  if (pool && lut) launch_persistent(conv3x3_fp6_kernel<CIN, NF, true, true>, a, gy, st, 0, 512);
+  else if (pool) launch_persistent(conv3x3_fp6_kernel<CIN, NF, true, false>, a, gy, st, 0, 512);
+  else if (lut) launch_persistent(conv3x3_fp6_kernel<CIN, NF, false, true>, a, gy, st, 0, 512);
+  else launch_persistent(conv3x3_fp6_kernel<CIN, NF, false, false>, a, gy, st, 0, 512);
+}
+
+template <int CIN>
+static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
+                           hipStream_t st) {
+  if (nf == NF_MUL0) launch_fp6_nf<CIN, NF_MUL0>(a, pool, lut, gy, st);
+  else if (nf == NF_MUL) launch_fp6_nf<CIN, NF_MUL>(a, pool, lut, gy, st);
+  else if (nf == NF_DIV) launch_fp6_nf<CIN, NF_DIV>(a, pool, lut, gy, st);
+  else launch_fp6_nf<CIN, NF_DECAY>(a, pool, lut, gy, st);
 }
 
 void launch_conv3x3_fp6(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
                         hipStream_t st) {
-  if (nf == NF_MUL0) launch_fp6_nf<NF_MUL0>(a, pool, lut, gy, st);
-  else if (nf == NF_MUL) launch_fp6_nf<NF_MUL>(a, pool, lut, gy, st);
-  else if (nf == NF_DIV) launch_fp6_nf<NF_DIV>(a, pool, lut, gy, st);
-  else launch_fp6_nf<NF_DECAY>(a, pool, lut, gy, st);
+  if (a.Cin == 64) launch_fp6_cin<64>(a, nf, pool, lut, gy, st);
+  else launch_fp6_cin<128>(a, nf, pool, lut, gy, st);
 }
 
 }  // namespace snnqp

@@ -583,7 +583,8 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   if (g->Cout & 31) return "Cout must be a multiple of 32";
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
   if (in_type == SNNQP_BITS) {
-    if (g->Cin != 128) return "bit input needs Cin == 128";
+    const bool fp6 = w->code_max > 0 && w->code_max <= 7;     // conv3x3_fp6.hip: Cin 64 / 128
+    if (g->Cin != 128 && !(fp6 && g->Cin == 64)) return "bit input needs Cin == 128 (or 64 with codes <= 7)";
   } else if (in_type == SNNQP_U8) {     // any count 0..255 (taken as x - 128 without a table)
     if (g->Cin != 2) return "u8 input needs Cin == 2";
   } else {

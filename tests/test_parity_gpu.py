@@ -811,6 +811,39 @@ def test_conv_block_any_image_size(dev, oracle, shape):
   np.testing.assert_array_equal(_np(u2), eu)
 
 
+@pytest.mark.parametrize("cout", [64, 128, 160])
+def test_conv_block_64_input_channels(dev, oracle, cout):
+  """Blocks of 64 input channels (config.channels = 64) run on the fp6 MFMA kernel too
+  (one 64-channel plane, 9 k-steps); codes wider than fp6 holds stay on the direct-form
+  kernel.  Bit-exact rasters / pooled rasters / potentials."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=5, B=3, hw=8, cin=64, cout=cout, seed=1701, gain=5.0)
+  rng = np.random.Generator(np.random.PCG64(88))
+  x = (rng.random((5, 3, 12, 20, 64)) < 0.2).astype(np.uint8)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  eu, es = oracle.conv_block(x, qw, c["bn"], None, "int")
+  assert 0.01 < es.mean() < 0.6
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  geom = ops.ConvGeom(12, 20, 64, cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(x, dev))
+  for x_max in (1, 0):
+    u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                impl=L.IMPL_MFMA, x_max=x_max)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(u), eu)
+  _, sp = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                               pool=2, impl=L.IMPL_MFMA, want_u=False, x_max=1)
+  np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
+  with pytest.raises(L.SnnqpError):       # int8 MFMA kernel is Cin = 128 only
+    ops.conv_lif_forward(xin, geom, dataclasses.replace(w, code_max=0), _mslif(),
+                         packed_out=True, impl=L.IMPL_MFMA)
+  u, s = ops.conv_lif_forward(xin, geom, dataclasses.replace(w, code_max=0), _mslif(),
+                              bn=_bn(c["bn"], dev), packed_out=True)      # AUTO -> direct form
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+
+
 def test_mfma_kernel_refuses_unsupported_shapes(dev):
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
