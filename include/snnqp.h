@@ -204,7 +204,8 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
 
 /* Same for QuantDense: x [T][B][K], weights [K][N] (GENERIC) .
  * IMPL_MFMA additionally needs `wt`: the int8 codes tiled by
- * snnqp_pack_codes_mfma (Npad = N rounded up to 32), BITS input, K % 32 == 0,
+ * snnqp_pack_codes_mfma (Npad = N rounded up to 32; K rows zero-padded to a multiple
+ * of 32 when K is not one), BITS input (zero bits beyond K),
  * T <= 160, s_type BITS. */
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,

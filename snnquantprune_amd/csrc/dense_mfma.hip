@@ -31,7 +31,7 @@ constexpr int KSC = BK / 32;     // MFMA k-steps per chunk
 struct DenseMfmaArgs {
   const uint32_t *x;
   int64_t xs_t, xs_b;            // word strides
-  int32_t T, B, K, N, KS, SB;    // KS = K / 32, SB samples per workgroup
+  int32_t T, B, K, N, KS, SB;    // KS = ceil(K / 32), SB samples per workgroup
   const int8_t *wt;              // MFMA-tiled codes [Npad/32][KS][64][16]
   Dequant dq;
   BnP bn;
@@ -223,7 +223,8 @@ const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
   if (!wt) return "MFMA-tiled codes `wt` not given";
   if (in_type != SNNQP_BITS) return "input must be bit-packed";
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
-  if (K & 31) return "K must be a multiple of 32";
+  (void)K;   // any K: the tiles `wt` are zero-padded to ceil(K / 32) k-steps and the packed
+             // input rows carry zero bits beyond K
   if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
   return nullptr;
 }
@@ -246,7 +247,7 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   SNNQP_REQUIRE(T <= 160, SNNQP_EUNSUPPORTED, "dense mfma: T > 160");
   DenseMfmaArgs a;
   a.x = (const uint32_t *)x; a.xs_t = xs_t; a.xs_b = xs_b;
-  a.T = T; a.B = B; a.K = K; a.N = N; a.KS = K / 32;
+  a.T = T; a.B = B; a.K = K; a.N = N; a.KS = (K + 31) / 32;
   a.wt = wt;
   a.dq = make_dequant(w->L, w->m);
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);

@@ -100,7 +100,14 @@ class PackedKernel:
       if row_perm is not None:
         codes = codes.index_select(0, row_perm)
       codes = codes.contiguous()
-      wt = ops.pack_codes_mfma(codes, n_pad) if codes.shape[0] % 32 == 0 else None
+      if self.kernel.ndim == 2 and codes.shape[0] % 32:
+        # dense layers: zero rows up to a multiple of 32 (the packed input rows carry
+        # zero bits there), so K = 784 etc. stay on the MFMA kernel
+        pad = 32 - codes.shape[0] % 32
+        tiles_src = torch.cat([codes, codes.new_zeros((pad, codes.shape[1]))], 0)
+      else:
+        tiles_src = codes
+      wt = ops.pack_codes_mfma(tiles_src, n_pad) if tiles_src.shape[0] % 32 == 0 else None
       w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max,
                      code_max=base.code_max)
       self._wt[key] = w

@@ -354,6 +354,29 @@ def test_dense_block_long_T_falls_back(dev, oracle):
   np.testing.assert_array_equal(_np(u), eu)
 
 
+def test_dense_block_k_not_multiple_of_32(dev, oracle):
+  """K = 784 (a flattened 28x28 image) and other sizes that are not multiples of 32: the
+  codes are tiled with zero rows up to the next k-step, the block stays on the MFMA kernel."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(78))
+  for K, N in ((784, 100), (50, 33)):
+    T, B = 6, 5
+    std = 8.0 / np.sqrt(K)
+    leaf = {"kernel": (rng.standard_normal((K, N)) * std).astype(F32),
+            "DuQ_0": {"a": F32([3 * std]), "c": F32([3 * std])},
+            "prune_0": {"mask": (rng.random((K, N)) > 0.5).astype(F32)}}
+    x = (rng.random((T, B, K)) < 0.2).astype(np.uint8)
+    w = _weight(leaf, 4, dev, transposed=True)
+    assert w.wt is not None and w.wt.shape[1] == (K + 31) // 32
+    u, s = ops.dense_lif_forward(ops.pack_bits(_t(x, dev)), w, K, N, _mslif(), packed_out=True,
+                                 impl=L.IMPL_MFMA)
+    eu, es = oracle.dense_block(x, qweight_of(oracle, leaf, 4), None, "int")
+    assert es.mean() > 0.01
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(u), eu)
+
+
 def test_dense_block_fseq_path(dev, oracle, golden_dir):
   """Unquantised float32 weights, real-valued input: k-ascending fmaf chain,
   bit-exact vs the oracle's fseq mode and within 1e-5 relative of float64."""
