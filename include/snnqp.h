@@ -187,7 +187,7 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       [T][B][OH/pool][OW/pool][Cout].
  * impl  SNNQP_IMPL_GENERIC: direct form, any geometry / types.
  *       SNNQP_IMPL_MFMA: int8 MFMA implicit GEMM; needs W_I8, 3x3 / stride 1 /
- *       pad 1 / no dilation / groups 1, Cout % 32 == 0 and
+ *       pad 1 / no dilation / groups 1 and
  *       (BITS input with Cin == 128 and `wt` = the codes tiled by
  *       snnqp_pack_codes_mfma (K = 9 * Cin), or U8 input with Cin == 2, any
  *       count 0..255), s_type BITS.  SNNQP_IMPL_AUTO picks MFMA when it can.

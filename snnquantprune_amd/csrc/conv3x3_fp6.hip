@@ -114,6 +114,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   const int cout_base = blockIdx.y * 128 + cg * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
+  const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
+  const uint32_t cmask = chan_mask(cout_base, a.Cout);
 
   // tables: byte -> 8 nibbles (bit i set -> 1.0 = 0x2 in nibble i); dequant table
   if (tid < 256) {
@@ -142,8 +144,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   }
 
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
-  if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
-  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cout];
+  if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
+  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
   // table mode: spikes count 4 (block scale 2^2 on A) and the chain starts from the
   // address of the entry of acc = 0, so the f32 accumulator is the table address
@@ -321,14 +323,14 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
         asm volatile("" : "+v"(accN), "+v"(x), "+v"(uu), "+v"(w), "+s"(m0), "+s"(m1));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w;
+      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
     };
     auto epilogue = [&](const v16f &acc, int t) {
       v2f y[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = dequant2(acc[2 * j], acc[2 * j + 1]);
       const uint32_t w = tile_neurons<NF, POOL, false>(y, u, lc, a.nrn);
-      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w;
+      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
     };
     // staging of halo(t2) into its buffer around a step: the table reads go first, the
     // word of halo(t2 + 1) is requested as soon as its register is free, the LDS

@@ -96,6 +96,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
+  const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
+  const uint32_t cmask = chan_mask(cout_base, a.Cout);
   if (LUTM == LUT_SHARED) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid);
   // start value of every accumulator chain: the address of the entry of acc = 0
   const v16i cb = splat16(LUTM == LUT_SHARED ? (int)lds_addr(lds) + LUT_OFF + 4 * a.lut_bound : 0);
@@ -113,8 +115,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   }
 
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
-  if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
-  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cout];
+  if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
+  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
   const int tx = (n & 3) | (((n >> 3) & 1) << 2);
@@ -274,8 +276,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       }
       if (store_lane) {
         uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
-        o[ob0] = w0;
-        o[ob1] = w1;
+        o[ob0] = w0 & cmask;
+        o[ob1] = w1 & cmask;
       }
     };
     auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
@@ -283,8 +285,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       const uint32_t w1 = tile_epilogue<NF, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane);
       if (store_lane) {
         uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
-        o[ob0] = w0;
-        o[ob1] = w1;
+        o[ob0] = w0 & cmask;
+        o[ob1] = w1 & cmask;
       }
     };
     // call right after the barrier that follows epilogue(t)
@@ -384,6 +386,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
   const int cout = wave_on ? cout_base + n : n;
+  const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
+  const uint32_t cmask = chan_mask(cout_base, a.Cout);
   // smallest non-zero |input current| of this workgroup's channels (per-channel tables
   // only): decides whether the membrane update may be one fused multiply-add
   uint32_t *wgmin = obuf + OutStage<POOL>::BYTES / 4;
@@ -430,7 +434,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         uint32_t bv = 0;
         if (k < 24) {
           const int dy = k >> 3, b = k & 7;
-          if (b < 6 && wave_on) {    // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
+          if (b < 6 && cout < a.Cout) {   // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
             const int code = a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
             wsum += code;
             bv = (uint8_t)(LUTM == LUT_CHANNEL ? code * 8 : code);   // see build_lut_channel
@@ -452,8 +456,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   }
 
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
-  if (a.bn.mean) { lc.bmean = a.bn.mean[cout]; lc.bmul = a.bn.mul[cout]; lc.bbias = a.bn.bias[cout]; }
-  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cout];
+  if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
+  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
   const int tx = (n & 3) | (((n >> 3) & 1) << 2);
@@ -540,8 +544,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
           }
           if (store_lane) {
             uint32_t *o = obuf + ((t0 + tt) % FL) * (OutStage<POOL>::NPIX * 4);
-            o[ob0] = words[0];
-            o[ob1] = words[1];
+            o[ob0] = words[0] & cmask;
+            o[ob1] = words[1] & cmask;
           }
         }
         PHASE_MARK(1)
@@ -580,7 +584,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
     return "dilated convolution";
   if (g->groups != 1) return "grouped convolution";
   if (g->H <= 0 || g->W <= 0) return "empty image";    // any size: edge patches are clipped
-  if (g->Cout & 31) return "Cout must be a multiple of 32";
+  if (g->Cout <= 0) return "no output channels";    // any count: the last word is masked
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
   if (in_type == SNNQP_BITS) {
     const bool fp6 = w->code_max > 0 && w->code_max <= 7;     // conv3x3_fp6.hip: Cin 64 / 128

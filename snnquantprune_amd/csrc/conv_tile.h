@@ -155,6 +155,14 @@ struct LaneConsts {
   float vr;      // v_reset (a VGPR operand of the reset select when it is not 0)
 };
 
+// Output-channel block of a wave when Cout is not a multiple of 32: `cout` is the real
+// channel (u_io skips lanes beyond Cout), `cpar` a clamped index for the per-channel
+// parameter loads, `cmask` the bits of the block's spike word that exist.
+__device__ __forceinline__ uint32_t chan_mask(int cout_base, int Cout) {
+  const int valid = Cout - cout_base;
+  return valid >= 32 ? 0xFFFFFFFFu : valid <= 0 ? 0u : (1u << valid) - 1u;
+}
+
 // The neuron update forms of spiking_learning.py, one straight-line epilogue each
 // (template parameter NF of the conv kernels):
 //   NF_MUL0   u += (x - u) * m, reset to 0        multi_step_LIF with tau = 2^j (m = 1/tau,
@@ -375,7 +383,7 @@ __device__ __forceinline__ void flush_ring(const uint32_t *obuf, const ConvMfmaA
                                            int t0, int n, int b, int y0, int x0, int tid) {
   constexpr int NPIX = OutStage<POOL>::NPIX;
   constexpr int PW = POOL ? 4 : 8;              // patch width in output pixels
-  const int CW = a.Cout >> 5;
+  const int CW = (a.Cout + 31) >> 5;
   const int cwb = blockIdx.y * 4;
   const int nw = min(4, CW - cwb);
   const int OH = POOL ? a.H >> 1 : a.H, OW = POOL ? a.W >> 1 : a.W;
@@ -412,7 +420,7 @@ __device__ __forceinline__ void u_io_tile(float (&u)[16], const ConvMfmaArgs &a,
     const int y = y0 + tl * 4 + (h | ((i >> 3) << 1));
     const int x = x0 + (i & 7);
     const int64_t o = (((int64_t)b * a.H + y) * a.W + x) * a.Cout + cout;
-    const bool in = y < a.H && x < a.W;
+    const bool in = y < a.H && x < a.W && cout < a.Cout;
     if (LOAD) u[i] = in ? ui[o] : 0.0f;
     else if (in) uo[o] = u[i];
   }
@@ -430,7 +438,7 @@ __device__ __forceinline__ void u_io(float (&u)[2][16], const ConvMfmaArgs &a,
       const int y = y0 + tl * 4 + (h | ((i >> 3) << 1));
       const int x = x0 + (i & 7);
       const int64_t o = (((int64_t)b * a.H + y) * a.W + x) * a.Cout + cout;
-      const bool in = y < a.H && x < a.W;
+      const bool in = y < a.H && x < a.W && cout < a.Cout;
       if (LOAD) u[tl][i] = in ? ui[o] : 0.0f;
       else if (in) uo[o] = u[tl][i];
     }

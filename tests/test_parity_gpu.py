@@ -834,6 +834,37 @@ def test_conv_block_any_image_size(dev, oracle, shape):
   np.testing.assert_array_equal(_np(u2), eu)
 
 
+@pytest.mark.parametrize("cin", [128, 64, 2])
+@pytest.mark.parametrize("cout", [100, 40, 200])
+def test_conv_block_any_output_channel_count(dev, oracle, cin, cout):
+  """Cout that is not a multiple of 32 (config.channels = 100, ...): the last spike word
+  of a pixel is masked, per-channel parameters clamped, potentials of the channels that do
+  not exist neither read nor written."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  hw = 8 if cin > 2 else 16
+  c = cases.conv_block_case(T=4, B=3, hw=hw, cin=cin, cout=cout, seed=1801,
+                            gain=5.0 if cin > 2 else 4.0)
+  if cin == 2:
+    c["x"] = np.minimum(c["x"], 1).astype(np.uint8)
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  geom = ops.ConvGeom(hw, hw, cin, cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xt = _t(c["x"], dev)
+  xin = xt if cin == 2 else ops.pack_bits(xt)
+  for pool, key in ((1, "s_bits"), (2, "pooled_bits")):
+    u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                pool=pool, impl=L.IMPL_MFMA, x_max=1)
+    np.testing.assert_array_equal(_np(s), e[key])
+    np.testing.assert_array_equal(_np(u), e["u"])
+  u1, s1 = ops.conv_lif_forward(xin[:2], geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                                impl=L.IMPL_MFMA, x_max=1)
+  u2, s2 = ops.conv_lif_forward(xin[2:], geom, w, _mslif(), bn=_bn(c["bn"], dev), u0=u1,
+                                packed_out=True, impl=L.IMPL_MFMA, x_max=1)
+  np.testing.assert_array_equal(np.concatenate([_np(s1), _np(s2)]), e["s_bits"])
+  np.testing.assert_array_equal(_np(u2), e["u"])
+
+
 @pytest.mark.parametrize("cout", [64, 128, 160])
 def test_conv_block_64_input_channels(dev, oracle, cout):
   """Blocks of 64 input channels (config.channels = 64) run on the fp6 MFMA kernel too
