@@ -186,11 +186,12 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  * s_out spikes, type s_type (SNNQP_F32: 0.0/1.0, or SNNQP_BITS),
  *       [T][B][OH/pool][OW/pool][Cout].
  * impl  SNNQP_IMPL_GENERIC: direct form, any geometry / types.
- *       SNNQP_IMPL_MFMA: int8 MFMA implicit GEMM; needs W_I8, 3x3 / stride 1 /
- *       pad 1 / no dilation / groups 1 and
- *       (BITS input with Cin == 128 and `wt` = the codes tiled by
- *       snnqp_pack_codes_mfma (K = 9 * Cin), or U8 input with Cin == 2, any
- *       count 0..255), s_type BITS.  SNNQP_IMPL_AUTO picks MFMA when it can.
+ *       SNNQP_IMPL_MFMA: MFMA implicit GEMM (fp6 codes x fp4 spikes when
+ *       code_max <= 7, else int8); needs W_I8, 3x3 / stride 1 / pad 1 / no
+ *       dilation / groups 1 and (BITS input with Cin == 128 -- or 64 when
+ *       code_max <= 7 -- and `wt` = the codes tiled by snnqp_pack_codes_mfma
+ *       (K = 9 * Cin), or U8 input with Cin == 2, any count 0..255), s_type BITS;
+ *       any H, W, Cout and neuron kind.  SNNQP_IMPL_AUTO picks MFMA when it can.
  * x_max an upper bound of the input values if known (1 for spikes), else 0: with
  *       weights' abs_sum_max it bounds |acc| and lets the MFMA kernels dequantise
  *       through an LDS table instead of arithmetic. */
