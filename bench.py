@@ -75,13 +75,84 @@ def cpu_baseline(args, variables_np):
   n = max(1, args.cpu_samples)
   x = syn.poisson_spikes((n, args.frames, 128, 128, 2), args.lam, seed=4242).astype(np.float32)
   o.conv3_dense_forward(x[:1, :2], cq, bns, dq, mode="float")      # warm-up, discarded
-  t0 = time.perf_counter()
-  o.conv3_dense_forward(x, cq, bns, dq, mode="float")
-  dt = time.perf_counter() - t0
   cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-  return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
-          "sample": "%d samples of the same C3 workload (T=%d, 128x128x2), oracle float "
-                    "mode, numpy/BLAS threads = host cores, %.1f s" % (n, args.frames, dt)}
+  cpu = "unknown"
+  try:
+    with open("/proc/cpuinfo") as f:
+      for line in f:
+        if line.startswith("model name"):
+          cpu = line.split(":", 1)[1].strip()
+          break
+  except OSError:
+    pass
+
+  def timed(xs):
+    t0 = time.perf_counter()
+    o.conv3_dense_forward(xs, cq, bns, dq, mode="float")
+    return time.perf_counter() - t0
+
+  # numpy/BLAS thread count: all host cores is not the fastest setting for these matrix
+  # sizes, so the sample is timed at several and the best is the baseline (SURVEY 8d asks
+  # for n = 1 and n = all cores; both are in `by_threads`)
+  by_threads = {}
+  try:
+    from threadpoolctl import threadpool_limits
+    for nthreads in sorted({1, 8, 32, int(cores)}):
+      if nthreads > cores:
+        continue
+      with threadpool_limits(limits=nthreads):
+        k = n if nthreads > 1 else min(n, 2)
+        dt = timed(x[:k])
+      by_threads[nthreads] = {"value": k / dt, "samples": k, "seconds": round(dt, 2)}
+  except ImportError:
+    dt = timed(x)
+    by_threads[int(cores)] = {"value": n / dt, "samples": n, "seconds": round(dt, 2)}
+  best = max(by_threads, key=lambda t: by_threads[t]["value"])
+  out = {"value": by_threads[best]["value"], "unit": "samples/s", "cores": int(best),
+         "kind": "port", "cpu": cpu, "host_cores": int(cores),
+         "sample": "%d samples of the same C3 workload (T=%d, 128x128x2), oracle float mode "
+                   "(dense float32 fake-quantised weights, BLAS matmul on im2col), best of the "
+                   "BLAS thread counts tried" % (by_threads[best]["samples"], args.frames),
+         "by_threads": {str(k): v for k, v in sorted(by_threads.items())}}
+  # the batch is embarrassingly parallel: W single-threaded worker processes, one slice of
+  # samples each (fresh interpreters that never touch the GPU), W = the box's CPU share
+  try:
+    import subprocess, tempfile
+    W = int(min(16, cores))
+    per = 12                     # ~6-8 s of CPU work per worker
+    payload = {"bits": np.int32(args.bits),
+               "x": syn.poisson_spikes((W * per, args.frames, 128, 128, 2), args.lam,
+                                       seed=4243).astype(np.uint8)}
+    for name, leaf in [("conv%d" % i, p["QuantConv_%d" % i]) for i in range(3)] + \
+                      [("dense", p["QuantDense_0"])]:
+      payload[name + "_kernel"] = leaf["kernel"]
+      payload[name + "_a"] = np.float32(leaf["DuQ_0"]["a"][0])
+      payload[name + "_c"] = np.float32(leaf["DuQ_0"]["c"][0])
+      if "prune_0" in leaf:
+        payload[name + "_mask"] = leaf["prune_0"]["mask"]
+    for i in range(3):
+      for k, v in bn_of(variables_np, i).items():
+        payload["bn%d_%s" % (i, k)] = v
+    with tempfile.TemporaryDirectory() as tmp:
+      path = os.path.join(tmp, "payload.npz")
+      np.savez(path, **payload)
+      env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+      procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", path,
+                                 str(i * per), str((i + 1) * per)], stdout=subprocess.PIPE,
+                                env=env, cwd=ROOT) for i in range(W)]
+      res = [json.loads(pr.communicate(timeout=300)[0].decode().strip().splitlines()[-1])
+             for pr in procs]
+    secs = max(r["seconds"] for r in res)
+    nproc = sum(r["samples"] for r in res)
+    out["by_processes"] = {"workers": W, "samples": nproc, "seconds": round(secs, 2),
+                           "value": nproc / secs}
+    if nproc / secs > out["value"]:
+      out.update(value=nproc / secs, cores=W,
+                 sample="%d samples of the same C3 workload (T=%d, 128x128x2), oracle float mode, "
+                        "%d single-threaded worker processes" % (nproc, args.frames, W))
+  except Exception as e:          # no subprocesses on this box: keep the in-process figure
+    out["by_processes"] = {"value": None, "note": "not measured: %s" % type(e).__name__}
+  return out
 
 
 def main():
