@@ -191,7 +191,7 @@ def main():
 
   def fence():
     if world > 1:
-      torch.distributed.barrier()
+      torch.distributed.barrier(device_ids=[local])
     torch.cuda.synchronize()
 
   for _ in range(args.warmup):
@@ -301,8 +301,10 @@ def main():
       "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-      "dtype": "conv0/dense: int8 codes x u8/binary -> int32 (i8 MFMA); conv1-2: fp6 codes x "
-               "fp4 spikes -> f32 exact integers (f8f6f4 MFMA); f32 membrane",
+      "dtype": "int8",
+      "dtype_detail": "integer codes x integer inputs, exact sums: conv0/dense int8 x u8/binary -> "
+                      "int32 (i8 MFMA); conv1-2 the same integers as fp6 codes x fp4 spikes -> f32 "
+                      "(f8f6f4 MFMA, sums < 2^24 exact); membrane potentials f32",
       "data": "synthetic Poisson(%g)>0 spikes, N(0,1/fan_in) weights, random seeds fixed" % args.lam,
       "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
                               "qdense(2048->512->110) + vote, " if args.model == "cextnet" else
@@ -322,4 +324,8 @@ def main():
 
 
 if __name__ == "__main__":
-  main()
+  try:
+    main()
+  finally:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+      torch.distributed.destroy_process_group()

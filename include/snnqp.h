@@ -188,9 +188,11 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  * impl  SNNQP_IMPL_GENERIC: direct form, any geometry / types.
  *       SNNQP_IMPL_MFMA: MFMA implicit GEMM (fp6 codes x fp4 spikes when
  *       code_max <= 7, else int8); needs W_I8, 3x3 / stride 1 / pad 1 / no
- *       dilation / groups 1 and (BITS input with Cin == 128 -- or 64 when
- *       code_max <= 7 -- and `wt` = the codes tiled by snnqp_pack_codes_mfma
- *       (K = 9 * Cin), or U8 input with Cin == 2, any count 0..255), s_type BITS;
+ *       dilation / groups 1 and (BITS input with Cin <= 128 and `wt` = the codes
+ *       of the kernel zero-padded along Cin to Cpad = 64 (Cin <= 64) or 128,
+ *       tiled by snnqp_pack_codes_mfma with K = 9 * Cpad (row = tap * Cpad + cin);
+ *       a pixel keeps its ceil(Cin / 32) spike words, zero bits beyond Cin --
+ *       or U8 input with Cin == 2, any count 0..255), s_type BITS;
  *       any H, W, Cout and neuron kind.  SNNQP_IMPL_AUTO picks MFMA when it can.
  * x_max an upper bound of the input values if known (1 for spikes), else 0: with
  *       weights' abs_sum_max it bounds |acc| and lets the MFMA kernels dequantise

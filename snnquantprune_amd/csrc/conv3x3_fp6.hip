@@ -102,6 +102,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   constexpr int TAB_OFF = 2 * F6_HALO;
   constexpr int LUT_OFF = TAB_OFF + F6_TAB;
   constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
+  constexpr int LUT_ZERO = LUT_OFF + 4 * LUT_CAP;
   constexpr int OB_OFF = LUT_OFF + LUT_BYTES;
   __shared__ __attribute__((aligned(16))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16];
   uint32_t *obuf = (uint32_t *)(lds + OB_OFF);
@@ -124,7 +125,10 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     for (int bit = 0; bit < 8; ++bit) v |= ((tid >> bit) & 1) ? (0x2u << (4 * bit)) : 0u;
     ((uint32_t *)(lds + TAB_OFF))[tid] = v;
   }
-  if (LUT) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid, 512);
+  // the entry of acc = 0 sits at the fixed byte LUT_ZERO whatever the launch's bound is,
+  // so the table read takes the (signed) accumulator as its address register and
+  // LUT_ZERO as the instruction's immediate offset
+  if (LUT) build_lut((float *)(lds + LUT_OFF) + (LUT_CAP - a.lut_bound), a.lut_bound, a.dq, tid, 512);
 
   // B operand: k-step ks = NP tap + kk covers channels 64 kk .. +63 of the tap; lane
   // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile WPP tap + 2 kk + h
@@ -147,9 +151,9 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
   if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
-  // table mode: spikes count 4 (block scale 2^2 on A) and the chain starts from the
-  // address of the entry of acc = 0, so the f32 accumulator is the table address
-  const float c0 = LUT ? (float)(lds0 + LUT_OFF + 4 * a.lut_bound) : 0.0f;
+  // table mode: spikes count 4 (block scale 2^2 on A), so the f32 accumulator is the
+  // byte offset of its table entry from the entry of acc = 0.  The chain starts from
+  // the inline constant 0: no accumulator preload in either mode.
   constexpr int SCALE_A = LUT ? 129 : 127;       // E8M0: 2^(s - 127)
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
@@ -165,6 +169,9 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   // staging task of this thread: word wi of halo pixel pix
   const int s_pix = tid / WPP, s_wi = tid % WPP;
   const bool s_task = tid < HALO * HALO * WPP;
+  // a pixel has ceil(Cin / 32) spike words in memory; the planes beyond them (Cin below
+  // the template's 64 / 128) are zero spikes against zero codes
+  const int wpm = (a.Cin + 31) >> 5;
   const int s_hy = s_pix / HALO, s_hx = s_pix % HALO;
   uint8_t *s_dst = lds + (s_wi >> 1) * F6_PLANE + (s_hy * F6_PITCH + s_hx) * 32 +
                    (((s_wi & 1) ^ (s_hy & 1)) * 16);
@@ -193,8 +200,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     }
 
     const int gy = y0 + s_hy - 1, gx = x0 + s_hx - 1;
-    const bool s_valid = s_task && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * WPP + s_wi;
+    const bool s_valid = s_task && s_wi < wpm && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * wpm + s_wi;
     uint32_t stg = 0;
     auto stage_load = [&](int t) {
       stg = s_valid ? xb[(int64_t)t * a.xs_t + s_goff] : 0u;
@@ -202,10 +209,11 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     v4i s_exp = {0, 0, 0, 0};
     auto stage_expand = [&]() {                  // table reads; consumed by stage_write
       if (s_task) {
-        s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg << 2) & 0x3FCu));
-        s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 6) & 0x3FCu));
-        s_exp.z = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 14) & 0x3FCu));
-        s_exp.w = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((stg >> 22) & 0x3FCu));
+        const uint32_t sw = stg;
+        s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw << 2) & 0x3FCu));
+        s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 6) & 0x3FCu));
+        s_exp.z = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 14) & 0x3FCu));
+        s_exp.w = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 22) & 0x3FCu));
       }
     };
     auto stage_write = [&](int buf) {
@@ -224,13 +232,22 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
           v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, acc,
           4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
     };
-    auto splat_c0 = [&]() -> v16f {              // 16 v_mov per step, not 16 live registers
-      float c = c0;
-      asm volatile("" : "+v"(c));
-      return v16f{c, c, c, c, c, c, c, c, c, c, c, c, c, c, c, c};
+    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the first MFMA of a chain takes C = 0 (an inline constant of the instruction)
+    auto mfma_first = [&](const v4i &av, v16f &acc) {
+      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+          v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
+          v8i{bf[0][0], bf[0][1], bf[0][2], bf[0][3], bf[0][4], bf[0][5], 0, 0}, zero16,
+          4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+    };
+    // table entry of the accumulator value a4 = 4 acc: address register = (int)a4, which
+    // is negative for negative sums; the LDS address adder wraps, so base + LUT_ZERO is
+    // the entry (the compiler folds LUT_ZERO into the offset field: ds_read_b32 ... offset:)
+    auto lut_read = [&](float a4) -> float {
+      return *(lds_cfloat_t *)((lds_cu8_t *)lds + LUT_ZERO + (int)a4);
     };
     auto dequant2 = [&](float a0, float a1) -> v2f {
-      if (LUT) return v2f{lds_read_f32((uint32_t)a0), lds_read_f32((uint32_t)a1)};
+      if (LUT) return v2f{lut_read(a0), lut_read(a1)};
       const v2f af = {a0, a1};       // exact integers: the same division sequence
       v2f q = af * a.dq.rL;
       const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
@@ -242,12 +259,12 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-      acc = splat_c0();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < F6_KS; ++ks) {
         if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
-        mfma_one(ks, A[ks % (PF + 1)], acc);
+        if (ks == 0) mfma_first(A[0], acc);
+        else mfma_one(ks, A[ks % (PF + 1)], acc);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -267,7 +284,6 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-      accN = splat_c0();
       constexpr int YD = SNNQP_F6_YDIST;         // pairs the table reads run ahead
       v2f y[YD + 1], x = {0.f, 0.f}, uu = {0.f, 0.f};
       unsigned long long m0 = 0, m1 = 0;
@@ -284,7 +300,11 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
           x = x * lc.bmul;
           x = x + lc.bbias;
         } else if (q == 2) {       // membrane update of the neuron form (conv_tile.h)
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 32)   // diagnostic build: FMA membrane update
+          uu = neuron_update<NF, true>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
+#else
           uu = neuron_update<NF>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
+#endif
           m0 = __ballot(uu.x >= a.nrn.vth);
           m1 = __ballot(uu.y >= a.nrn.vth);
         } else {
@@ -305,11 +325,19 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       };
 #pragma unroll
       for (int ks = 0; ks < F6_KS; ++ks) {
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 32)   // diagnostic build: half of the A reads
+        if (ks + PF < F6_KS) {
+          if ((ks & 1) == 0) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
+          else A[(ks + PF) % (PF + 1)] = A[(ks + PF - 1) % (PF + 1)];
+        }
+#else
         if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
+#endif
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1)   // diagnostic build: 2 of 18 MFMAs
         if (ks < 2)
 #endif
-        mfma_one(ks, A[ks % (PF + 1)], accN);
+        if (ks == 0) mfma_first(A[0], accN);
+        else mfma_one(ks, A[ks % (PF + 1)], accN);
 #if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 2))   // diagnostic build: no epilogue
 #pragma unroll
         for (int q = 0; q < PPS; ++q)
@@ -333,7 +361,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
     };
     // staging of halo(t2) into its buffer around a step: the table reads go first, the
-    // word of halo(t2 + 1) is requested as soon as its register is free, the LDS
+    // word of halo(t2 + 1) is requested as soon as its register is free (one step ahead is
+    // enough: two steps ahead measured the same), the LDS
     // write comes after the step's MFMAs
     auto stage_begin = [&](int t2) {
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
@@ -416,7 +445,7 @@ static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, u
 
 void launch_conv3x3_fp6(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
                         hipStream_t st) {
-  if (a.Cin == 64) launch_fp6_cin<64>(a, nf, pool, lut, gy, st);
+  if (a.Cin <= 64) launch_fp6_cin<64>(a, nf, pool, lut, gy, st);
   else launch_fp6_cin<128>(a, nf, pool, lut, gy, st);
 }
 

@@ -2,7 +2,7 @@
 // DVS128 topology (examples/tcja/models.py:111-147): implicit-GEMM int8 MFMA
 // (v_mfma_i32_32x32x32_i8) + dequantisation + eval BatchNorm + neuron update +
 // optional 2x2 max-pool, with the T loop inside the kernel.  Two kernels:
-//   conv3x3_bits_kernel  bit-packed input, Cin = 128, any int8 codes and neuron kind
+//   conv3x3_bits_kernel  bit-packed input, Cin <= 128, any int8 codes and neuron kind
 //                        (codes of magnitude <= 7 go to conv3x3_fp6.hip instead)
 //   conv3x3_u8c2_kernel  uint8 event counts, Cin = 2 (the first layer)
 //
@@ -76,12 +76,13 @@ extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
 // ---------------------------------------------------------------------------
 // Bit-packed input, Cin = 128.
 // ---------------------------------------------------------------------------
-template <int NF, bool POOL, int LUTM>
-__global__ void __launch_bounds__(256, 1)
-conv3x3_bits_kernel(ConvMfmaArgs a) {
+template <int NF, bool POOL, int LUTM, int CIN>
+__device__ __forceinline__ void conv3x3_bits_body(const ConvMfmaArgs &a) {
   static_assert(LUTM != LUT_CHANNEL, "per-channel tables of K = 1152 do not fit LDS");
-  constexpr int CIN = 128;
+  static_assert(CIN == 64 || CIN == 128, "two or four 32-channel planes");
   constexpr int KK = CIN / 32;
+  constexpr int NSLOT = 18 * KK;                 // MFMAs of one step (9 taps x KK x 2 tiles)
+  constexpr int PPS = (64 + NSLOT - 1) / NSLOT;  // epilogue pieces per MFMA slot
   constexpr int NTASK = HALO * HALO * KK;        // (pixel, word) staging tasks
   constexpr int TPT = (NTASK + 255) / 256;       // tasks per thread
   constexpr int LUT_BYTES = LutBytes<LUTM>::value;
@@ -130,6 +131,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
            ((tap / 3 + 4 * tl) * HPITCH + tap % 3) * 32;
   };
   const uint32_t *xb = (const uint32_t *)a.x;
+  // a pixel has ceil(Cin / 32) spike words in memory; planes beyond them stay zero
+  const int wpm = (a.Cin + 31) >> 5;
   // LDS word index of this lane's spike word (tile 0 / 1) inside one obuf slot
   const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
   const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
@@ -154,9 +157,9 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         if (task < NTASK) {
           const int pix = task / KK, wi = task % KK;
           const int gy = y0 + pix / HALO - 1, gx = x0 + pix % HALO - 1;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+          if (wi < wpm && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
             wv = xb[(int64_t)t * a.xs_t + (int64_t)b * a.xs_b +
-                    ((int64_t)gy * a.W + gx) * KK + wi];
+                    ((int64_t)gy * a.W + gx) * wpm + wi];
         }
         stg[k] = wv;
       }
@@ -200,9 +203,9 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         }
       }
     };
-    // One pipelined step in a hand-placed order: 72 issue slots, each = one MFMA
-    // of step t+1, one A-fragment read for the next tap, and one quarter of a
-    // neuron pair of step t's epilogue (16 pairs x 4 pieces = 64 slots), fenced
+    // One pipelined step in a hand-placed order: 72 issue slots (36 at Cin <= 64), each =
+    // one MFMA of step t+1, one A-fragment read for the next tap, and one (two) quarter(s)
+    // of a neuron pair of step t's epilogue (16 pairs x 4 pieces = 64 pieces), fenced
     // with sched_barrier so the order survives.  An in-order wave overlaps the
     // matrix pipe and the VALU only when their instructions alternate; left to
     // itself the scheduler emits bursts of MFMAs and bursts of VALU (measured:
@@ -232,17 +235,29 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       piece1(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int slot = 0; slot < 72; ++slot) {
-        const int tap = slot >> 3, m = slot & 7, kk = m >> 1, tl = m & 1;
+      for (int slot = 0; slot < NSLOT; ++slot) {
+        const int tap = slot / (2 * KK), m = slot % (2 * KK), kk = m >> 1, tl = m & 1;
         // A fragment for the same position of the next tap
         if (tap + 1 < 9)
           A[(tap + 1) & 1][m] = *(const v4i *)(base + aoff(tap + 1, kk, tl));
-        if (tl == 0)
-          accN0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN0, 0, 0, 0);
-        else
-          accN1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN1, 0, 0, 0);
-        if (slot < 64) {
-          const int j = slot >> 2, piece = slot & 3;
+#if defined(SNNQP_BITS_ABL) && (SNNQP_BITS_ABL & 1)   // diagnostic build: 2 of 72 MFMAs
+        if (slot < 2) {
+#else
+        {
+#endif
+          if (tl == 0)
+            accN0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN0, 0, 0, 0);
+          else
+            accN1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PPS; ++q) {
+          const int pc = slot * PPS + q;
+#if defined(SNNQP_BITS_ABL) && (SNNQP_BITS_ABL & 2)   // diagnostic build: no epilogue
+          if (true) continue;
+#endif
+          if (pc >= 64) continue;
+          const int j = pc >> 2, piece = pc & 3;
           float *up = (j < 8) ? &u[0][(j & 7) * 2] : &u[1][(j & 7) * 2];
           if (piece == 0) {
             if (j + 1 < 16) piece1(j + 1);
@@ -338,6 +353,18 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
   }
   PROBE_END()
+}
+
+template <int NF, bool POOL, int LUTM>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_bits_kernel(ConvMfmaArgs a) {            // 64 < Cin <= 128
+  conv3x3_bits_body<NF, POOL, LUTM, 128>(a);
+}
+
+template <int NF, bool POOL, int LUTM>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_bits64_kernel(ConvMfmaArgs a) {          // Cin <= 64: half the k-steps
+  conv3x3_bits_body<NF, POOL, LUTM, 64>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -587,8 +614,9 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   if (g->Cout <= 0) return "no output channels";    // any count: the last word is masked
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
   if (in_type == SNNQP_BITS) {
-    const bool fp6 = w->code_max > 0 && w->code_max <= 7;     // conv3x3_fp6.hip: Cin 64 / 128
-    if (g->Cin != 128 && !(fp6 && g->Cin == 64)) return "bit input needs Cin == 128 (or 64 with codes <= 7)";
+    // any width up to 128: `wt` is tiled from the kernel zero-padded along Cin to 64
+    // (Cin <= 64) or 128; the spike words beyond ceil(Cin / 32) are not read
+    if (g->Cin < 1 || g->Cin > 128) return "bit input needs Cin <= 128";
   } else if (in_type == SNNQP_U8) {     // any count 0..255 (taken as x - 128 without a table)
     if (g->Cin != 2) return "u8 input needs Cin == 2";
   } else {
@@ -655,8 +683,13 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   if (in_type == SNNQP_BITS && w->code_max > 0 && w->code_max <= 7) {
     launch_conv3x3_fp6(a, nf, pl, lut, gy, st);  // codes exact in fp6: f8f6f4 MFMA
   } else if (in_type == SNNQP_BITS) {
-    if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED, 0);
-    else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE, 0);
+    if (g->Cin <= 64) {
+      if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits64_kernel, LUT_SHARED, 0);
+      else SNNQP_CONV_LAUNCH(conv3x3_bits64_kernel, LUT_NONE, 0);
+    } else {
+      if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED, 0);
+      else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE, 0);
+    }
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
     const size_t ldsb = lds_fixed + u8c2_table_bytes(lm, a.lut_bound);

@@ -105,6 +105,16 @@ class PackedKernel:
         # zero bits there), so K = 784 etc. stay on the MFMA kernel
         pad = 32 - codes.shape[0] % 32
         tiles_src = torch.cat([codes, codes.new_zeros((pad, codes.shape[1]))], 0)
+      elif (self.kernel.ndim == 4 and row_perm is None and 2 < base.w.shape[2] <= 128
+            and base.w.shape[2] not in (64, 128)):
+        # convolution over bit-packed spikes: the MFMA kernels walk 64 or 128 input
+        # channels per tap; other widths (config.channels = 100, 96, 48 ...) get zero
+        # codes up to the next of the two (the spike words carry zero bits there)
+        kh, kw, ci, co = base.w.shape
+        cpad = 64 if ci <= 64 else 128          # snnqp.h: `wt` of a conv block
+        padded = base.w.new_zeros((kh, kw, cpad, co))
+        padded[:, :, :ci] = base.w
+        tiles_src = padded.reshape(-1, co)
       else:
         tiles_src = codes
       wt = ops.pack_codes_mfma(tiles_src, n_pad) if tiles_src.shape[0] % 32 == 0 else None

@@ -890,12 +890,40 @@ def test_conv_block_64_input_channels(dev, oracle, cout):
   _, sp = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
                                pool=2, impl=L.IMPL_MFMA, want_u=False, x_max=1)
   np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
-  with pytest.raises(L.SnnqpError):       # int8 MFMA kernel is Cin = 128 only
-    ops.conv_lif_forward(xin, geom, dataclasses.replace(w, code_max=0), _mslif(),
-                         packed_out=True, impl=L.IMPL_MFMA)
+  # the same codes through the int8 MFMA kernel (what wider codes take): two 32-channel
+  # planes per tap at Cin <= 64
   u, s = ops.conv_lif_forward(xin, geom, dataclasses.replace(w, code_max=0), _mslif(),
-                              bn=_bn(c["bn"], dev), packed_out=True)      # AUTO -> direct form
+                              bn=_bn(c["bn"], dev), packed_out=True, impl=L.IMPL_MFMA)
   np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("cin", [3, 32, 48, 65, 96, 100])
+def test_conv_block_any_input_channel_count(dev, oracle, cin, bits):
+  """Blocks whose input width is not 64 or 128 (config.channels = 100, 96, 48, ...) stay on
+  the MFMA kernels: the tiled codes are zero-padded along Cin to 64 / 128 and the kernels
+  read the ceil(Cin / 32) spike words a pixel really has.  fp6 kernel (4-bit codes) and
+  int8 kernel (8-bit codes), rasters / pooled rasters / potentials bit-exact."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=4, B=3, hw=8, cin=cin, cout=96, seed=1901 + cin, gain=5.0, bits=bits)
+  rng = np.random.Generator(np.random.PCG64(cin))
+  x = (rng.random((4, 3, 9, 14, cin)) < 0.25).astype(np.uint8)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  eu, es = oracle.conv_block(x, qw, c["bn"], None, "int")
+  assert 0.005 < es.mean() < 0.7, es.mean()
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert (w.code_max <= 7) == (bits == 4)
+  geom = ops.ConvGeom(9, 14, cin, 96, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(x, dev))
+  u, s = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                              impl=L.IMPL_MFMA)
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+  _, sp = ops.conv_lif_forward(xin, geom, w, _mslif(), bn=_bn(c["bn"], dev), packed_out=True,
+                               pool=2, impl=L.IMPL_MFMA, want_u=False)
+  np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
 
 
 def test_mfma_kernel_refuses_unsupported_shapes(dev):
