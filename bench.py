@@ -259,7 +259,7 @@ def main():
   # dominant KERNEL = the device function with the largest share of the step, as
   # rocprofv3 --stats groups it (conv1 and conv2 are two launches of one kernel):
   # achieved = algorithmic ops (bytes) per launch / average launch duration
-  conv_kernel = "conv3x3_fp6_kernel" if fp6 else "conv3x3_bits_kernel"
+  conv_kernel = "conv3x3_bits_kernel"   # one device function, fp6 or int8 instruction inside
   groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
             "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
             "dense_mfma_kernel": ["dense[32768->110]"]}

@@ -1,28 +1,33 @@
 // Fused QuantConv(3x3, stride 1, pad 1) + BatchNorm + neuron (+ 2x2 max-pool) over
-// all T timesteps for bit-packed spikes (Cin = 128) and weight codes of magnitude
-// <= 7 (DuQ up to 4 bits).  Replaces the same reference path as conv3x3_mfma.hip:
-// SpikingBlock.__call__, spiking_learning.py:446-462, QuantConv flax_qconv.py:147-188,
-// pool examples/tcja/models.py:145-147.
+// all T timesteps for bit-packed spikes, Cin <= 128, any int8 weight codes.  Replaces
+// SpikingBlock.__call__, spiking_learning.py:446-462, with QuantConv
+// flax_qconv.py:147-188 and the pool of examples/tcja/models.py:145-147.
 //
-// The contraction runs on the block-scaled f8f6f4 MFMA (32x32x64, K = 64 per
-// instruction): A = spikes as fp4 (e2m1: 0 or 1.0), B = codes as fp6 (e2m3: every
-// integer up to 7 is exact), f32 accumulation of integers below 2^24 -- the same
-// integer the int8 kernel accumulates, at half the A bytes per MAC through LDS (the
-// resource the int8 kernel saturates) and a faster matrix rate.
+// The contraction runs on one of two matrix instructions (template parameter FMT):
+//  * codes of magnitude <= 7 (DuQ up to 4 bits): the block-scaled f8f6f4 MFMA
+//    (32x32x64, K = 64 per instruction), A = spikes as fp4 (e2m1: 0 or 1.0), B = codes
+//    as fp6 (e2m3: every integer up to 7 is exact), f32 accumulation of integers below
+//    2^24 -- the same integer an int8 MFMA accumulates, at half the A bytes per MAC
+//    through LDS and twice the matrix rate;
+//  * wider codes (8-bit DuQ, the reference's shipped configs): v_mfma_i32_32x32x32_i8,
+//    A = spikes as bytes, B = the int8 codes, 36 k-steps instead of 18.
 //
 // A workgroup is 8 waves on one 8x8-pixel patch, two waves per SIMD: wave w owns
-// output channels [32 (w & 3), +32) of tile w >> 2 (4x8 pixels), its 18 B fragments
-// (108 registers) for the whole launch, the tile's membrane potentials and two
+// output channels [32 (w & 3), +32) of tile w >> 2 (4x8 pixels), its B fragments for
+// the whole launch (108 registers fp6, 144 int8), the tile's membrane potentials and two
 // accumulator sets.  The loop is software-pipelined over t inside each wave: the
 // MFMAs of step t + 1 alternate with the instructions of the neuron epilogue of step
-// t, so the matrix pipe and the VALU run together; one workgroup barrier per step.
+// t; one workgroup barrier per step.  (Two waves per SIMD measured 10-20 % faster than
+// the one-wave, two-tiles-per-wave form of the int8 kernel this file replaced.)
 //
-// The halo of step t + 1 (10 x 10 pixels x 128 spike bits) is expanded to fp4 by a
-// byte -> 8-nibble LDS table and written to the other LDS buffer during step t; its
-// global load was issued a step earlier.  LDS image: two planes (64-channel
-// halves), rows of 12 pixels, 32 B per pixel = the two 16-byte lane halves, swapped
-// on odd rows: every tap/half offset is an instruction immediate and the reads
-// are bank-conflict free.
+// The halo of step t + 1 (10 x 10 pixels x Cin spike bits) is expanded to the A format
+// (fp4 by a byte -> 8-nibble LDS table, bytes by arithmetic) and written to the other
+// LDS buffer during step t; its global load was issued a step earlier.  LDS image: one
+// plane per k-step of a tap (64 fp4 / 32 byte channels = 32 B per pixel), rows of 12
+// pixels, the two 16-byte lane halves swapped on odd rows: every tap/half offset is an
+// instruction immediate and the reads are bank-conflict free.
+#include <type_traits>
+
 #include "conv_tile.h"
 
 namespace snnqp {
@@ -33,8 +38,8 @@ typedef __attribute__((address_space(3))) const v4i lds_cv4i_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
 
 // k-steps of 64: (tap, 64-channel group); Cin = 64 or 128 (template parameter CIN)
-constexpr int F6_PITCH = 12;                 // pixels per LDS halo row (10 used)
-constexpr int F6_PLANE = HALO * F6_PITCH * 32;   // one 64-channel half of a halo image
+constexpr int F6_PITCH = HPITCH;             // pixels per LDS halo row (10 used)
+constexpr int F6_PLANE = HPLANE;             // one k-step plane of a halo image (conv_tile.h)
 constexpr int F6_TAB = 1024;                 // byte -> 8 fp4 nibbles
 #ifndef SNNQP_F6_PREFETCH
 #define SNNQP_F6_PREFETCH 4
@@ -87,11 +92,23 @@ extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
 #define F6_MARK(i)
 #endif
 
-template <int CIN, int NF, bool POOL, bool LUT>
+// FMT: the matrix instruction the contraction runs on
+//   FMT_FP6: v_mfma_scale_f32_32x32x64_f8f6f4, fp4 spikes x fp6 codes (|code| <= 7), K = 64
+//   FMT_I8 : v_mfma_i32_32x32x32_i8, byte spikes x int8 codes (any 8-bit code), K = 32
+// Same workgroup shape, LDS image geometry (a plane = the 32 bytes a pixel contributes
+// to one k-step), pipeline and epilogue; the formats differ in the B fragments, the
+// bit -> operand expansion of the halo and the accumulator type.
+enum { FMT_FP6 = 0, FMT_I8 = 1 };
+
+template <int FMT, int CIN, int NF, bool POOL, bool LUT>
 __global__ void __launch_bounds__(512, 1)
-conv3x3_fp6_kernel(ConvMfmaArgs a) {
+conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
-  constexpr int NP = CIN / 64;                   // planes of the halo image
+  constexpr bool I8 = FMT == FMT_I8;
+  typedef typename std::conditional<I8, v16i, v16f>::type acc_t;
+  constexpr int KCH = I8 ? 32 : 64;              // input channels of one k-step
+  constexpr int BR = I8 ? 4 : 6;                 // registers of one B fragment
+  constexpr int NP = CIN / KCH;                  // planes of the halo image
   constexpr int WPP = CIN / 32;                  // spike words per pixel
   constexpr int F6_KS = 9 * NP;
   constexpr int F6_HALO = NP * F6_PLANE;         // one fp4 halo image
@@ -119,7 +136,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   const uint32_t cmask = chan_mask(cout_base, a.Cout);
 
   // tables: byte -> 8 nibbles (bit i set -> 1.0 = 0x2 in nibble i); dequant table
-  if (tid < 256) {
+  if (!I8 && tid < 256) {                        // (int8: bits -> bytes by arithmetic)
     uint32_t v = 0;
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) v |= ((tid >> bit) & 1) ? (0x2u << (4 * bit)) : 0u;
@@ -132,18 +149,24 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
 
   // B operand: k-step ks = NP tap + kk covers channels 64 kk .. +63 of the tap; lane
   // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile WPP tap + 2 kk + h
-  int bf[F6_KS][6];
+  // (int8: k-step ks = WPP tap + kk is int8 tile ks as it is, lane (n, h) holds k = 16 h + j)
+  int bf[F6_KS][BR];
   {
     const v4i *wtile = (const v4i *)a.wt + (int64_t)(cout_base >> 5) * (9 * WPP) * 64;
 #pragma unroll
     for (int ks = 0; ks < F6_KS; ++ks) {
-      const int ks8 = (ks / NP) * WPP + (ks % NP) * 2 + h;
-      v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-      if (wave_on) {
-        lo = wtile[ks8 * 64 + n];
-        hi = wtile[ks8 * 64 + 32 + n];
+      if constexpr (I8) {
+        const v4i t = wave_on ? wtile[ks * 64 + lane] : v4i{0, 0, 0, 0};
+        bf[ks][0] = t.x; bf[ks][1] = t.y; bf[ks][2] = t.z; bf[ks][3] = t.w;
+      } else {
+        const int ks8 = (ks / NP) * WPP + (ks % NP) * 2 + h;
+        v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (wave_on) {
+          lo = wtile[ks8 * 64 + n];
+          hi = wtile[ks8 * 64 + 32 + n];
+        }
+        fp6_pack32(lo, hi, bf[ks]);
       }
-      fp6_pack32(lo, hi, bf[ks]);
     }
   }
 
@@ -151,8 +174,8 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
   if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
-  // table mode: spikes count 4 (block scale 2^2 on A), so the f32 accumulator is the
-  // byte offset of its table entry from the entry of acc = 0.  The chain starts from
+  // table mode: spikes count 4 (block scale 2^2 on A / spike bytes of 4), so the accumulator
+  // is the byte offset of its table entry from the entry of acc = 0.  The chain starts from
   // the inline constant 0: no accumulator preload in either mode.
   constexpr int SCALE_A = LUT ? 129 : 127;       // E8M0: 2^(s - 127)
 
@@ -173,8 +196,9 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   // the template's 64 / 128) are zero spikes against zero codes
   const int wpm = (a.Cin + 31) >> 5;
   const int s_hy = s_pix / HALO, s_hx = s_pix % HALO;
-  uint8_t *s_dst = lds + (s_wi >> 1) * F6_PLANE + (s_hy * F6_PITCH + s_hx) * 32 +
-                   (((s_wi & 1) ^ (s_hy & 1)) * 16);
+  // fp4: word wi = half wi & 1 of plane wi >> 1; bytes: word wi = both halves of plane wi
+  uint8_t *s_dst = lds + (I8 ? s_wi : s_wi >> 1) * F6_PLANE + (s_hy * F6_PITCH + s_hx) * 32 +
+                   ((((I8 ? 0 : s_wi) & 1) ^ (s_hy & 1)) * 16);
   const uint32_t tab0 = lds0 + TAB_OFF;
   const uint32_t *xb = (const uint32_t *)a.x;
 
@@ -202,13 +226,15 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     const int gy = y0 + s_hy - 1, gx = x0 + s_hx - 1;
     const bool s_valid = s_task && s_wi < wpm && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * wpm + s_wi;
-    uint32_t stg = 0;
+    uint32_t stg = 0, stg_cur = 0;
     auto stage_load = [&](int t) {
       stg = s_valid ? xb[(int64_t)t * a.xs_t + s_goff] : 0u;
     };
     v4i s_exp = {0, 0, 0, 0};
     auto stage_expand = [&]() {                  // table reads; consumed by stage_write
-      if (s_task) {
+      if (I8) {
+        stg_cur = stg;
+      } else if (s_task) {
         const uint32_t sw = stg;
         s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw << 2) & 0x3FCu));
         s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 6) & 0x3FCu));
@@ -217,7 +243,15 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       }
     };
     auto stage_write = [&](int buf) {
-      if (s_task) *(v4i *)(s_dst + buf * F6_HALO) = s_exp;
+      if (I8) {
+        if (s_task) {
+          uint8_t *d = s_dst + buf * F6_HALO;
+          *(v4i *)d = expand16<LUT>(stg_cur & 0xFFFFu);                 // channels 0..15
+          *(v4i *)(d + (s_hy & 1 ? -16 : 16)) = expand16<LUT>(stg_cur >> 16);
+        }
+      } else if (s_task) {
+        *(v4i *)(s_dst + buf * F6_HALO) = s_exp;
+      }
     };
     auto a_read = [&](int buf, int ks) -> v4i {
       const int tap = ks / NP;
@@ -226,36 +260,39 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? abase_odd : abase_even) + off);
     };
     constexpr int PF = SNNQP_F6_PREFETCH;        // A fragments in flight ahead of the MFMA
-    auto mfma_one = [&](int ks, const v4i &av, v16f &acc) {
-      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-          v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
-          v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, acc,
-          4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+    auto mfma_acc = [&](int ks, const v4i &av, const acc_t &c) -> acc_t {
+      if constexpr (I8) {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(
+            av, v4i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3]}, c, 0, 0, 0);
+      } else {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+            v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
+            v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, c,
+            4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+      }
     };
-    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma_one = [&](int ks, const v4i &av, acc_t &acc) { acc = mfma_acc(ks, av, acc); };
     // the first MFMA of a chain takes C = 0 (an inline constant of the instruction)
-    auto mfma_first = [&](const v4i &av, v16f &acc) {
-      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-          v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
-          v8i{bf[0][0], bf[0][1], bf[0][2], bf[0][3], bf[0][4], bf[0][5], 0, 0}, zero16,
-          4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+    auto mfma_first = [&](const v4i &av, acc_t &acc) {
+      const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc = mfma_acc(0, av, zero16);
     };
     // table entry of the accumulator value a4 = 4 acc: address register = (int)a4, which
     // is negative for negative sums; the LDS address adder wraps, so base + LUT_ZERO is
     // the entry (the compiler folds LUT_ZERO into the offset field: ds_read_b32 ... offset:)
-    auto lut_read = [&](float a4) -> float {
+    auto lut_read = [&](auto a4) -> float {       // float accumulators: one v_cvt_i32_f32
       return *(lds_cfloat_t *)((lds_cu8_t *)lds + LUT_ZERO + (int)a4);
     };
-    auto dequant2 = [&](float a0, float a1) -> v2f {
+    auto dequant2 = [&](auto a0, auto a1) -> v2f {
       if (LUT) return v2f{lut_read(a0), lut_read(a1)};
-      const v2f af = {a0, a1};       // exact integers: the same division sequence
+      const v2f af = {(float)a0, (float)a1};     // exact integers: the same division sequence
       v2f q = af * a.dq.rL;
-      const v2f e = __builtin_elementwise_fma(-q, v2f{a.dq.L, a.dq.L}, af);
-      q = __builtin_elementwise_fma(e, v2f{a.dq.rL, a.dq.rL}, q);
+      const v2f e = fma2(-q, v2f{a.dq.L, a.dq.L}, af);
+      q = fma2(e, v2f{a.dq.rL, a.dq.rL}, q);
       return q * a.dq.m;
     };
     // MFMA(0) of a patch: nothing to overlap with
-    auto mfma_only = [&](int buf, v16f &acc) {
+    auto mfma_only = [&](int buf, acc_t &acc) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
@@ -280,7 +317,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     //   piece 1 (pair j)    : BatchNorm (3 packed ops)
     //   piece 2 (pair j)    : membrane update (3 packed ops) + threshold compares
     //   piece 3 (pair j)    : reset + spike word select
-    auto fused_step = [&](int buf, v16f &accN, const v16f &accC, int t) {
+    auto fused_step = [&](int buf, acc_t &accN, const acc_t &accC, int t) {
       v4i A[PF + 1];
 #pragma unroll
       for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
@@ -353,7 +390,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
       }
       if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
     };
-    auto epilogue = [&](const v16f &acc, int t) {
+    auto epilogue = [&](const acc_t &acc, int t) {
       v2f y[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = dequant2(acc[2 * j], acc[2 * j + 1]);
@@ -377,7 +414,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     // one pipeline step: MFMA(t + 1) || epilogue(t); halo(t + 2) staged meanwhile.
     // One barrier per step: inside it every wave reads halo(t + 1) and writes
     // halo(t + 2) into the other buffer.
-    auto step = [&](int t, v16f &accN, const v16f &accC) {
+    auto step = [&](int t, acc_t &accN, const acc_t &accC) {
 #if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 8))   // diagnostic build: no flush
       if (t >= FL && t % FL == 0)                // steps < t are behind a barrier
         flush_ring<POOL, SLOTS, 512>(obuf, a, t - FL, FL, b, y0, x0, tid);
@@ -394,7 +431,7 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
     };
 
     // pipeline prologue: halo(0) staged; MFMA(0) while halo(1) is staged
-    v16f accA, accB;
+    acc_t accA, accB;
     stage_load(0);
     stage_begin(0);
     stage_end(0);
@@ -425,28 +462,34 @@ conv3x3_fp6_kernel(ConvMfmaArgs a) {
   }
 }
 
-template <int CIN, int NF>
+template <int FMT, int CIN, int NF>
 static void launch_fp6_nf(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
                           hipStream_t st) {
-  if (pool && lut) launch_persistent(conv3x3_fp6_kernel<CIN, NF, true, true>, a, gy, st, 0, 512);
-  else if (pool) launch_persistent(conv3x3_fp6_kernel<CIN, NF, true, false>, a, gy, st, 0, 512);
-  else if (lut) launch_persistent(conv3x3_fp6_kernel<CIN, NF, false, true>, a, gy, st, 0, 512);
-  else launch_persistent(conv3x3_fp6_kernel<CIN, NF, false, false>, a, gy, st, 0, 512);
+  if (pool && lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, true>, a, gy, st, 0, 512);
+  else if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, false>, a, gy, st, 0, 512);
+  else if (lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, true>, a, gy, st, 0, 512);
+  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, false>, a, gy, st, 0, 512);
 }
 
-template <int CIN>
+template <int FMT, int CIN>
 static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
                            hipStream_t st) {
-  if (nf == NF_MUL0) launch_fp6_nf<CIN, NF_MUL0>(a, pool, lut, gy, st);
-  else if (nf == NF_MUL) launch_fp6_nf<CIN, NF_MUL>(a, pool, lut, gy, st);
-  else if (nf == NF_DIV) launch_fp6_nf<CIN, NF_DIV>(a, pool, lut, gy, st);
-  else launch_fp6_nf<CIN, NF_DECAY>(a, pool, lut, gy, st);
+  if (nf == NF_MUL0) launch_fp6_nf<FMT, CIN, NF_MUL0>(a, pool, lut, gy, st);
+  else if (nf == NF_MUL) launch_fp6_nf<FMT, CIN, NF_MUL>(a, pool, lut, gy, st);
+  else if (nf == NF_DIV) launch_fp6_nf<FMT, CIN, NF_DIV>(a, pool, lut, gy, st);
+  else launch_fp6_nf<FMT, CIN, NF_DECAY>(a, pool, lut, gy, st);
 }
 
-void launch_conv3x3_fp6(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
+// i8: codes wider than fp6 holds (|code| > 7) -> the int8 instruction
+void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, bool lut, unsigned gy,
                         hipStream_t st) {
-  if (a.Cin <= 64) launch_fp6_cin<64>(a, nf, pool, lut, gy, st);
-  else launch_fp6_cin<128>(a, nf, pool, lut, gy, st);
+  if (i8) {
+    if (a.Cin <= 64) launch_fp6_cin<FMT_I8, 64>(a, nf, pool, lut, gy, st);
+    else launch_fp6_cin<FMT_I8, 128>(a, nf, pool, lut, gy, st);
+  } else {
+    if (a.Cin <= 64) launch_fp6_cin<FMT_FP6, 64>(a, nf, pool, lut, gy, st);
+    else launch_fp6_cin<FMT_FP6, 128>(a, nf, pool, lut, gy, st);
+  }
 }
 
 }  // namespace snnqp

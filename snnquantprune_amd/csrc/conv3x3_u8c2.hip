@@ -1,30 +1,15 @@
-// Fused SpikingBlock for the 3x3 / stride 1 / pad 1 QuantConv layers of the
-// DVS128 topology (examples/tcja/models.py:111-147): implicit-GEMM int8 MFMA
-// (v_mfma_i32_32x32x32_i8) + dequantisation + eval BatchNorm + neuron update +
-// optional 2x2 max-pool, with the T loop inside the kernel.  Two kernels:
-//   conv3x3_bits_kernel  bit-packed input, Cin <= 128, any int8 codes and neuron kind
-//                        (codes of magnitude <= 7 go to conv3x3_fp6.hip instead)
-//   conv3x3_u8c2_kernel  uint8 event counts, Cin = 2 (the first layer)
+// Fused SpikingBlock for the first 3x3 / stride 1 / pad 1 QuantConv layer of the DVS128
+// topology (examples/tcja/models.py:111-147, Cin = 2 event-count frames): implicit-GEMM
+// int8 MFMA (v_mfma_i32_32x32x32_i8) + dequantisation + eval BatchNorm + neuron update +
+// optional 2x2 max-pool, with the T loop inside the kernel (conv3x3_u8c2_kernel), and
+// the host side of both fused conv kernels: what they support
+// (conv3x3_mfma_unsupported) and the dispatch (run_conv3x3_mfma) -- bit-packed inputs
+// go to conv3x3_bits.hip.
 //
-// Mapping of the bits kernel (one 256-thread workgroup = 4 waves, persistent over patches):
-//  * a patch is 8x8 output pixels of one sample = two 32-row MFMA tiles (4x8
-//    pixels each); wave w owns output channels [32w, 32w+32) of a 128-channel
-//    block (blockIdx.y);
-//  * the wave's weights -- all 9 taps x Cin for its 32 channels -- live in
-//    registers for the whole launch (the B operand; 144 registers at Cin = 128),
-//    loaded once from the MFMA-tiled codes (snnqp_pack_codes_mfma);
-//  * per timestep the 10x10 halo of input spikes is expanded from bits to
-//    {0,1} bytes into LDS once (one plane per k-step, conv_tile.h) and every tap's A
-//    fragment is one ds_read_b128 at an immediate offset, fetched one tap ahead of
-//    the MFMAs that consume it;
-//  * C/D layout: lane = output channel, register = pixel, so the per-channel
-//    dequant/BatchNorm constants are per-lane registers, the membrane potential
-//    of the patch stays in 32 VGPRs for all T, and the v_cmp that thresholds a
-//    register *is* the packed spike word of two pixels (64-bit lane mask);
-//    pooling is an OR of those scalar masks;
-//  * the loop is software-pipelined over t: the MFMAs of step t+1 and the
-//    dequant/BN/neuron epilogue of step t alternate in one basic block, so the
-//    matrix pipe and the VALU overlap inside the single wave each SIMD holds.
+// C/D layout of the MFMA: lane = output channel, register = pixel, so the per-channel
+// dequant / BatchNorm constants are per-lane registers, the membrane potentials of a
+// tile stay in 16 VGPRs for all T, and the v_cmp that thresholds a register *is* the
+// packed spike word of two pixels (64-bit lane mask); pooling is an OR of those masks.
 #include <type_traits>
 
 #include "conv_tile.h"
@@ -72,300 +57,6 @@ extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
 #define PHASE_MARK(i)
 #define PHASE_DUMP()
 #endif
-
-// ---------------------------------------------------------------------------
-// Bit-packed input, Cin = 128.
-// ---------------------------------------------------------------------------
-template <int NF, bool POOL, int LUTM, int CIN>
-__device__ __forceinline__ void conv3x3_bits_body(const ConvMfmaArgs &a) {
-  static_assert(LUTM != LUT_CHANNEL, "per-channel tables of K = 1152 do not fit LDS");
-  static_assert(CIN == 64 || CIN == 128, "two or four 32-channel planes");
-  constexpr int KK = CIN / 32;
-  constexpr int NSLOT = 18 * KK;                 // MFMAs of one step (9 taps x KK x 2 tiles)
-  constexpr int PPS = (64 + NSLOT - 1) / NSLOT;  // epilogue pieces per MFMA slot
-  constexpr int NTASK = HALO * HALO * KK;        // (pixel, word) staging tasks
-  constexpr int TPT = (NTASK + 255) / 256;       // tasks per thread
-  constexpr int LUT_BYTES = LutBytes<LUTM>::value;
-  constexpr int LUT_OFF = 2 * HALO_BYTES;
-  constexpr int FL = OutStage<POOL>::FL;
-  __shared__ __attribute__((aligned(16))) uint8_t
-      lds[2 * HALO_BYTES + LUT_BYTES + OutStage<POOL>::BYTES];
-  uint32_t *obuf = (uint32_t *)(lds + LUT_OFF + LUT_BYTES);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 31, h = lane >> 5;
-  const int cout_base = blockIdx.y * 128 + wave * 32;
-  const bool wave_on = cout_base < a.Cout;
-  const int cout = wave_on ? cout_base + n : n;
-  const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
-  const uint32_t cmask = chan_mask(cout_base, a.Cout);
-  if (LUTM == LUT_SHARED) build_lut((float *)(lds + LUT_OFF), a.lut_bound, a.dq, tid);
-  // start value of every accumulator chain: the address of the entry of acc = 0
-  const v16i cb = splat16(LUTM == LUT_SHARED ? (int)lds_addr(lds) + LUT_OFF + 4 * a.lut_bound : 0);
-
-  // B operand: lane (n, h) holds W[tap][cin = 32 kk + 16 h + j][cout], j < 16:
-  // k-step tap * KK + kk of this wave's 32-column block in the MFMA-tiled codes.
-  v4i bf[9][KK];
-  {
-    const v4i *wtile = (const v4i *)a.wt + ((int64_t)(cout_base >> 5) * (9 * KK)) * 64 + lane;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-        bf[tap][kk] = wave_on ? wtile[(tap * KK + kk) * 64] : v4i{0, 0, 0, 0};
-  }
-
-  LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
-  if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
-  if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
-
-  const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
-  const int tx = (n & 3) | (((n >> 3) & 1) << 2);
-  // A fragment of (tap, kk), tile tl: pixel (4 tl + ty + dy, tx + dx) of plane kk; the
-  // lane halves are swapped on odd halo rows, so dy = 1 uses the other base
-  const int pixb = (ty * HPITCH + tx) * 32;
-  const int abase_even = pixb + ((h ^ (ty & 1)) << 4);
-  const int abase_odd = pixb + ((h ^ (ty & 1) ^ 1) << 4);
-  auto aoff = [&](int tap, int kk, int tl) -> int {
-    return ((tap / 3) & 1 ? abase_odd : abase_even) + kk * HPLANE +
-           ((tap / 3 + 4 * tl) * HPITCH + tap % 3) * 32;
-  };
-  const uint32_t *xb = (const uint32_t *)a.x;
-  // a pixel has ceil(Cin / 32) spike words in memory; planes beyond them stay zero
-  const int wpm = (a.Cin + 31) >> 5;
-  // LDS word index of this lane's spike word (tile 0 / 1) inside one obuf slot
-  const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
-  const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
-  const bool store_lane = POOL ? lane < 8 : lane < 32;
-
-  PROBE_BEGIN()
-  PatchWalk pw(a);
-  for (int64_t r = pw.first; r < pw.count; r += pw.stride) {
-    int b, y0, x0;
-    pw.decode(a, r, b, y0, x0);
-
-    float u[2][16];
-    if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
-    else zero_u(u);
-
-    uint32_t stg[TPT];
-    auto stage_load = [&](int t) {
-#pragma unroll
-      for (int k = 0; k < TPT; ++k) {
-        const int task = tid + k * 256;
-        uint32_t wv = 0;
-        if (task < NTASK) {
-          const int pix = task / KK, wi = task % KK;
-          const int gy = y0 + pix / HALO - 1, gx = x0 + pix % HALO - 1;
-          if (wi < wpm && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            wv = xb[(int64_t)t * a.xs_t + (int64_t)b * a.xs_b +
-                    ((int64_t)gy * a.W + gx) * wpm + wi];
-        }
-        stg[k] = wv;
-      }
-    };
-    auto stage_store = [&](int buf) {
-      uint8_t *base = lds + buf * HALO_BYTES;
-#pragma unroll
-      for (int k = 0; k < TPT; ++k) {
-        const int task = tid + k * 256;
-        if (task < NTASK) {
-          const int pix = task / KK, wi = task % KK;
-          const int hy = pix / HALO, hx = pix % HALO;
-          *(v4i *)(base + halo_addr(hy, hx, wi, 0)) = expand16<LUTM != LUT_NONE>(stg[k] & 0xFFFFu);
-          *(v4i *)(base + halo_addr(hy, hx, wi, 1)) = expand16<LUTM != LUT_NONE>(stg[k] >> 16);
-        }
-      }
-    };
-    // all 72 MFMAs of one step; A fragments are fetched one tap ahead
-    auto mfma_step = [&](const uint8_t *base, v16i &acc0, v16i &acc1) {
-      v4i A[2][2 * KK];
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        A[0][kk] = *(const v4i *)(base + aoff(0, kk, 0));
-        A[0][KK + kk] = *(const v4i *)(base + aoff(0, kk, 1));
-      }
-      acc0 = cb;
-      acc1 = cb;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) {
-#pragma unroll
-          for (int kk = 0; kk < KK; ++kk) {
-            A[(tap + 1) & 1][kk] = *(const v4i *)(base + aoff(tap + 1, kk, 0));
-            A[(tap + 1) & 1][KK + kk] = *(const v4i *)(base + aoff(tap + 1, kk, 1));
-          }
-        }
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][kk], bf[tap][kk], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][KK + kk], bf[tap][kk], acc1, 0, 0, 0);
-        }
-      }
-    };
-    // One pipelined step in a hand-placed order: 72 issue slots (36 at Cin <= 64), each =
-    // one MFMA of step t+1, one A-fragment read for the next tap, and one (two) quarter(s)
-    // of a neuron pair of step t's epilogue (16 pairs x 4 pieces = 64 pieces), fenced
-    // with sched_barrier so the order survives.  An in-order wave overlaps the
-    // matrix pipe and the VALU only when their instructions alternate; left to
-    // itself the scheduler emits bursts of MFMAs and bursts of VALU (measured:
-    // time = sum of the two instead of their maximum).
-    //   piece 1 (pair j+1): dequantise (LDS table reads or packed arithmetic)
-    //   piece 2 (pair j)  : BatchNorm (3 packed ops)
-    //   piece 3 (pair j)  : membrane update (3 packed ops) + threshold compares
-    //   piece 4 (pair j)  : reset + spike word select
-    auto fused_step = [&](const uint8_t *base, v16i &accN0, v16i &accN1,
-                          const v16i &accC0, const v16i &accC1, int t) {
-      v4i A[2][2 * KK];
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        A[0][2 * kk] = *(const v4i *)(base + aoff(0, kk, 0));
-        A[0][2 * kk + 1] = *(const v4i *)(base + aoff(0, kk, 1));
-      }
-      accN0 = cb;
-      accN1 = cb;
-      v2f y[2], x, uu;
-      unsigned long long m0 = 0, m1 = 0;
-      uint32_t w0 = 0, w1 = 0;
-      auto piece1 = [&](int j) {            // j = pair index 0..15
-        const int a0 = (j < 8) ? accC0[(j & 7) * 2] : accC1[(j & 7) * 2];
-        const int a1 = (j < 8) ? accC0[(j & 7) * 2 + 1] : accC1[(j & 7) * 2 + 1];
-        y[j & 1] = dequant_pair<LUTM>(a0, a1, a.dq);
-      };
-      piece1(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int slot = 0; slot < NSLOT; ++slot) {
-        const int tap = slot / (2 * KK), m = slot % (2 * KK), kk = m >> 1, tl = m & 1;
-        // A fragment for the same position of the next tap
-        if (tap + 1 < 9)
-          A[(tap + 1) & 1][m] = *(const v4i *)(base + aoff(tap + 1, kk, tl));
-#if defined(SNNQP_BITS_ABL) && (SNNQP_BITS_ABL & 1)   // diagnostic build: 2 of 72 MFMAs
-        if (slot < 2) {
-#else
-        {
-#endif
-          if (tl == 0)
-            accN0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN0, 0, 0, 0);
-          else
-            accN1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[tap & 1][m], bf[tap][kk], accN1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < PPS; ++q) {
-          const int pc = slot * PPS + q;
-#if defined(SNNQP_BITS_ABL) && (SNNQP_BITS_ABL & 2)   // diagnostic build: no epilogue
-          if (true) continue;
-#endif
-          if (pc >= 64) continue;
-          const int j = pc >> 2, piece = pc & 3;
-          float *up = (j < 8) ? &u[0][(j & 7) * 2] : &u[1][(j & 7) * 2];
-          if (piece == 0) {
-            if (j + 1 < 16) piece1(j + 1);
-          } else if (piece == 1) {
-            x = y[j & 1] - lc.bmean;
-            x = x * lc.bmul;
-            x = x + lc.bbias;
-          } else if (piece == 2) {
-            uu = neuron_update<NF>(x, v2f{up[0], up[1]}, lc, a.nrn);
-            m0 = __ballot(uu.x >= a.nrn.vth);
-            m1 = __ballot(uu.y >= a.nrn.vth);
-          } else {
-            up[0] = neuron_reset<NF>(uu.x, m0, lc);
-            up[1] = neuron_reset<NF>(uu.y, m1, lc);
-            uint32_t &w = (j < 8) ? w0 : w1;
-            const int i = (j & 7) * 2;
-            if (POOL) {
-              const unsigned long long o = m0 | m1;
-              const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
-              w = writelane_u32(pw, i >> 1, w);
-            } else {
-              const int r0 = (i & 3) + 8 * (i >> 2);
-              w = writelane_u32((uint32_t)m0, r0, w);
-              w = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, w);
-              w = writelane_u32((uint32_t)m1, r0 + 1, w);
-              w = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, w);
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (store_lane) {
-        uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
-        o[ob0] = w0 & cmask;
-        o[ob1] = w1 & cmask;
-      }
-    };
-    auto epilogue = [&](const v16i &acc0, const v16i &acc1, int t) {
-      const uint32_t w0 = tile_epilogue<NF, POOL, LUTM>(acc0, u[0], a.dq, lc, a.nrn, lane);
-      const uint32_t w1 = tile_epilogue<NF, POOL, LUTM>(acc1, u[1], a.dq, lc, a.nrn, lane);
-      if (store_lane) {
-        uint32_t *o = obuf + (t % FL) * (OutStage<POOL>::NPIX * 4);
-        o[ob0] = w0 & cmask;
-        o[ob1] = w1 & cmask;
-      }
-    };
-    // call right after the barrier that follows epilogue(t)
-    auto flush_after = [&](int t) {
-      if ((t + 1) % FL == 0 || t + 1 == a.T) {
-        flush_out<POOL>(obuf, a, t - t % FL, t % FL + 1, b, y0, x0, tid);
-        lds_barrier();
-      }
-    };
-
-    // pipeline prologue: halo(0) staged, MFMA(0) done, halo(1) staged
-    v16i accA0, accA1, accB0, accB1;
-    stage_load(0);
-    stage_store(0);
-    if (a.T > 1) stage_load(1);
-    lds_barrier();
-    mfma_step(lds, accA0, accA1);
-    if (a.T > 1) stage_store(1);
-    lds_barrier();
-
-    // steady state, unrolled by two so the accumulator roles alternate:
-    //   MFMA(t+1) -> next  ||  epilogue(t) <- cur ; then stage halo(t+2)
-    int t = 0;
-    for (; t + 2 < a.T; t += 2) {
-      stage_load(t + 2);
-      fused_step(lds + HALO_BYTES, accB0, accB1, accA0, accA1, t);   // MFMA(t+1) || epilogue(t)
-      stage_store(0);                                  // halo(t+2) -> even buffer
-      lds_barrier();
-      flush_after(t);
-      if (t + 3 < a.T) stage_load(t + 3);
-      fused_step(lds, accA0, accA1, accB0, accB1, t + 1);            // MFMA(t+2) || epilogue(t+1)
-      if (t + 3 < a.T) stage_store(1);                 // halo(t+3) -> odd buffer
-      lds_barrier();
-      flush_after(t + 1);
-    }
-    // here MFMA(t) is in accA and, if t+1 < T, halo(t+1) is staged in the odd buffer
-    if (t + 1 < a.T) {
-      fused_step(lds + HALO_BYTES, accB0, accB1, accA0, accA1, t);
-      lds_barrier();
-      flush_after(t);
-      epilogue(accB0, accB1, t + 1);
-      lds_barrier();
-      flush_after(t + 1);
-    } else {
-      epilogue(accA0, accA1, t);
-      lds_barrier();   // also: LDS is re-staged by the next patch
-      flush_after(t);
-    }
-    if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
-  }
-  PROBE_END()
-}
-
-template <int NF, bool POOL, int LUTM>
-__global__ void __launch_bounds__(256, 1)
-conv3x3_bits_kernel(ConvMfmaArgs a) {            // 64 < Cin <= 128
-  conv3x3_bits_body<NF, POOL, LUTM, 128>(a);
-}
-
-template <int NF, bool POOL, int LUTM>
-__global__ void __launch_bounds__(256, 1)
-conv3x3_bits64_kernel(ConvMfmaArgs a) {          // Cin <= 64: half the k-steps
-  conv3x3_bits_body<NF, POOL, LUTM, 64>(a);
-}
 
 // ---------------------------------------------------------------------------
 // u8 event-count input with Cin = 2 (the DVS polarity pair, conv0): K = 18 of
@@ -680,16 +371,9 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     else if (nf == NF_DIV) SNNQP_CONV_LAUNCH_NF(KERN, NF_DIV, LM, LDS);             \
     else SNNQP_CONV_LAUNCH_NF(KERN, NF_DECAY, LM, LDS);                             \
   } while (0)
-  if (in_type == SNNQP_BITS && w->code_max > 0 && w->code_max <= 7) {
-    launch_conv3x3_fp6(a, nf, pl, lut, gy, st);  // codes exact in fp6: f8f6f4 MFMA
-  } else if (in_type == SNNQP_BITS) {
-    if (g->Cin <= 64) {
-      if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits64_kernel, LUT_SHARED, 0);
-      else SNNQP_CONV_LAUNCH(conv3x3_bits64_kernel, LUT_NONE, 0);
-    } else {
-      if (lut) SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_SHARED, 0);
-      else SNNQP_CONV_LAUNCH(conv3x3_bits_kernel, LUT_NONE, 0);
-    }
+  if (in_type == SNNQP_BITS) {
+    // conv3x3_bits.hip: codes exact in fp6 -> f8f6f4 MFMA, wider codes -> int8 MFMA
+    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
     const size_t ldsb = lds_fixed + u8c2_table_bytes(lm, a.lut_bound);

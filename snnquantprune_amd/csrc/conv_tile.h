@@ -1,5 +1,5 @@
-// Device helpers shared by the fused conv3x3 MFMA kernels (conv3x3_mfma.hip,
-// conv3x3_fp6.hip): patch schedule, LDS tables, the neuron epilogue on the MFMA
+// Device helpers shared by the fused conv3x3 MFMA kernels (conv3x3_u8c2.hip,
+// conv3x3_bits.hip): patch schedule, LDS tables, the neuron epilogue on the MFMA
 // C/D layout, spike-word staging.  gfx950 only.
 #pragma once
 #include "kernels.h"
@@ -9,7 +9,30 @@ namespace snnqp {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+// Two neurons (two pixels of one channel) travel through the epilogue side by side.
+// As SCALAR float32 instructions: on gfx950 the packed forms (v_pk_fma/mul/add_f32) take
+// two passes anyway and, unlike scalar VALU ops, do not overlap with an MFMA in flight
+// (tools/ubench/mfma_overlap_classes.hip: 4 v_pk_fma + 1 MFMA = 25.5 ns against 9.7 +
+// 13.9 apart; 8 v_fma_f32 + 1 f8f6f4 MFMA = 21.7 ns against 18.4 + 15.3).
+// -DSNNQP_PACKED_F32 brings the packed forms back for A/B runs.
+#ifdef SNNQP_PACKED_F32
 typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct v2f {
+  float x, y;
+};
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f operator+(v2f a, float b) { return v2f{a.x + b, a.y + b}; }
+__device__ __forceinline__ v2f operator-(v2f a, float b) { return v2f{a.x - b, a.y - b}; }
+__device__ __forceinline__ v2f operator*(v2f a, float b) { return v2f{a.x * b, a.y * b}; }
+__device__ __forceinline__ v2f operator-(v2f a) { return v2f{-a.x, -a.y}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
+  return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+}
+#endif
 
 #ifndef SNNQP_U8C2_UNROLL
 #define SNNQP_U8C2_UNROLL 1
@@ -48,7 +71,6 @@ constexpr int HALO = 10;
 // B/clk/CU; the earlier pixel-major image with an XOR swizzle measured 63).
 constexpr int HPITCH = 12;
 constexpr int HPLANE = HALO * HPITCH * 32;      // one k-step plane
-constexpr int HALO_BYTES = 4 * HPLANE;          // one expanded halo image (Cin = 128)
 
 struct ConvMfmaArgs {
   const void *x;
@@ -69,11 +91,6 @@ struct ConvMfmaArgs {
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
 };
-
-// byte offset of half `hh` (0/1) of k-step kk of halo pixel (hy, hx)
-__device__ __forceinline__ int halo_addr(int hy, int hx, int kk, int hh) {
-  return kk * HPLANE + (hy * HPITCH + hx) * 32 + ((hh ^ (hy & 1)) << 4);
-}
 
 // 16 spike bits -> 16 bytes {0, 1} (or {0, 4} when the accumulator indexes a table)
 template <bool X4>
@@ -252,8 +269,8 @@ __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq, f
   v2f a = {(float)a0, (float)a1};
   if (OFFS) a = a + off;
   v2f q = a * dq.rL;
-  const v2f e = __builtin_elementwise_fma(-q, v2f{dq.L, dq.L}, a);
-  q = __builtin_elementwise_fma(e, v2f{dq.rL, dq.rL}, q);
+  const v2f e = fma2(-q, v2f{dq.L, dq.L}, a);
+  q = fma2(e, v2f{dq.rL, dq.rL}, q);
   return q * dq.m;
 }
 
@@ -269,9 +286,21 @@ __device__ __forceinline__ v2f neuron_update(v2f x, v2f u, const LaneConsts &lc,
     return ud + x;
   }
   // u - 0 == u exactly, so NF_MUL0 skips the subtraction
+#ifndef SNNQP_PACKED_F32
+  if (FMA) {
+    // conv0's table kernel: no MFMA worth overlapping (one per 1024 updates), and one
+    // v_pk_add + one v_pk_fma per pair issue in fewer slots than four scalar ops
+    // (measured 7.8 against 8.1 ms), so this variant keeps the packed forms
+    typedef float v2fp __attribute__((ext_vector_type(2)));
+    const v2fp up = {u.x, u.y}, xp = {x.x, x.y};
+    const v2fp dp = NF == NF_MUL0 ? xp - up : xp - (up - lc.vr);
+    const v2fp r = __builtin_elementwise_fma(dp, v2fp{nrn.inv_k, nrn.inv_k}, up);
+    return v2f{r.x, r.y};
+  }
+#endif
   const v2f d = NF == NF_MUL0 ? x - u : x - (u - lc.vr);
   if (NF == NF_DIV) return u + v2f{d.x / nrn.k, d.y / nrn.k};
-  if (FMA) return __builtin_elementwise_fma(d, v2f{nrn.inv_k, nrn.inv_k}, u);
+  if (FMA) return fma2(d, v2f{nrn.inv_k, nrn.inv_k}, u);
   const v2f dk = d * nrn.inv_k;
   return u + dk;
 }
@@ -475,8 +504,8 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
   hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(threads), dyn_lds, st, a);
 }
 
-// conv3x3_fp6.hip: bit-packed input, Cin = 128, codes of magnitude <= 7, fast neuron
-void launch_conv3x3_fp6(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
+// conv3x3_bits.hip: bit-packed input, Cin <= 128; i8 = codes wider than fp6 holds
+void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, bool lut, unsigned gy,
                         hipStream_t st);
 
 }  // namespace snnqp

@@ -50,7 +50,7 @@ __device__ __forceinline__ v4i expand16b(uint32_t b) {
   return o;
 }
 
-// Workgroup barrier ordering LDS traffic only (see conv3x3_mfma.hip): the K loop
+// Workgroup barrier ordering LDS traffic only (see conv_tile.h): the K loop
 // keeps the next chunk's global loads in flight across it.
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");

@@ -3,7 +3,7 @@
 N-D (here 1-D and 2-D) convolution, NHWC inputs, HWIO `kernel`, string or
 explicit padding, strides, input / kernel dilation, feature groups; weights
 pass through the configured quantiser and the prune mask.  The arithmetic runs
-in libsnnqp (csrc/generic_block.hip; csrc/conv3x3_mfma.hip when fused with the
+in libsnnqp (csrc/generic_block.hip; csrc/conv3x3_bits.hip / conv3x3_u8c2.hip when fused with the
 neuron in SpikingBlock).
 """
 

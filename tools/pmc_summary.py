@@ -56,7 +56,7 @@ if "--traffic" in sys.argv:
     tag = None
     if "conv3x3_u8c2_kernel" in k:
       tag = "conv3x3[128x128x2->128]"
-    elif "conv3x3_fp6_kernel" in k or "conv3x3_bits_kernel" in k:
+    elif "conv3x3_bits_kernel" in k or "conv3x3_fp6_kernel" in k:
       tag = "conv3x3[64x64x128->128]" if k.endswith("#0") else "conv3x3[32x32x128->128]"
     elif "dense_mfma_kernel" in k:
       tag = "dense[32768->110]"
