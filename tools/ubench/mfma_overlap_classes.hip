@@ -11,7 +11,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // CLS: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_cmp + v_cndmask (through an SGPR pair), 3 v_cvt,
-//      4 ds_read_b32, 5 ds_read_b128, 6 v_writelane, 7 v_pk_mul + v_pk_add
+//      4 ds_read_b32, 5 ds_read_b128, 6 v_writelane, 7 v_pk_mul + v_pk_add,
+//      8 v_cmp + v_cndmask through VCC, 9 v_cvt_i32_f32
 template <int CLS, int NV, int MF, int WPS>   // MF: 0 none, 1 int8 32x32x32, 2 f8f6f4 fp4 x fp6
 __global__ void __launch_bounds__(256, WPS) k(int *out, int iters, float a, float b) {
   __shared__ __attribute__((aligned(16))) float lds[4096];
@@ -49,6 +50,11 @@ __global__ void __launch_bounds__(256, WPS) k(int *out, int iters, float a, floa
           if (v & 1) asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(x[r]) : "v"(x[r]), "s"(m));
           else asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(x[r]));
         }
+        if (CLS == 8) {       // the same through VCC (VOP2 / VOPC encodings)
+          if (v & 1) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(x[r]) : "v"(x[r]), "v"(b) : );
+          else asm volatile("v_cmp_le_f32_e32 vcc, %0, %1" : : "v"(a), "v"(x[r]) : "vcc");
+        }
+        if (CLS == 9) asm volatile("v_cvt_i32_f32_e32 %0, %1" : "=v"(xi[r]) : "v"(x[r]));
         if (CLS == 3) asm volatile("v_cvt_f32_i32_e32 %0, %1" : "=v"(x[r]) : "v"(xi[r]));
         if (CLS == 4) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x[r]) : "v"(addr), "n"(256 * 1));
         if (CLS == 5) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[v % 4]) : "v"(addr), "n"(1024));
@@ -98,7 +104,9 @@ int main() {
   row<1, 4>(out, "v_pk_fma_f32");
   row<7, 4>(out, "v_pk_mul/add_f32");
   row<2, 8>(out, "v_cmp(sgpr)+v_cndmask");
+  row<8, 8>(out, "v_cmp(vcc)+v_cndmask e32");
   row<3, 8>(out, "v_cvt_f32_i32");
+  row<9, 8>(out, "v_cvt_i32_f32");
   row<4, 8>(out, "ds_read_b32 + wait");
   row<5, 2>(out, "ds_read_b128 + wait");
   row<5, 4>(out, "ds_read_b128 + wait");
@@ -107,7 +115,9 @@ int main() {
   row<0, 8, 2>(out, "v_fma_f32");
   row<1, 4, 2>(out, "v_pk_fma_f32");
   row<2, 8, 2>(out, "v_cmp(sgpr)+v_cndmask");
+  row<8, 8, 2>(out, "v_cmp(vcc)+v_cndmask e32");
   row<3, 8, 2>(out, "v_cvt_f32_i32");
+  row<9, 8, 2>(out, "v_cvt_i32_f32");
   row<5, 2, 2>(out, "ds_read_b128 + wait");
   row<6, 8, 2>(out, "v_writelane_b32");
   return 0;
