@@ -376,7 +376,13 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
-    const size_t ldsb = lds_fixed + u8c2_table_bytes(lm, a.lut_bound);
+    // the kernel is compiled for SNNQP_U8C2_WPS workgroups per CU: stage fewer timesteps per
+    // pass rather than lose one of them to LDS (T >= 32 with the per-channel tables took
+    // 54 KiB and ran two per CU: 11.2 against 7.9 ms per 20480 sample-steps)
+    const size_t per_wg = (size_t)(160 * 1024) / SNNQP_U8C2_WPS - 1024;
+    const size_t lds_rest = lds_fixed - (size_t)a.tchunk * HIMG2 + u8c2_table_bytes(lm, a.lut_bound);
+    while (a.tchunk > 8 && (size_t)a.tchunk * HIMG2 + lds_rest > per_wg) a.tchunk -= 8;
+    const size_t ldsb = (size_t)a.tchunk * HIMG2 + lds_rest;
     if (lutc) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_CHANNEL, ldsb);
     else if (lut) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_SHARED, ldsb);
     else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_NONE, ldsb);
