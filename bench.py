@@ -49,6 +49,9 @@ def parse():
   ap.add_argument("--prune", type=float, default=0.9)
   ap.add_argument("--lam", type=float, default=0.1,
                   help="Poisson rate of the synthetic events; spikes are (Poisson(lam) > 0)")
+  ap.add_argument("--counts", action="store_true",
+                  help="event COUNT frames, Poisson(lam) per pixel and polarity as the reference's "
+                       "preprocessing produces them (input_pipeline.py:195-218), instead of binary")
   ap.add_argument("--model", choices=("c3", "cextnet"), default="c3",
                   help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
                        "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
@@ -180,7 +183,11 @@ def main():
   gen = torch.Generator(device=dev)
   gen.manual_seed(8627169 + rank)
   p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
-  x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
+  if args.counts:
+    x = torch.poisson(torch.full((B, T, 128, 128, 2), float(args.lam), device=dev),
+                      generator=gen).clamp_(max=255).to(torch.uint8)
+  else:
+    x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
   if args.input == "f32":
     x = x.to(torch.float32)
 
@@ -305,7 +312,8 @@ def main():
       "dtype_detail": "integer codes x integer inputs, exact sums: conv0/dense int8 x u8/binary -> "
                       "int32 (i8 MFMA); conv1-2 the same integers as fp6 codes x fp4 spikes -> f32 "
                       "(f8f6f4 MFMA, sums < 2^24 exact); membrane potentials f32",
-      "data": "synthetic Poisson(%g)>0 spikes, N(0,1/fan_in) weights, random seeds fixed" % args.lam,
+      "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
+              % args.lam + ", N(0,1/fan_in) weights, random seeds fixed",
       "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
                               "qdense(2048->512->110) + vote, " if args.model == "cextnet" else
                               "C3: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->110)+LIF + vote, ") +

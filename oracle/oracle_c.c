@@ -5,10 +5,12 @@
  *   lax.dot_general at flax_qdense.py:87 / lax.conv_general_dilated at
  *   flax_qconv.py:158 with one fixed summation order (XLA leaves it open).
  *
- * oracle_check_div: exhaustive proof obligation for the three-instruction
- *   division used by the HIP epilogues, q = a*r; e = fma(-q, L, a);
- *   q' = fma(e, r, q) with r = fl(1/L): counts integers |a| <= amax for which
- *   q' differs from the IEEE quotient fl(a / L) (DuQ dequantisation
+ * oracle_check_div: exhaustive proof obligation for the two-instruction
+ *   division used by the HIP epilogues, t = a*r_lo; q = fma(a, r_hi, t) with
+ *   r_hi = fl(1/L), r_lo = fl(1/L - r_hi) (a split reciprocal: the fma rounds
+ *   a/L * (1 + ~2^-48) once, and a quotient of integers a < 2^24 by L never
+ *   lies that close to a rounding boundary): counts integers |a| <= amax for
+ *   which q differs from the IEEE quotient fl(a / L) (DuQ dequantisation
  *   x / (n_lvl - 1), quant.py:443).  Must return 0.
  *
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC -fopenmp oracle_c.c -lm
@@ -33,14 +35,14 @@ void oracle_fseq_matmul(const float *x, const float *w, float *y, int64_t m,
 
 int64_t oracle_check_div(int32_t L, int32_t amax) {
   const float Lf = (float)L;
-  const float r = 1.0f / Lf;
+  const float r_hi = 1.0f / Lf;
+  const float r_lo = (float)(1.0 / (double)Lf - (double)r_hi);
   int64_t bad = 0;
 #pragma omp parallel for reduction(+ : bad) schedule(static)
   for (int32_t a = -amax; a <= amax; ++a) {
     const float af = (float)a;
-    float q = af * r;
-    const float e = fmaf(-q, Lf, af);
-    q = fmaf(e, r, q);
+    const float t = af * r_lo;
+    const float q = fmaf(af, r_hi, t);
     const float ref = af / Lf;
     if (memcmp(&q, &ref, 4) != 0 && !(q == 0.0f && ref == 0.0f)) ++bad;
   }

@@ -43,41 +43,36 @@ void set_error(const char *fmt, ...);
   } while (0)
 
 // ---- dequantisation:  x = fl(fl(acc / L) * m) -----------------------------
-// The division is done as q = a*r; e = fma(-q, L, a); q' = fma(e, r, q) with
-// r = fl(1/L); oracle/oracle_c.c:oracle_check_div proves it equal to the IEEE
-// quotient for every integer |a| <= 2^24 and every L = 2^(b-1) - 1.
+// The division is two instructions: t = a * r_lo; q = fma(a, r_hi, t) with the split
+// reciprocal r_hi = fl(1/L), r_lo = fl(1/L - r_hi).  The fma rounds a/L * (1 + ~2^-48)
+// once, and a quotient of an integer |a| < 2^24 by L is never that close to a rounding
+// boundary of float32 (distance >= 2^-24 / L relative): it IS the IEEE quotient.
+// oracle/oracle_c.c:oracle_check_div counts the exceptions exhaustively (none) for
+// every L = 2^(b-1) - 1 (tests/test_oracle_cpu.py).
 struct Dequant {
-  float L, rL, m;
-  int has_div;
+  float L, rL, rLlo, m;
 };
 
 inline Dequant make_dequant(float L, float m) {
   Dequant d;
   d.L = L;
   d.rL = 1.0f / L;
+  d.rLlo = (float)(1.0 / (double)L - (double)d.rL);
   d.m = m;
-  d.has_div = (L != 1.0f);
   return d;
 }
 
-// Branch-free form for straight-line epilogues: with L == 1 the three ops are
-// the identity (q = a, e = 0, q' = a).
+// exact a / L for an integer-valued a (L == 1: t = 0, q = a)
+__device__ __forceinline__ float div_exact(float a, const Dequant &d) {
+  return __builtin_fmaf(a, d.rL, a * d.rLlo);
+}
+
 __device__ __forceinline__ float dequant_acc_nb(int acc, const Dequant &d) {
-  const float a = (float)acc;
-  float q = a * d.rL;
-  const float e = __builtin_fmaf(-q, d.L, a);
-  q = __builtin_fmaf(e, d.rL, q);
-  return q * d.m;
+  return div_exact((float)acc, d) * d.m;
 }
 
 __device__ __forceinline__ float dequant_acc(int acc, const Dequant &d) {
-  float a = (float)acc;
-  if (d.has_div) {
-    float q = a * d.rL;
-    float e = __builtin_fmaf(-q, d.L, a);
-    a = __builtin_fmaf(e, d.rL, q);
-  }
-  return a * d.m;
+  return div_exact((float)acc, d) * d.m;
 }
 
 // ---- neuron update, spiking_learning.py:357-438 ----------------------------

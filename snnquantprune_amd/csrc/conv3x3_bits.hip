@@ -285,10 +285,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     };
     auto dequant2 = [&](auto a0, auto a1) -> v2f {
       if (LUT) return v2f{lut_read(a0), lut_read(a1)};
-      const v2f af = {(float)a0, (float)a1};     // exact integers: the same division sequence
-      v2f q = af * a.dq.rL;
-      const v2f e = fma2(-q, v2f{a.dq.L, a.dq.L}, af);
-      q = fma2(e, v2f{a.dq.rL, a.dq.rL}, q);
+      const v2f af = {(float)a0, (float)a1};     // exact integers: the division of common.h
+      const v2f q = fma2(af, v2f{a.dq.rL, a.dq.rL}, af * a.dq.rLlo);
       return q * a.dq.m;
     };
     // MFMA(0) of a patch: nothing to overlap with

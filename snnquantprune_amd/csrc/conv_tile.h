@@ -209,7 +209,7 @@ __device__ __forceinline__ float lds_read_f32(uint32_t addr) {
 }
 
 // lut[i] = fl(fl((i - bound) / L) * m): the dequantised current of accumulator
-// value i - bound, built once per workgroup (same three-instruction division).
+// value i - bound, built once per workgroup (same exact division, common.h).
 __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &dq,
                                           int tid, int nthreads = 256) {
   for (int i = tid; i <= 2 * bound; i += nthreads) lut[i] = dequant_acc_nb(i - bound, dq);
@@ -268,9 +268,7 @@ __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq, f
   if (LUTM != LUT_NONE) return v2f{lds_read_f32((uint32_t)a0), lds_read_f32((uint32_t)a1)};
   v2f a = {(float)a0, (float)a1};
   if (OFFS) a = a + off;
-  v2f q = a * dq.rL;
-  const v2f e = fma2(-q, v2f{dq.L, dq.L}, a);
-  q = fma2(e, v2f{dq.rL, dq.rL}, q);
+  const v2f q = fma2(a, v2f{dq.rL, dq.rL}, a * dq.rLlo);     // exact a / L (common.h)
   return q * dq.m;
 }
 

@@ -196,10 +196,12 @@ def test_int_and_float_modes_agree_away_from_ties(oracle):
   assert (si != sf).mean() < 1e-3
 
 
-def test_three_instruction_division_is_exact(oracle):
-  """The HIP epilogues divide by L = n_lv - 1 with mul + 2 fma; exhaustive."""
-  for L in (1, 3, 7, 15, 31, 63, 127):
-    assert oracle.clib().oracle_check_div(L, 1 << 22) == 0
+def test_two_instruction_division_is_exact(oracle):
+  """The HIP epilogues divide by L = n_lv - 1 with one mul + one fma on a split reciprocal
+  (csrc/common.h); exhaustive over every accumulator value float32 holds exactly, for every
+  L of a 2..16-bit signed quantiser and a few other divisors."""
+  for L in [(1 << (b - 1)) - 1 for b in range(2, 17)] + [5, 100, 255]:
+    assert oracle.clib().oracle_check_div(L, 1 << 24) == 0, L
 
 
 def test_vote_and_metrics(oracle):
