@@ -106,15 +106,22 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int cout = wave_on ? cout_base + n : n;
   const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
   const uint32_t cmask = chan_mask(cout_base, a.Cout);
-  // smallest non-zero |input current| of this workgroup's channels (per-channel tables
-  // only): decides whether the membrane update may be one fused multiply-add
+  // smallest non-zero |input current| of this workgroup's channels (table kernels):
+  // decides whether the membrane update may be one fused multiply-add
   uint32_t *wgmin = obuf + OutStage<POOL>::BYTES / 4;
-  if (LUTM == LUT_CHANNEL) {
+  if (LUTM != LUT_NONE) {
     if (tid == 0) *wgmin = 0x7F800000u;
     lds_barrier();
   }
   // tables and constants become visible with the first staging barrier
-  if (LUTM == LUT_SHARED) build_lut((float *)(lds + lut_off), a.lut_bound, a.dq, tid);
+  if (LUTM == LUT_SHARED) {
+    build_lut((float *)(lds + lut_off), a.lut_bound, a.dq, tid);
+    if (NF == NF_MUL0) {             // BatchNorm of every entry, per channel: may the update fuse?
+      lds_barrier();
+      atomicMin(wgmin, lut_bn_min_bits((const float *)(lds + lut_off), a.lut_bound, a.bn,
+                                       blockIdx.y * 128, a.Cout, tid, 256));
+    }
+  }
   if (LUTM == LUT_CHANNEL) {
     const uint32_t mb = build_lut_channel((float *)(lds + lut_off), a.lut_bound, a.dq, a.bn,
                                           blockIdx.y * 128, a.Cout, tid);
@@ -274,9 +281,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       }
       };
       bool fma_ok = false;
-      if (NF == NF_MUL0 && LUTM == LUT_CHANNEL)
+      if (NF == NF_MUL0 && LUTM != LUT_NONE)
         fma_ok = lif_fma_is_exact(*wgmin, a.nrn.k_log2, a.T, a.u0 != nullptr);
-      if (NF == NF_MUL0 && LUTM == LUT_CHANNEL && fma_ok) run_chunk(std::true_type{});
+      if (NF == NF_MUL0 && LUTM != LUT_NONE && fma_ok) run_chunk(std::true_type{});
       else run_chunk(std::false_type{});
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);

@@ -257,6 +257,27 @@ __device__ __forceinline__ bool lif_fma_is_exact(uint32_t min_x_bits, int j, int
   return min_x_bits >= need;
 }
 
+// Smallest non-zero |BatchNorm_c(entry)| (as float32 bits) over the shared table and the 128
+// channels of a workgroup: the `min_x_bits` of lif_fma_is_exact for the kernels that apply
+// BatchNorm in the epilogue.  Same operation order as the epilogue.  nthreads % 128 == 0,
+// so a thread keeps one channel.
+__device__ __forceinline__ uint32_t lut_bn_min_bits(const float *lut, int bound, const BnP &bn,
+                                                    int cout0, int Cout, int tid, int nthreads) {
+  int c = cout0 + (tid & 127);
+  if (c >= Cout) c = Cout - 1;
+  float mean = 0.f, mul = 1.f, bias = 0.f;
+  if (bn.mean) { mean = bn.mean[c]; mul = bn.mul[c]; bias = bn.bias[c]; }
+  uint32_t mb = 0x7F800000u;
+  for (int i = tid >> 7; i <= 2 * bound; i += nthreads >> 7) {
+    float x = lut[i] - mean;
+    x = x * mul;
+    x = x + bias;
+    const uint32_t b = __float_as_uint(x) & 0x7FFFFFFFu;
+    if (b != 0 && b < mb) mb = b;
+  }
+  return mb;
+}
+
 // Dequantised currents of two accumulator registers (two pixels, same channel).
 // Table modes: the register is the LDS address of its entry.  Otherwise packed
 // float32 ops (v_pk_*_f32 keep every rounding of the scalar sequence).

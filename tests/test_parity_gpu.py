@@ -558,7 +558,8 @@ def test_conv_block_pipeline_tails(dev, oracle, T):
 @pytest.mark.parametrize("mode", ["channel", "channel_nobn", "shared_counts", "shared_8bit",
                                   "none_xmax", "c128_none", "channel_cout160",
                                   "c128_i8_5bit", "c128_i8_8bit", "c128_fp6_cout160",
-                                  "channel_tiny_currents", "channel_T40", "none_u8_255"])
+                                  "channel_tiny_currents", "channel_T40", "none_u8_255",
+                                  "shared_tiny_currents", "shared_T40"])
 def test_conv_block_table_modes(dev, oracle, mode):
   """The MFMA kernels dequantise through LDS tables when the accumulator bound
   allows (per-channel tables with BatchNorm folded in, one shared table, or plain
@@ -566,7 +567,7 @@ def test_conv_block_table_modes(dev, oracle, mode):
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
   cin, hw, bits, cout, lam, x_hint = 2, 16, 4, 128, None, None
-  if mode == "shared_8bit":
+  if mode in ("shared_8bit", "shared_tiny_currents", "shared_T40"):
     bits = 8
   if mode.startswith("c128"):
     cin, hw = 128, 8
@@ -579,15 +580,16 @@ def test_conv_block_table_modes(dev, oracle, mode):
   # conv0 runs the membrane update as one fused multiply-add when the table proves no
   # subnormal can arise within T steps; channel_tiny_currents (currents ~2^-126: subnormal membrane potentials) and
   # a carried-in u0 (below) must take the two-step form, channel_T40 the fused one
-  T = 40 if mode == "channel_T40" else 4
+  # (the shared-table kernel proves the same from BatchNorm of every table entry)
+  T = 40 if mode.endswith("_T40") else 4
   c = cases.conv_block_case(T=T, B=3, hw=hw, cin=cin, cout=cout, bits=bits, seed=1201,
                             gain=5.0 if cin > 2 else 4.0, random_bn=mode != "channel_nobn")
-  if mode == "channel_tiny_currents":
+  if mode.endswith("tiny_currents"):
     z, one = np.zeros(cout, F32), np.ones(cout, F32)
     c["bn"] = dict(mean=z, var=one, scale=(one * F32(2.0 ** -126)).astype(F32), bias=z, eps=0.0)
   x = c["x"]
   if cin == 2:
-    if mode.startswith("channel") or mode == "shared_8bit":
+    if mode.startswith("channel") or mode in ("shared_8bit", "shared_tiny_currents", "shared_T40"):
       x = np.minimum(x, 1).astype(np.uint8)              # binary events: bound = sum |code|
     elif mode == "shared_counts":
       x = (x * 5).astype(np.uint8)                        # counts up to ~20
@@ -614,7 +616,7 @@ def test_conv_block_table_modes(dev, oracle, mode):
   if mode == "c128_none":
     x_max = 0                                             # no bound given: arithmetic dequant
   bn = _bn(c["bn"], dev) if mode != "channel_nobn" else None
-  if mode == "channel_tiny_currents":
+  if mode.endswith("tiny_currents"):
     bn = ops.BnCoeffs(_t(c["bn"]["mean"], dev), _t(c["bn"]["scale"], dev), _t(c["bn"]["bias"], dev))
   if bn is None:
     qw = qweight_of(oracle, c["leaf"], c["bits"])
