@@ -81,7 +81,11 @@ typedef struct {
   const void *w;
   float L;
   float m;
-  int32_t abs_sum_max; /* W_I8: max over outputs of sum_k |code|; 0 = unknown */
+  int32_t abs_sum_max; /* W_I8: a bound of |acc| per unit of input: with the non-negative
+                        * inputs of the integer kernels (spikes, counts <= x_max),
+                        * |acc| <= abs_sum_max * x_max.  Tightest: max over outputs of
+                        * max(sum of positive codes, sum of |negative codes|); the
+                        * max of sum_k |code| is valid too.  0 = unknown */
   int32_t code_max;    /* W_I8: max |code|; 0 = unknown.  Codes of magnitude <= 7 are
                           exact in fp6 (e2m3) and may take the f8f6f4 MFMA */
 } snnqp_weight_t;

@@ -120,6 +120,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   constexpr int LUT_OFF = TAB_OFF + F6_TAB;
   constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
   constexpr int LUT_ZERO = LUT_OFF + 4 * LUT_CAP;
+  static_assert(LUT_ZERO < 65536, "the table's centre must be a ds_read immediate offset");
   constexpr int OB_OFF = LUT_OFF + LUT_BYTES;
   __shared__ __attribute__((aligned(16))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16];
   uint32_t *obuf = (uint32_t *)(lds + OB_OFF);

@@ -383,12 +383,19 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
-    // the kernel is compiled for SNNQP_U8C2_WPS workgroups per CU: stage fewer timesteps per
-    // pass rather than lose one of them to LDS (T >= 32 with the per-channel tables took
-    // 54 KiB and ran two per CU: 11.2 against 7.9 ms per 20480 sample-steps)
-    const size_t per_wg = (size_t)(160 * 1024) / SNNQP_U8C2_WPS - 1024;
+    // LDS decides how many workgroups share a CU (every variant needs < 128 VGPRs: up to four
+    // waves per SIMD): stage fewer timesteps per pass rather than lose a workgroup to LDS --
+    // four per CU measured 7.1 ms on the headline shape, three 7.8, two 11.2
     const size_t lds_rest = lds_fixed - (size_t)a.tchunk * HIMG2 + u8c2_table_bytes(lm, a.lut_bound);
-    while (a.tchunk > 8 && (size_t)a.tchunk * HIMG2 + lds_rest > per_wg) a.tchunk -= 8;
+    for (int wgs = 4; wgs >= 2; --wgs) {
+      const size_t per_wg = (size_t)(160 * 1024) / wgs - 1024;
+      int tc = a.tchunk;
+      while (tc > 16 && (size_t)tc * HIMG2 + lds_rest > per_wg) tc -= 8;
+      if ((size_t)tc * HIMG2 + lds_rest <= per_wg) {
+        a.tchunk = tc;
+        break;
+      }
+    }
     const size_t ldsb = (size_t)a.tchunk * HIMG2 + lds_rest;
     if (lutc) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_CHANNEL, ldsb);
     else if (lut) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_SHARED, ldsb);

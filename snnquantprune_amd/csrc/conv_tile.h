@@ -50,7 +50,10 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
 //                as well (conv0: |acc| <= LUT2_CAP), so the epilogue starts at the
 //                membrane update
 enum { LUT_NONE = 0, LUT_SHARED = 1, LUT_CHANNEL = 2 };
-constexpr int LUT_CAP = 2047;
+// 4095: a 32 KiB table.  conv0 on event counts with 8-bit codes (|acc| <= sum|w| * x_max, a few
+// thousand) then still dequantises by table and keeps three workgroups per CU; in the bits
+// kernel the entry of acc = 0 stays an instruction immediate (< 64 KiB from the LDS base).
+constexpr int LUT_CAP = 4095;
 #ifndef SNNQP_LUT2_CAP
 #define SNNQP_LUT2_CAP 40
 #endif

@@ -114,7 +114,7 @@ class Weight:
   L: float = 1.0
   m: float = 1.0
   wt: Optional[torch.Tensor] = None
-  abs_sum_max: int = 0      # max over outputs of sum_k |code| (bounds |acc|)
+  abs_sum_max: int = 0      # |acc| <= abs_sum_max * x_max (max one-sided code sum over the outputs)
   code_max: int = 0         # max |code| (<= 7: exact in fp6)
 
   def struct(self) -> L.WeightT:

@@ -64,8 +64,12 @@ class PackedKernel:
                                    want_fq=False, want_codes=True)
     if int(flags.item()) & (L.FLAG_CODE_OVERFLOW | L.FLAG_MASK_NOT_BINARY):
       return None
-    mag = codes.reshape(-1, codes.shape[-1]).to(torch.int32).abs()
-    stats = torch.stack([mag.sum(0).max(), mag.max()]).tolist()     # one readback
+    c2 = codes.reshape(-1, codes.shape[-1]).to(torch.int32)
+    # inputs of the integer kernels are never negative (spikes, event counts), so an
+    # accumulator lies in [-sum of |negative codes|, +sum of positive codes] * x_max: the
+    # larger one-sided sum over the outputs bounds |acc| (about half of sum |code|)
+    side = torch.maximum(c2.clamp(min=0).sum(0).max(), (-c2).clamp(min=0).sum(0).max())
+    stats = torch.stack([side, c2.abs().max()]).tolist()             # one readback
     self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=int(stats[0]),
                            code_max=int(stats[1]))
     return self._int

@@ -608,7 +608,7 @@ def test_conv_block_table_modes(dev, oracle, mode):
   if mode.startswith("channel"):
     assert 0 < bound <= 40, bound
   elif mode.startswith("shared"):
-    assert 40 < bound <= 2047 and x_max <= 31, (bound, x_max)
+    assert 40 < bound <= 4095 and x_max <= 31, (bound, x_max)
   elif mode == "none_xmax":
     assert 31 < x_max <= 127
   elif mode == "none_u8_255":
