@@ -122,7 +122,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   constexpr int LUT_ZERO = LUT_OFF + 4 * LUT_CAP;
   static_assert(LUT_ZERO < 65536, "the table's centre must be a ds_read immediate offset");
   constexpr int OB_OFF = LUT_OFF + LUT_BYTES;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16 + 16];
+  uint32_t *nxt = (uint32_t *)(lds + OB_OFF + SLOTS * NPIX * 16);   // claimed patch (PatchWalk)
   uint32_t *obuf = (uint32_t *)(lds + OB_OFF);
   const uint32_t lds0 = lds_addr(lds) & 0x3FFFFu;   // < 2^18: offsets fold into immediates
 
@@ -212,7 +213,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 #endif
 
   PatchWalk pw(a);
-  for (int64_t r = pw.first; r < pw.count; r += pw.stride) {
+  int r = (int)pw.first;                 // patch indices fit 31 bits (launch check)
+  while (r < (int)pw.count) {
+    int r_next = r + (int)pw.stride;
+    if (pw.queue && tid == 0) r_next = (int)pw.claim(); // next patch, a patch ahead
     int b, y0, x0;
     pw.decode(a, r, b, y0, x0);
 
@@ -458,7 +462,14 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       flush_ring<POOL, SLOTS, 512>(obuf, a, done, a.T - done, b, y0, x0, tid);
     }
     if (a.u_out && wave_on) u_io_tile<false>(u, a, b, y0, x0, cout, h, role);
+    if (pw.queue) {                      // the claimed patch, to the whole workgroup
+      if (tid == 0) nxt[0] = (uint32_t)r_next;
+      lds_barrier();
+      r_next = __builtin_amdgcn_readfirstlane((int)nxt[0]);
+    }
+    r = r_next;
   }
+  if (pw.queue && tid == 0) pw.finish();
 }
 
 template <int FMT, int CIN, int NF>

@@ -10,6 +10,7 @@
 // dequant / BatchNorm constants are per-lane registers, the membrane potentials of a
 // tile stay in 16 VGPRs for all T, and the v_cmp that thresholds a register *is* the
 // packed spike word of two pixels (64-bit lane mask); pooling is an OR of those masks.
+#include <mutex>
 #include <type_traits>
 
 #include "conv_tile.h"
@@ -20,20 +21,28 @@ namespace snnqp {
 // Diagnostic build only (python csrc/build.py with SNNQP_PROBE=1): shader-clock
 // and 100 MHz real-time stamps of workgroup 0 around the persistent loop, to
 // read the clock the chip sustains inside this kernel.  Never in the product.
-__device__ unsigned long long snnqp_clock_probe[4];
-extern "C" int snnqp_debug_read_probe(unsigned long long *out4) {
-  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(snnqp_clock_probe), 32);
+__device__ unsigned long long snnqp_clock_probe[5];
+__device__ unsigned int snnqp_wg_span[2 * 4096];   // per workgroup: start, end (100 MHz ticks, low 32 bits)
+extern "C" int snnqp_debug_read_wg_span(unsigned int *out8192) {
+  return (int)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(snnqp_wg_span), 8192 * 4);
+}
+extern "C" int snnqp_debug_read_probe(unsigned long long *out5) {
+  return (int)hipMemcpyFromSymbol(out5, HIP_SYMBOL(snnqp_clock_probe), 40);
 }
 #define PROBE_BEGIN()                                                        \
   unsigned long long pc0 = 0, pr0 = 0;                                       \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)              \
+    snnqp_wg_span[2 * blockIdx.x] = (unsigned int)__builtin_amdgcn_s_memrealtime(); \
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {              \
     pc0 = __builtin_amdgcn_s_memtime();                                      \
     pr0 = __builtin_amdgcn_s_memrealtime();                                  \
   }
 #define PROBE_END()                                                          \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)              \
+    snnqp_wg_span[2 * blockIdx.x + 1] = (unsigned int)__builtin_amdgcn_s_memrealtime(); \
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {              \
     snnqp_clock_probe[0] = __builtin_amdgcn_s_memtime() - pc0;               \
-    snnqp_clock_probe[1] = __builtin_amdgcn_s_memrealtime() - pr0;           \
+    snnqp_clock_probe[4] = __builtin_amdgcn_s_memrealtime() - pr0;           \
   }
 #define PHASE_DECL() unsigned long long ph_t = 0, ph_acc[3] = {0, 0, 0};
 #define PHASE_START() ph_t = __builtin_amdgcn_s_memtime();
@@ -203,7 +212,10 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   PHASE_DECL()
   PROBE_BEGIN()
   PatchWalk pw(a);
-  for (int64_t r = pw.first; r < pw.count; r += pw.stride) {
+  int r = (int)pw.first;                 // patch indices fit 31 bits (launch check)
+  while (r < (int)pw.count) {
+    int r_next = r + (int)pw.stride;
+    if (pw.queue && tid == 0) r_next = (int)pw.claim(); // next patch, a patch ahead
     int b, y0, x0;
     pw.decode(a, r, b, y0, x0);
 
@@ -287,7 +299,14 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       else run_chunk(std::false_type{});
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
+    if (pw.queue) {                      // the claimed patch, to the whole workgroup
+      if (tid == 0) wgmin[2] = (uint32_t)r_next;
+      lds_barrier();
+      r_next = __builtin_amdgcn_readfirstlane((int)wgmin[2]);
+    }
+    r = r_next;
   }
+  if (pw.queue && tid == 0) pw.finish();
   PROBE_END()
   PHASE_DUMP()
 }
@@ -295,6 +314,27 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+
+uint32_t *sched_slot(int dev, hipStream_t st) {
+  static std::mutex mu;
+  static uint32_t *pool[64] = {nullptr};
+  static unsigned next[64] = {0};
+  if (dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool[dev]) {
+    uint32_t *p = nullptr;
+    const size_t bytes = (size_t)SCHED_SLOTS * SCHED_WORDS * sizeof(uint32_t);
+    if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
+    // zeroed on the launch stream's device before the first user; the memset is ordered
+    // before that launch on `st`, later launches find the slots zeroed by their last users
+    if (hipMemsetAsync(p, 0, bytes, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    pool[dev] = p;
+  }
+  return pool[dev] + (size_t)(next[dev]++ % SCHED_SLOTS) * SCHED_WORDS;
+}
 
 const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                      const snnqp_weight_t *w, const int8_t *wt,

@@ -38,7 +38,7 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
 #define SNNQP_U8C2_UNROLL 1
 #endif
 #ifndef SNNQP_U8C2_WPS
-#define SNNQP_U8C2_WPS 3    // waves per SIMD the conv0 kernel is compiled for (168 VGPRs; uses ~135)
+#define SNNQP_U8C2_WPS 4    // waves per SIMD the conv0 kernel is compiled for (128 VGPRs)
 #endif
 
 // Dequantisation by LDS table (fast neuron path only).  The accumulator is made
@@ -93,7 +93,14 @@ struct ConvMfmaArgs {
   int32_t lut_bound;  // > 0: |acc| <= lut_bound guaranteed, dequant by LDS table
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
+  uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk
 };
+
+// Work queues of one launch: per blockIdx.y, one patch counter per XCD queue and one count
+// of finished workgroups (the last one zeroes the words for the slot's next user).
+constexpr int SCHED_Y = 8;                  // blockIdx.y values a slot serves (Cout <= 1024)
+constexpr int SCHED_WORDS = SCHED_Y * 16;   // words of one slot
+constexpr int SCHED_SLOTS = 64;             // launches in flight per device
 
 // 16 spike bits -> 16 bytes {0, 1} (or {0, 4} when the accumulator indexes a table)
 template <bool X4>
@@ -117,6 +124,8 @@ struct PatchWalk {
   int64_t first, count, stride;
   int ppb, xcd;
   bool split;
+  uint32_t *queue;    // this workgroup's patch counter, or null
+  uint32_t *done;
   __device__ __forceinline__ explicit PatchWalk(const ConvMfmaArgs &a) {
     ppb = a.tiles_y * a.tiles_x;
     split = a.xcd_split != 0;
@@ -130,6 +139,27 @@ struct PatchWalk {
       first = blockIdx.x;
       stride = gridDim.x;
       count = a.npatch;
+    }
+    queue = a.sched ? a.sched + blockIdx.y * 16 + xcd : nullptr;
+    done = a.sched ? a.sched + blockIdx.y * 16 + 8 : nullptr;
+  }
+  // Dynamic schedule: the first patch of a workgroup is its static one; every further patch
+  // is claimed from the queue (workgroups that the CU's oldest-first issue favours finish
+  // their patches sooner and would otherwise idle while the youngest still has a quarter
+  // of its static share left: 4.75 against 7.44 ms measured inside conv0).  One thread
+  // claims, a patch ahead so that the atomic's round trip hides behind the patch.
+  __device__ __forceinline__ int64_t claim() const {
+    return stride + (int64_t)atomicAdd(queue, 1u);
+  }
+  // after the last claim of the workgroup (one thread): count it; the last of the launch
+  // zeroes the slot
+  __device__ __forceinline__ void finish() const {
+    __threadfence();
+    const uint32_t total = gridDim.x;
+    if (atomicAdd(done, 1u) + 1u == total) {
+      for (int i = 0; i < 8; ++i) done[i - 8] = 0u;
+      __threadfence();
+      *done = 0u;
     }
   }
   __device__ __forceinline__ void decode(const ConvMfmaArgs &a, int64_t r, int &b, int &y0,
@@ -506,6 +536,11 @@ __device__ __forceinline__ v16i splat16(int v) {
   return v16i{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
 }
 
+// Work-queue words for a launch: a per-device pool of zeroed slots, handed out round-robin
+// (a launch leaves its slot zeroed; SCHED_SLOTS launches may be in flight per device).
+// Allocated once per device and kept for the life of the process.  null -> static walk.
+uint32_t *sched_slot(int dev, hipStream_t st);
+
 template <typename K>
 static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st,
                                      size_t dyn_lds = 0, int threads = 256) {
@@ -523,6 +558,11 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
     gx &= ~7u;
     a.xcd_split = 1;
   }
+#ifdef SNNQP_STATIC_WALK          // diagnostic build: the static patch walk
+  a.sched = nullptr;
+#else
+  a.sched = gy <= (unsigned)SCHED_Y && a.npatch < (1ll << 30) ? sched_slot(dev, st) : nullptr;
+#endif
   hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(threads), dyn_lds, st, a);
 }
 
