@@ -12,10 +12,10 @@
 //  * wider codes (8-bit DuQ, the reference's shipped configs): v_mfma_i32_32x32x32_i8,
 //    A = spikes as bytes, B = the int8 codes, 36 k-steps instead of 18.
 //
-// A workgroup is 8 waves on one 8x8-pixel patch, two waves per SIMD: wave w owns
-// output channels [32 (w & 3), +32) of tile w >> 2 (4x8 pixels), its B fragments for
+// A workgroup is 4 waves on one 4x8-pixel tile (patch), two workgroups per CU = two waves
+// per SIMD: wave w owns output channels [32 w, +32) of the tile, its B fragments for
 // the whole launch (108 registers fp6, 144 int8), the tile's membrane potentials and two
-// accumulator sets.  The loop is software-pipelined over t inside each wave: the
+// accumulator sets.  (SNNQP_BITS_TILES = 2: 8 waves on an 8x8 patch, wave w on tile w >> 2.)  The loop is software-pipelined over t inside each wave: the
 // MFMAs of step t + 1 alternate with the instructions of the neuron epilogue of step
 // t; one workgroup barrier per step.  (Two waves per SIMD measured 10-20 % faster than
 // the one-wave, two-tiles-per-wave form of the int8 kernel this file replaced.)
@@ -39,7 +39,18 @@ typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
 
 // k-steps of 64: (tap, 64-channel group); Cin = 64 or 128 (template parameter CIN)
 constexpr int F6_PITCH = HPITCH;             // pixels per LDS halo row (10 used)
-constexpr int F6_PLANE = HPLANE;             // one k-step plane of a halo image (conv_tile.h)
+// 4x8-pixel tiles of a workgroup's patch.  1: a workgroup is 4 waves on a 4x8 patch and two
+// of them share a CU -- while one sits at its per-step barrier (the waves of a workgroup
+// drift apart; removing the barrier measured -7 %) the other's waves have the SIMDs: conv1
+// 6.68 -> 6.15 ms although the halo staged per output grows from 100/64 to 60/32 pixels.
+// 2: the 8-wave workgroup on an 8x8 patch, one per CU.
+#ifndef SNNQP_BITS_TILES
+#define SNNQP_BITS_TILES 1
+#endif
+constexpr int F6_TILES = SNNQP_BITS_TILES;
+constexpr int F6_ROWS = 4 * F6_TILES + 2;    // halo rows of a patch
+constexpr int F6_NT = 256 * F6_TILES;        // threads of a workgroup: 4 waves per tile
+constexpr int F6_PLANE = F6_ROWS * HPITCH * 32;   // one k-step plane of a halo image
 constexpr int F6_TAB = 1024;                 // byte -> 8 fp4 nibbles
 #ifndef SNNQP_F6_PREFETCH
 #define SNNQP_F6_PREFETCH 4
@@ -101,7 +112,7 @@ extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
 enum { FMT_FP6 = 0, FMT_I8 = 1 };
 
 template <int FMT, int CIN, int NF, bool POOL, bool LUT>
-__global__ void __launch_bounds__(512, 1)
+__global__ void __launch_bounds__(F6_NT, 2 / F6_TILES)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
   constexpr bool I8 = FMT == FMT_I8;
@@ -115,7 +126,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   constexpr int PPS = (32 + F6_KS - 1) / F6_KS;  // epilogue pieces per MFMA slot
   constexpr int FL = POOL ? 16 : 4;              // timesteps per flush block
   constexpr int SLOTS = 2 * FL;                  // ring of staged spike words
-  constexpr int NPIX = OutStage<POOL>::NPIX;
+  constexpr int NPIX = OutStage<POOL>::NPIX * F6_TILES / 2;
   constexpr int TAB_OFF = 2 * F6_HALO;
   constexpr int LUT_OFF = TAB_OFF + F6_TAB;
   constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
@@ -129,7 +140,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
-  const int role = wave >> 2;                    // the tile (4x8 pixels) of this wave
+  const int role = F6_TILES == 2 ? wave >> 2 : 0;   // the tile (4x8 pixels) of this wave
   const int cg = wave & 3;
   const int cout_base = blockIdx.y * 128 + cg * 32;
   const bool wave_on = cout_base < a.Cout;
@@ -147,7 +158,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   // the entry of acc = 0 sits at the fixed byte LUT_ZERO whatever the launch's bound is,
   // so the table read takes the (signed) accumulator as its address register and
   // LUT_ZERO as the instruction's immediate offset
-  if (LUT) build_lut((float *)(lds + LUT_OFF) + (LUT_CAP - a.lut_bound), a.lut_bound, a.dq, tid, 512);
+  if (LUT) build_lut((float *)(lds + LUT_OFF) + (LUT_CAP - a.lut_bound), a.lut_bound, a.dq, tid, F6_NT);
 
   // B operand: k-step ks = NP tap + kk covers channels 64 kk .. +63 of the tap; lane
   // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile WPP tap + 2 kk + h
@@ -193,7 +204,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
   // staging task of this thread: word wi of halo pixel pix
   const int s_pix = tid / WPP, s_wi = tid % WPP;
-  const bool s_task = tid < HALO * HALO * WPP;
+  const bool s_task = tid < F6_ROWS * HALO * WPP;
   // a pixel has ceil(Cin / 32) spike words in memory; the planes beyond them (Cin below
   // the template's 64 / 128) are zero spikes against zero codes
   const int wpm = (a.Cin + 31) >> 5;
@@ -420,7 +431,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     auto step = [&](int t, acc_t &accN, const acc_t &accC) {
 #if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 8))   // diagnostic build: no flush
       if (t >= FL && t % FL == 0)                // steps < t are behind a barrier
-        flush_ring<POOL, SLOTS, 512>(obuf, a, t - FL, FL, b, y0, x0, tid);
+        flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, t - FL, FL, b, y0, x0, tid);
 #endif
       F6_MARK(0)
       stage_begin(t + 2);
@@ -459,7 +470,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     lds_barrier();
     {
       const int done = a.T >= 2 ? ((a.T - 2) / FL) * FL : 0;
-      flush_ring<POOL, SLOTS, 512>(obuf, a, done, a.T - done, b, y0, x0, tid);
+      flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, done, a.T - done, b, y0, x0, tid);
     }
     if (a.u_out && wave_on) u_io_tile<false>(u, a, b, y0, x0, cout, h, role);
     if (pw.queue) {                      // the claimed patch, to the whole workgroup
@@ -475,10 +486,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 template <int FMT, int CIN, int NF>
 static void launch_fp6_nf(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
                           hipStream_t st) {
-  if (pool && lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, true>, a, gy, st, 0, 512);
-  else if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, false>, a, gy, st, 0, 512);
-  else if (lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, true>, a, gy, st, 0, 512);
-  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, false>, a, gy, st, 0, 512);
+  if (pool && lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, true>, a, gy, st, 0, F6_NT);
+  else if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, false>, a, gy, st, 0, F6_NT);
+  else if (lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, true>, a, gy, st, 0, F6_NT);
+  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, false>, a, gy, st, 0, F6_NT);
 }
 
 template <int FMT, int CIN>
@@ -491,8 +502,12 @@ static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, u
 }
 
 // i8: codes wider than fp6 holds (|code| > 7) -> the int8 instruction
-void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, bool lut, unsigned gy,
+void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, bool lut, unsigned gy,
                         hipStream_t st) {
+  ConvMfmaArgs a = a0;                       // this kernel's patch: F6_TILES tiles of 4x8 pixels
+  a.patch_h = 4 * F6_TILES;
+  a.tiles_y = (a.H + a.patch_h - 1) / a.patch_h;
+  a.npatch = (int64_t)a.B * a.tiles_y * a.tiles_x;
   if (i8) {
     if (a.Cin <= 64) launch_fp6_cin<FMT_I8, 64>(a, nf, pool, lut, gy, st);
     else launch_fp6_cin<FMT_I8, 128>(a, nf, pool, lut, gy, st);

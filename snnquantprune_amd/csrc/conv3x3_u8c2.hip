@@ -387,6 +387,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.bn = make_bn(bn);
   a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
+  a.patch_h = 8;
   a.tiles_y = (g->H + 7) / 8; a.tiles_x = (g->W + 7) / 8;
   a.npatch = (int64_t)B * a.tiles_y * a.tiles_x;
   const int nf = neuron_form(a.nrn);          // which straight-line epilogue (conv_tile.h)

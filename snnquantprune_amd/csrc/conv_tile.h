@@ -94,6 +94,7 @@ struct ConvMfmaArgs {
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
   uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk
+  int32_t patch_h;    // rows of a patch: 8 (two 4x8 tiles), or 4 (conv3x3_bits.hip, one tile)
 };
 
 // Work queues of one launch: per blockIdx.y, one patch counter per XCD queue and one count
@@ -167,7 +168,7 @@ struct PatchWalk {
     const int within = (int)(r % ppb);
     const int bi = (int)(r / ppb);
     b = split ? xcd + 8 * bi : bi;
-    y0 = (within / a.tiles_x) * 8;
+    y0 = (within / a.tiles_x) * a.patch_h;
     x0 = (within % a.tiles_x) * 8;
   }
 };
@@ -459,10 +460,9 @@ __device__ __forceinline__ int out_pix(int tl, int lane) {
 // Writes timesteps [t0, t0 + n) of the patch at (y0, x0) (full-resolution
 // coordinates) from obuf (a ring of SLOTS timesteps) to global memory.  All NT
 // threads of the workgroup take part.
-template <bool POOL, int SLOTS, int NT>
+template <bool POOL, int SLOTS, int NT, int NPIX = OutStage<POOL>::NPIX>
 __device__ __forceinline__ void flush_ring(const uint32_t *obuf, const ConvMfmaArgs &a,
                                            int t0, int n, int b, int y0, int x0, int tid) {
-  constexpr int NPIX = OutStage<POOL>::NPIX;
   constexpr int PW = POOL ? 4 : 8;              // patch width in output pixels
   const int CW = (a.Cout + 31) >> 5;
   const int cwb = blockIdx.y * 4;
