@@ -1,0 +1,67 @@
+"""Randomised shapes through the fused conv block: the MFMA kernels (work queue, clipped
+edge patches, masked channel words, padded Cin, both operand formats, conv0 variants)
+against the direct-form kernel on the same inputs, bit for bit."""
+import numpy as np
+import torch
+
+
+def conv_block_random(dev, N, seed, verbose=False):
+  """Runs N random geometries; returns the descriptions of the mismatching ones."""
+  from snnquantprune_amd import _lib as L, ops, packing, synthetic as syn
+  from snnquantprune_amd.quant import QuantDesc
+  rng = np.random.Generator(np.random.PCG64(seed))
+  failures = []
+  for it in range(N):
+    first = rng.random() < 0.35                      # a 2-channel event layer (conv0 kernel)
+    cin = 2 if first else int(rng.integers(3, 129))
+    cout = int(rng.choice([32, 64, 96, 100, 128, 160, 256, 300]))
+    H, W = int(rng.integers(3, 41)), int(rng.integers(3, 41))
+    T, B = int(rng.integers(1, 10)), int(rng.integers(1, 21))
+    bits = int(rng.choice([3, 4, 5, 8]))
+    pool = int(rng.choice([1, 2]))
+    if pool == 2:
+      H, W = H + (H & 1), W + (W & 1)
+    leaf = syn.quant_leaf((3, 3, cin, cout), float(rng.uniform(3, 7)), int(rng.integers(1 << 30)), True,
+                          float(rng.choice([0.0, 0.5, 0.9])))
+    a = float(leaf["DuQ_0"]["a"][0])
+    Lq = float(2 ** (bits - 1) - 1)
+    pk = packing.PackedKernel(torch.from_numpy(leaf["kernel"]).to(dev), QuantDesc(L.Q_DUQ, bits, a, a, Lq, a),
+                              torch.from_numpy(leaf["prune_0"]["mask"]).to(dev))
+    w = pk.int_weight_mfma((cout + 31) // 32 * 32)
+    if first:
+      kind = rng.choice(["binary", "counts", "big"])
+      lam = {"binary": 0.2, "counts": 0.6, "big": 20.0}[kind]
+      x = torch.from_numpy(np.minimum(rng.poisson(lam, (T, B, H, W, cin)), 255).astype(np.uint8)).to(dev)
+      if kind == "binary":
+        x = x.clamp(max=1)
+      xin, x_max = x, ops.input_max_bound(x)
+    else:
+      x = torch.from_numpy((rng.random((T, B, H, W, cin)) < 0.2).astype(np.uint8)).to(dev)
+      xin, x_max = ops.pack_bits(x), 1
+    bn = ops.BnCoeffs(torch.from_numpy(rng.normal(0, 0.2, cout).astype(np.float32)).to(dev),
+                      torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev),
+                      torch.from_numpy(rng.normal(0, 0.2, cout).astype(np.float32)).to(dev))
+    nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, float(rng.choice([2.0, 4.0, 3.0])), 1.0, float(rng.choice([0.0, 0.1])))
+    g = ops.ConvGeom(H, W, cin, cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+    u0 = None
+    if rng.random() < 0.3:
+      u0 = torch.from_numpy(rng.normal(0, 0.3, (B, H, W, cout)).astype(np.float32)).to(dev)
+    tag = "cin %d cout %d %dx%d T %d B %d bits %d pool %d x_max %d u0 %s" % (
+        cin, cout, H, W, T, B, bits, pool, x_max, u0 is not None)
+    try:
+      um, sm = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, u0=u0, packed_out=True, pool=pool,
+                                    impl=L.IMPL_MFMA, x_max=x_max)
+    except L.SnnqpError as e:
+      if verbose:
+        print("skip (%s): %s" % (tag, str(e)[:60]))
+      continue
+    ug, sg = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, u0=u0, packed_out=True, pool=1,
+                                  impl=L.IMPL_GENERIC, x_max=x_max)
+    if pool == 2:
+      sg = ops.maxpool2x2(sg)
+    ok = torch.equal(sm.bits, sg.bits) and torch.equal(um, ug)
+    if not ok:
+      failures.append(tag)
+    if verbose:
+      print("%s  %s  rate %.3f" % ("ok  " if ok else "FAIL", tag, float(sg.to_dense().float().mean())))
+  return failures

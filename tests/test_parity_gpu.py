@@ -1223,3 +1223,12 @@ def test_event_front_end_and_density_probes(dev, oracle):
   for inp in (_t(s, dev), ops.pack_bits(_t(s, dev))):
     np.testing.assert_array_equal(_np(ops.density(inp, counts=True)), nnz)     # exact counts
     np.testing.assert_allclose(_np(ops.density(inp)), oracle.density(s), rtol=2e-7)
+
+
+def test_conv_block_random_shapes(dev):
+  """40 random geometries (image sizes 3..40, Cin 2..128, Cout 32..300, T, B, pool, 3/4/5/8-bit
+  codes, binary / count / large-count events, carried-in potentials): the MFMA kernels --
+  work-queue schedule, clipped edge patches, masked channel words, padded Cin, fp6 and int8
+  formats, every conv0 table mode -- equal the direct-form kernel bit for bit."""
+  from tests.stress import conv_block_random
+  assert conv_block_random(dev, 40, 20261004) == []
