@@ -65,3 +65,50 @@ def conv_block_random(dev, N, seed, verbose=False):
     if verbose:
       print("%s  %s  rate %.3f" % ("ok  " if ok else "FAIL", tag, float(sg.to_dense().float().mean())))
   return failures
+
+
+def dense_block_random(dev, N, seed, verbose=False):
+  """Random dense SpikingBlocks (K 1..6000 not a multiple of anything, any N, T up to 60,
+  3..8-bit codes, every neuron form): the MFMA kernel against the direct-form kernel."""
+  from snnquantprune_amd import _lib as L, ops, packing, synthetic as syn
+  from snnquantprune_amd.quant import QuantDesc
+  rng = np.random.Generator(np.random.PCG64(seed))
+  failures = []
+  for it in range(N):
+    K = int(rng.choice([rng.integers(1, 200), rng.integers(200, 6000), 2048, 512, 784]))
+    n_out = int(rng.choice([rng.integers(1, 40), 110, 100, 512, rng.integers(100, 600)]))
+    T, B = int(rng.integers(1, 61)), int(rng.integers(1, 40))
+    bits = int(rng.choice([3, 4, 5, 8]))
+    leaf = syn.quant_leaf((K, n_out), float(rng.uniform(2, 8)), int(rng.integers(1 << 30)), True,
+                          float(rng.choice([0.0, 0.5, 0.9])))
+    a = float(leaf["DuQ_0"]["a"][0])
+    pk = packing.PackedKernel(torch.from_numpy(leaf["kernel"]).to(dev),
+                              QuantDesc(L.Q_DUQ, bits, a, a, float(2 ** (bits - 1) - 1), a),
+                              torch.from_numpy(leaf["prune_0"]["mask"]).to(dev))
+    w = pk.int_weight_mfma((n_out + 31) // 32 * 32)
+    x = ops.pack_bits(torch.from_numpy((rng.random((T, B, K)) < rng.uniform(0.02, 0.4)).astype(np.uint8)).to(dev))
+    kind = rng.choice(["ms2", "ms3", "plif", "lif", "vr"])
+    if kind == "plif":
+      nrn = ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, float(1.0 / (1.0 + np.exp(0.35))), 1.0, 0.0)
+    elif kind == "lif":
+      dec = torch.from_numpy((1.0 / (1.0 + np.exp(-rng.uniform(-1, 2, n_out)))).astype(np.float32)).to(dev)
+      nrn = ops.Neuron(L.NEURON_LIF, 1.0, 1.0, 0.0, decay=dec)
+    else:
+      nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0 if kind == "ms3" else 2.0, 1.0, 0.1 if kind == "vr" else 0.0)
+    u0 = None
+    if rng.random() < 0.3:
+      u0 = torch.from_numpy(rng.normal(0, 0.3, (B, n_out)).astype(np.float32)).to(dev)
+    tag = "K %d N %d T %d B %d bits %d %s u0 %s" % (K, n_out, T, B, bits, kind, u0 is not None)
+    try:
+      um, sm = ops.dense_lif_forward(x, w, K, n_out, nrn, u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+    except L.SnnqpError as e:
+      if verbose:
+        print("skip (%s): %s" % (tag, str(e)[:60]))
+      continue
+    ug, sg = ops.dense_lif_forward(x, w, K, n_out, nrn, u0=u0, packed_out=True, impl=L.IMPL_GENERIC)
+    ok = torch.equal(sm.bits, sg.bits) and torch.equal(um, ug)
+    if not ok:
+      failures.append(tag)
+    if verbose:
+      print("%s  %s  rate %.3f" % ("ok  " if ok else "FAIL", tag, float(sg.to_dense().float().mean())))
+  return failures

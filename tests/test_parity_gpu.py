@@ -1232,3 +1232,10 @@ def test_conv_block_random_shapes(dev):
   formats, every conv0 table mode -- equal the direct-form kernel bit for bit."""
   from tests.stress import conv_block_random
   assert conv_block_random(dev, 40, 20261004) == []
+
+
+def test_dense_block_random_shapes(dev):
+  """40 random dense blocks (any K and N, T up to 60, every neuron form, carried-in potentials):
+  the MFMA kernel equals the direct-form kernel bit for bit."""
+  from tests.stress import dense_block_random
+  assert dense_block_random(dev, 40, 20261005) == []
