@@ -252,9 +252,50 @@ _u8_flag_cache = None
 def forget_inputs():
   """Drops the cached facts about activation tensors (their maxima), as if every
   tensor were new: bench.py calls it each step so that the per-batch inspection
-  pass of a fresh input is inside the timed region."""
+  pass of a fresh input is inside the timed region.  Inspections requested ahead with
+  prefetch_input_bound() stay pending: each is consumed by one input_max_bound()."""
   global _u8_flag_cache
   _u8_flag_cache = None
+
+
+_pending_bounds = None
+_inspect_stream = None
+_inspect_bufs = None
+
+
+def prefetch_input_bound(x):
+  """Starts the inspection pass of a uint8 input batch (its maximum count, which selects
+  the first layer's kernel variant) on a side stream, so that the later
+  input_max_bound(x) finds the answer instead of launching the pass and waiting for it
+  in front of the first kernel -- what a serving loop does with the NEXT batch while the
+  current one computes.  `x` must already be produced on the current stream."""
+  global _pending_bounds, _inspect_stream
+  if isinstance(x, PackedSpikes) or x.dtype != torch.uint8 or not x.is_contiguous():
+    return
+  _require_gpu(x)
+  if _pending_bounds is None:
+    from ._cache import TensorCache
+    _pending_bounds = TensorCache(8)
+    _inspect_stream = torch.cuda.Stream(device=x.device)
+  if _pending_bounds.get((x,)) is not None:
+    return
+  global _inspect_bufs
+  if _inspect_bufs is None:                        # pinned words are slow to allocate: a small ring
+    _inspect_bufs = [torch.empty(8, dtype=torch.int32, pin_memory=True),
+                     torch.zeros(8, dtype=torch.int32, device=x.device), 0]
+  host_all, dev_all, k = _inspect_bufs
+  _inspect_bufs[2] = (k + 1) % 8
+  host, flags = host_all[k:k + 1], dev_all[k:k + 1]
+  ready = torch.cuda.Event()
+  ready.record()                                   # x as of now, on the current stream
+  with torch.cuda.stream(_inspect_stream):
+    _inspect_stream.wait_event(ready)
+    flags.zero_()
+    L.check(L.lib().snnqp_inspect_u8(_ptr(x), x.numel(), _ptr(flags), _stream()))
+    host.copy_(flags, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+  _pending_bounds.put((x,), None, (done, host, flags))
 
 
 def input_max_bound(x) -> int:
@@ -269,6 +310,12 @@ def input_max_bound(x) -> int:
     from ._cache import TensorCache
     _u8_flag_cache = TensorCache(16)
   v = _u8_flag_cache.get((x,))
+  if v is None and _pending_bounds is not None:
+    pend = _pending_bounds.get((x,))
+    if pend is not None:                           # requested ahead: wait for that pass only
+      pend[0].synchronize()
+      v = max(1, int(pend[1][0]) >> 8)
+      _u8_flag_cache.put((x,), None, v)
   if v is None:
     _require_gpu(x)
     xc = x.contiguous()
