@@ -14,7 +14,7 @@ def conv_block_random(dev, N, seed, verbose=False):
   for it in range(N):
     first = rng.random() < 0.35                      # a 2-channel event layer (conv0 kernel)
     cin = 2 if first else int(rng.integers(3, 129))
-    cout = int(rng.choice([32, 64, 96, 100, 128, 160, 256, 300]))
+    cout = int(rng.choice([32, 64, 96, 100, 128, 160, 256, 300, 1056]))   # 1056: > 8 channel blocks, static patch walk
     H, W = int(rng.integers(3, 41)), int(rng.integers(3, 41))
     T, B = int(rng.integers(1, 10)), int(rng.integers(1, 21))
     bits = int(rng.choice([3, 4, 5, 8]))
