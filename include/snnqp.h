@@ -92,6 +92,10 @@ typedef struct {
                         * max of sum_k |code| is valid too.  0 = unknown */
   int32_t code_max;    /* W_I8: max |code|; 0 = unknown.  Codes of magnitude <= 7 are
                           exact in fp6 (e2m3) and may take the f8f6f4 MFMA */
+  uint32_t min_current_bits; /* float32 bits of the smallest non-zero |input current| the block
+                          can see with the BatchNorm it is used with -- snnqp_current_min();
+                          lets the conv kernels run u + (x - u) / tau as one fused
+                          multiply-add when that is provably bit-identical.  0 = unknown */
 } snnqp_weight_t;
 
 /* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),
@@ -212,6 +216,13 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            const snnqp_neuron_t *nrn, const float *u0,
                            float *u_out, void *s_out, int s_type, int pool,
                            int impl, int x_max, snnqp_stream_t stream);
+
+/* Smallest non-zero |BatchNorm_c(fl(fl(acc / L) * m))| over |acc| <= bound and the Cout
+ * channels (bn nullable: identity), as float32 bits, atomically min-ed into *out_bits
+ * (device word the caller initialises to 0x7F800000).  For snnqp_weight_t.min_current_bits:
+ * once per (weights, BatchNorm) version. */
+int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound,
+                      int32_t Cout, uint32_t *out_bits, snnqp_stream_t stream);
 
 /* Same for QuantDense: x [T][B][K], weights [K][N] (GENERIC) .
  * IMPL_MFMA additionally needs `wt`: the int8 codes tiled by

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int8,
-                    c_int32, c_int64, c_void_p)
+                    c_int32, c_uint32, c_int64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
@@ -28,7 +28,7 @@ OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 
 class WeightT(Structure):
   _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
-              ("abs_sum_max", c_int32), ("code_max", c_int32)]
+              ("abs_sum_max", c_int32), ("code_max", c_int32), ("min_current_bits", c_uint32)]
 
 
 class BnT(Structure):
@@ -73,6 +73,7 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
         c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "snnqp_current_min": (c_int, [POINTER(WeightT), POINTER(BnT), c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_lif_forward": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(BnT),
                                   POINTER(NeuronT), c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p]),

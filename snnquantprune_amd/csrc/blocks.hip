@@ -37,6 +37,11 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                      u_out, s_out, s_type, nullptr, (hipStream_t)stream);
 }
 
+int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound,
+                      int32_t Cout, uint32_t *out_bits, snnqp_stream_t stream) {
+  return run_current_min(w, bn, bound, Cout, out_bits, (hipStream_t)stream);
+}
+
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,

@@ -111,7 +111,7 @@ extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
 // bit -> operand expansion of the halo and the accumulator type.
 enum { FMT_FP6 = 0, FMT_I8 = 1 };
 
-template <int FMT, int CIN, int NF, bool POOL, bool LUT>
+template <int FMT, int CIN, int NF, bool POOL, bool LUT, bool FMA = false>
 __global__ void __launch_bounds__(F6_NT, 2 / F6_TILES)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
@@ -354,7 +354,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 32)   // diagnostic build: FMA membrane update
           uu = neuron_update<NF, true>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
 #else
-          uu = neuron_update<NF>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
+          uu = neuron_update<NF, FMA, false>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
 #endif
           m0 = __ballot(uu.x >= a.nrn.vth);
           m1 = __ballot(uu.y >= a.nrn.vth);
@@ -408,7 +408,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       v2f y[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = dequant2(acc[2 * j], acc[2 * j + 1]);
-      const uint32_t w = tile_neurons<NF, POOL, false>(y, u, lc, a.nrn);
+      const uint32_t w = tile_neurons<NF, POOL, false, FMA>(y, u, lc, a.nrn);
       if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
     };
     // staging of halo(t2) into its buffer around a step: the table reads go first, the
@@ -502,12 +502,29 @@ static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, u
 }
 
 // i8: codes wider than fp6 holds (|code| > 7) -> the int8 instruction
-void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, bool lut, unsigned gy,
-                        hipStream_t st) {
+// NF_MUL0 with a table and the fused membrane update
+template <int FMT, int CIN>
+static void launch_fp6_fma(const ConvMfmaArgs &a, bool pool, unsigned gy, hipStream_t st) {
+  if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, true, true, true>, a, gy, st, 0, F6_NT);
+  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, false, true, true>, a, gy, st, 0, F6_NT);
+}
+
+void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, bool lut, bool fma,
+                         unsigned gy, hipStream_t st) {
   ConvMfmaArgs a = a0;                       // this kernel's patch: F6_TILES tiles of 4x8 pixels
   a.patch_h = 4 * F6_TILES;
   a.tiles_y = (a.H + a.patch_h - 1) / a.patch_h;
   a.npatch = (int64_t)a.B * a.tiles_y * a.tiles_x;
+  if (fma && lut && nf == NF_MUL0) {
+    if (i8) {
+      if (a.Cin <= 64) launch_fp6_fma<FMT_I8, 64>(a, pool, gy, st);
+      else launch_fp6_fma<FMT_I8, 128>(a, pool, gy, st);
+    } else {
+      if (a.Cin <= 64) launch_fp6_fma<FMT_FP6, 64>(a, pool, gy, st);
+      else launch_fp6_fma<FMT_FP6, 128>(a, pool, gy, st);
+    }
+    return;
+  }
   if (i8) {
     if (a.Cin <= 64) launch_fp6_cin<FMT_I8, 64>(a, nf, pool, lut, gy, st);
     else launch_fp6_cin<FMT_I8, 128>(a, nf, pool, lut, gy, st);

@@ -315,6 +315,29 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
 // host side
 // ---------------------------------------------------------------------------
 
+// snnqp_current_min: one thread per (channel, table slice)
+__global__ void __launch_bounds__(256)
+current_min_kernel(Dequant dq, BnP bn, int bound, int Cout, uint32_t *out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  uint32_t mb = 0x7F800000u;
+  if (c < Cout) {
+    float mean = 0.f, mul = 1.f, bias = 0.f;
+    if (bn.mean) { mean = bn.mean[c]; mul = bn.mul[c]; bias = bn.bias[c]; }
+    for (int i = (int)(threadIdx.x >> 6) + 4 * (int)blockIdx.y - bound; i <= bound; i += 4 * (int)gridDim.y) {
+      float x = dequant_acc_nb(i, dq) - mean;       // the epilogue's operation order
+      x = x * mul;
+      x = x + bias;
+      const uint32_t b = __float_as_uint(x) & 0x7FFFFFFFu;
+      if (b != 0 && b < mb) mb = b;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)mb, off);
+    mb = o < mb ? o : mb;
+  }
+  if ((threadIdx.x & 63) == 0 && mb != 0x7F800000u) atomicMin(out, mb);
+}
+
 uint32_t *sched_slot(int dev, hipStream_t st) {
   static std::mutex mu;
   static uint32_t *pool[64] = {nullptr};
@@ -334,6 +357,19 @@ uint32_t *sched_slot(int dev, hipStream_t st) {
     pool[dev] = p;
   }
   return pool[dev] + (size_t)(next[dev]++ % SCHED_SLOTS) * SCHED_WORDS;
+}
+
+int run_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound, int32_t Cout,
+                    uint32_t *out_bits, hipStream_t st) {
+  SNNQP_REQUIRE(w && out_bits && Cout > 0 && bound >= 0, SNNQP_EINVAL, "current_min: bad argument");
+  SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
+  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
+                        "batch-norm descriptor with null arrays");
+  const int slices = bound >= 256 ? 16 : 1;
+  hipLaunchKernelGGL(current_min_kernel, dim3((Cout + 63) / 64, slices), dim3(256), 0, st,
+                     make_dequant(w->L, w->m), make_bn(bn), bound, Cout, out_bits);
+  SNNQP_CHECK_LAUNCH("current_min_kernel");
+  return SNNQP_OK;
 }
 
 const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
@@ -421,7 +457,9 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   } while (0)
   if (in_type == SNNQP_BITS) {
     // conv3x3_bits.hip: codes exact in fp6 -> f8f6f4 MFMA, wider codes -> int8 MFMA
-    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, gy, st);
+    const bool fma = lut && nf == NF_MUL0 && w->min_current_bits != 0 &&
+                     lif_fma_is_exact(w->min_current_bits, a.nrn.k_log2, T, u0 != nullptr);
+    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, fma, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
     // LDS decides how many workgroups share a CU (every variant needs < 128 VGPRs: up to four

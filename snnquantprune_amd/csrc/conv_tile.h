@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t build_lut_channel(float *lut, int bound, con
 // it one), so d_t 2^-j is a multiple of q 2^(-j (t + 1)) >= 2^-149 with the significand
 // of d_t: representable, the product rounds nothing away.  `min_x_bits` = bits of the
 // smallest non-zero |x| the launch can see.
-__device__ __forceinline__ bool lif_fma_is_exact(uint32_t min_x_bits, int j, int T, bool has_u0) {
+__host__ __device__ __forceinline__ bool lif_fma_is_exact(uint32_t min_x_bits, int j, int T, bool has_u0) {
   if (has_u0 || j < 0) return false;
   const long long e = (long long)j * (T + 1) - 126;     // needed exponent of min |x|
   if (e > 100) return false;
@@ -331,7 +331,7 @@ __device__ __forceinline__ v2f dequant_pair(int a0, int a1, const Dequant &dq, f
 // FMA (NF_MUL0 only): u + d * m as one fused multiply-add.  Identical to the two-step
 // form whenever d * m is exact, i.e. never a subnormal with bits shifted out; the
 // caller proves that for the launch (lif_fma_is_exact) before taking this variant.
-template <int NF, bool FMA = false>
+template <int NF, bool FMA = false, bool PACKED = true>
 __device__ __forceinline__ v2f neuron_update(v2f x, v2f u, const LaneConsts &lc,
                                              const NeuronP &nrn) {
   if (NF == NF_DECAY) {
@@ -340,7 +340,7 @@ __device__ __forceinline__ v2f neuron_update(v2f x, v2f u, const LaneConsts &lc,
   }
   // u - 0 == u exactly, so NF_MUL0 skips the subtraction
 #ifndef SNNQP_PACKED_F32
-  if (FMA) {
+  if (FMA && PACKED) {
     // conv0's table kernel: no MFMA worth overlapping (one per 1024 updates), and one
     // v_pk_add + one v_pk_fma per pair issue in fewer slots than four scalar ops
     // (measured 7.8 against 8.1 ms), so this variant keeps the packed forms
@@ -567,7 +567,9 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
 }
 
 // conv3x3_bits.hip: bit-packed input, Cin <= 128; i8 = codes wider than fp6 holds
-void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, bool lut, unsigned gy,
-                        hipStream_t st);
+// fma: the membrane update as one fused multiply-add (NF_MUL0 with a table, proven exact
+// for this launch by the caller: snnqp_weight_t.min_current_bits + lif_fma_is_exact)
+void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, bool lut, bool fma,
+                         unsigned gy, hipStream_t st);
 
 }  // namespace snnqp

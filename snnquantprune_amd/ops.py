@@ -116,10 +116,11 @@ class Weight:
   wt: Optional[torch.Tensor] = None
   abs_sum_max: int = 0      # |acc| <= abs_sum_max * x_max (max one-sided code sum over the outputs)
   code_max: int = 0         # max |code| (<= 7: exact in fp6)
+  min_current_bits: int = 0  # smallest non-zero |BN(dequant(acc))| as float bits (current_min)
 
   def struct(self) -> L.WeightT:
     return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
-                     int(self.abs_sum_max), int(self.code_max))
+                     int(self.abs_sum_max), int(self.code_max), int(self.min_current_bits))
 
   @property
   def is_int(self):
@@ -448,6 +449,32 @@ class _timed:
 # ---------------------------------------------------------------------------
 # fused SpikingBlock
 # ---------------------------------------------------------------------------
+
+
+_current_min_cache = None
+
+
+def current_min_bits(weight: Weight, bn: Optional[BnCoeffs], bound: int, cout: int) -> int:
+  """float32 bits of the smallest non-zero |BatchNorm(dequant(acc))| over |acc| <= bound and
+  the channels: what Weight.min_current_bits wants (one device pass + a 4-byte read-back per
+  (weights, BatchNorm) version, cached)."""
+  global _current_min_cache
+  if _current_min_cache is None:
+    from ._cache import TensorCache
+    _current_min_cache = TensorCache(64)
+  key = (weight.w,) + ((bn.mean, bn.mul, bn.bias) if bn is not None else (None, None, None))
+  extra = (int(bound), int(cout), float(weight.L), float(weight.m))
+  v = _current_min_cache.get(key, extra)
+  if v is None:
+    _require_gpu(weight.w)
+    out = torch.full((1,), 0x7F800000, dtype=torch.int32, device=weight.w.device)
+    w = weight.struct()
+    b = bn.struct() if bn is not None else None
+    L.check(L.lib().snnqp_current_min(ctypes.byref(w), ctypes.byref(b) if b is not None else None,
+                                      int(bound), int(cout), _ptr(out), _stream()))
+    v = int(out.item()) & 0xFFFFFFFF
+    _current_min_cache.put(key, extra, v)
+  return v
 
 
 def _tb_strides(x, T, B, time_major: bool, unit: int):

@@ -17,6 +17,8 @@ import math
 from typing import Any, Callable, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib as L
@@ -315,6 +317,14 @@ class SpikingBlock(nn.Module):
         x = x.reshape(T, B, 1, geom.W, cin)
       if u0 is not None:
         u0 = u0.unsqueeze(1)
+    if (isinstance(x, ops.PackedSpikes) and w.is_int and w.min_current_bits == 0
+        and 0 < w.abs_sum_max <= 4095 and impl != L.IMPL_GENERIC and u0 is None
+        and not os.environ.get("SNNQP_NO_FUSED_UPDATE")):        # (A/B switch)
+      # table dequantisation applies: let the kernel fuse the membrane update where
+      # BatchNorm of every table entry proves that exact (snnqp.h, min_current_bits)
+      import dataclasses
+      w = dataclasses.replace(w, min_current_bits=ops.current_min_bits(
+          w, bn, int(w.abs_sum_max), geom.Cout))
     try:
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,

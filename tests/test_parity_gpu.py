@@ -1239,3 +1239,36 @@ def test_dense_block_random_shapes(dev):
   the MFMA kernel equals the direct-form kernel bit for bit."""
   from tests.stress import dense_block_random
   assert dense_block_random(dev, 40, 20261005) == []
+
+
+@pytest.mark.parametrize("bits", [4, 5])
+@pytest.mark.parametrize("tiny", [False, True])
+def test_conv_bits_kernel_fused_membrane_update(dev, oracle, bits, tiny):
+  """The bits kernel runs u + (x - u) / tau as one fused multiply-add when
+  min_current_bits (snnqp_current_min over BatchNorm of every table entry) proves it exact:
+  identical rasters and potentials with and without the hint, on fp6 (4-bit) and int8
+  (5-bit) codes; BatchNorm that scales the currents to ~2^-126 must be refused."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=6, B=3, hw=8, cin=128, cout=128, bits=bits, seed=2101, gain=5.0)
+  if tiny:
+    z, one = np.zeros(128, F32), np.ones(128, F32)
+    c["bn"] = dict(mean=z, var=one, scale=(one * F32(2.0 ** -126)).astype(F32), bias=z, eps=0.0)
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  bn = _bn(c["bn"], dev)
+  if tiny:
+    bn = ops.BnCoeffs(_t(c["bn"]["mean"], dev), _t(c["bn"]["scale"], dev), _t(c["bn"]["bias"], dev))
+  geom = ops.ConvGeom(8, 8, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+  mb = ops.current_min_bits(w, bn, int(w.abs_sum_max), 128)
+  x_min = np.array([mb], np.uint32).view(F32)[0]
+  assert (x_min < 2.0 ** -100) == tiny, x_min
+  wf = dataclasses.replace(w, min_current_bits=mb)
+  for pool, key in ((2, "pooled_bits"), (1, "s_bits")):
+    for ww in (w, wf):
+      u, s = ops.conv_lif_forward(xin, geom, ww, _mslif(), bn=bn, packed_out=True, pool=pool,
+                                  impl=L.IMPL_MFMA, x_max=1)
+      np.testing.assert_array_equal(_np(s), e[key])
+      np.testing.assert_array_equal(_np(u), e["u"])
