@@ -93,7 +93,8 @@ typedef struct {
   int32_t code_max;    /* W_I8: max |code|; 0 = unknown.  Codes of magnitude <= 7 are
                           exact in fp6 (e2m3) and may take the f8f6f4 MFMA */
   uint32_t min_current_bits; /* float32 bits of the smallest non-zero |input current| the block
-                          can see with the BatchNorm it is used with -- snnqp_current_min();
+                          can see with the BatchNorm it is used with -- snnqp_current_min()
+                          with bound = abs_sum_max (bit-packed inputs);
                           lets the conv kernels run u + (x - u) / tau as one fused
                           multiply-add when that is provably bit-identical.  0 = unknown */
 } snnqp_weight_t;

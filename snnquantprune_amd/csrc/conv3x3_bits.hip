@@ -502,11 +502,13 @@ static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, u
 }
 
 // i8: codes wider than fp6 holds (|code| > 7) -> the int8 instruction
-// NF_MUL0 with a table and the fused membrane update
+// NF_MUL0 with the fused membrane update
 template <int FMT, int CIN>
-static void launch_fp6_fma(const ConvMfmaArgs &a, bool pool, unsigned gy, hipStream_t st) {
-  if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, true, true, true>, a, gy, st, 0, F6_NT);
-  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, false, true, true>, a, gy, st, 0, F6_NT);
+static void launch_fp6_fma(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy, hipStream_t st) {
+  if (pool && lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, true, true, true>, a, gy, st, 0, F6_NT);
+  else if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, true, false, true>, a, gy, st, 0, F6_NT);
+  else if (lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, false, true, true>, a, gy, st, 0, F6_NT);
+  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, false, false, true>, a, gy, st, 0, F6_NT);
 }
 
 void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, bool lut, bool fma,
@@ -515,13 +517,13 @@ void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, boo
   a.patch_h = 4 * F6_TILES;
   a.tiles_y = (a.H + a.patch_h - 1) / a.patch_h;
   a.npatch = (int64_t)a.B * a.tiles_y * a.tiles_x;
-  if (fma && lut && nf == NF_MUL0) {
+  if (fma && nf == NF_MUL0) {
     if (i8) {
-      if (a.Cin <= 64) launch_fp6_fma<FMT_I8, 64>(a, pool, gy, st);
-      else launch_fp6_fma<FMT_I8, 128>(a, pool, gy, st);
+      if (a.Cin <= 64) launch_fp6_fma<FMT_I8, 64>(a, pool, lut, gy, st);
+      else launch_fp6_fma<FMT_I8, 128>(a, pool, lut, gy, st);
     } else {
-      if (a.Cin <= 64) launch_fp6_fma<FMT_FP6, 64>(a, pool, gy, st);
-      else launch_fp6_fma<FMT_FP6, 128>(a, pool, gy, st);
+      if (a.Cin <= 64) launch_fp6_fma<FMT_FP6, 64>(a, pool, lut, gy, st);
+      else launch_fp6_fma<FMT_FP6, 128>(a, pool, lut, gy, st);
     }
     return;
   }

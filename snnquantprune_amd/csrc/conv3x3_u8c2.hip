@@ -457,7 +457,8 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   } while (0)
   if (in_type == SNNQP_BITS) {
     // conv3x3_bits.hip: codes exact in fp6 -> f8f6f4 MFMA, wider codes -> int8 MFMA
-    const bool fma = lut && nf == NF_MUL0 && w->min_current_bits != 0 &&
+    // (min_current_bits covers |acc| <= abs_sum_max, table or not)
+    const bool fma = nf == NF_MUL0 && w->min_current_bits != 0 && w->abs_sum_max > 0 &&
                      lif_fma_is_exact(w->min_current_bits, a.nrn.k_log2, T, u0 != nullptr);
     launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, fma, gy, st);
   } else {

@@ -567,8 +567,8 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
 }
 
 // conv3x3_bits.hip: bit-packed input, Cin <= 128; i8 = codes wider than fp6 holds
-// fma: the membrane update as one fused multiply-add (NF_MUL0 with a table, proven exact
-// for this launch by the caller: snnqp_weight_t.min_current_bits + lif_fma_is_exact)
+// fma: the membrane update as one fused multiply-add (NF_MUL0, proven exact for this launch
+// by the caller: snnqp_weight_t.min_current_bits + lif_fma_is_exact)
 void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, bool lut, bool fma,
                          unsigned gy, hipStream_t st);
 

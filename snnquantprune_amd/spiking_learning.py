@@ -318,10 +318,10 @@ class SpikingBlock(nn.Module):
       if u0 is not None:
         u0 = u0.unsqueeze(1)
     if (isinstance(x, ops.PackedSpikes) and w.is_int and w.min_current_bits == 0
-        and 0 < w.abs_sum_max <= 4095 and impl != L.IMPL_GENERIC and u0 is None
+        and 0 < w.abs_sum_max < (1 << 22) and impl != L.IMPL_GENERIC and u0 is None
         and not os.environ.get("SNNQP_NO_FUSED_UPDATE")):        # (A/B switch)
-      # table dequantisation applies: let the kernel fuse the membrane update where
-      # BatchNorm of every table entry proves that exact (snnqp.h, min_current_bits)
+      # let the kernel fuse the membrane update where BatchNorm of every reachable
+      # dequantised accumulator value proves that exact (snnqp.h, min_current_bits)
       import dataclasses
       w = dataclasses.replace(w, min_current_bits=ops.current_min_bits(
           w, bn, int(w.abs_sum_max), geom.Cout))

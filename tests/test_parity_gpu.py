@@ -1241,13 +1241,14 @@ def test_dense_block_random_shapes(dev):
   assert dense_block_random(dev, 40, 20261005) == []
 
 
-@pytest.mark.parametrize("bits", [4, 5])
+@pytest.mark.parametrize("bits", [4, 5, 8])
 @pytest.mark.parametrize("tiny", [False, True])
 def test_conv_bits_kernel_fused_membrane_update(dev, oracle, bits, tiny):
   """The bits kernel runs u + (x - u) / tau as one fused multiply-add when
   min_current_bits (snnqp_current_min over BatchNorm of every table entry) proves it exact:
   identical rasters and potentials with and without the hint, on fp6 (4-bit) and int8
-  (5-bit) codes; BatchNorm that scales the currents to ~2^-126 must be refused."""
+  codes (5-bit: table; 8-bit: arithmetic dequantisation); BatchNorm that scales the
+  currents to ~2^-126 must be refused."""
   import dataclasses
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
