@@ -1273,3 +1273,29 @@ def test_conv_bits_kernel_fused_membrane_update(dev, oracle, bits, tiny):
                                   impl=L.IMPL_MFMA, x_max=1)
       np.testing.assert_array_equal(_np(s), e[key])
       np.testing.assert_array_equal(_np(u), e["u"])
+
+
+def test_conv_work_queues_on_concurrent_streams(dev, oracle):
+  """The patch work queues come from a per-device pool of slots: launches that overlap on
+  different streams (and more than 64 launches in a row, so slots are reused) still give
+  the oracle's rasters."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=5, B=24, hw=16, cin=128, seed=2301, gain=5.0)
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  geom = ops.ConvGeom(16, 16, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+  bn = _bn(c["bn"], dev)
+  torch.cuda.synchronize()
+  streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+  outs = []
+  for rep in range(30):                       # 90 launches: every slot of the pool reused
+    for st in streams:
+      with torch.cuda.stream(st):
+        outs.append(ops.conv_lif_forward(xin, geom, w, _mslif(), bn=bn, packed_out=True, pool=2,
+                                         impl=L.IMPL_MFMA, x_max=1))
+  torch.cuda.synchronize()
+  for u, s in outs:
+    np.testing.assert_array_equal(_np(s), e["pooled_bits"])
+    np.testing.assert_array_equal(_np(u), e["u"])
