@@ -419,10 +419,16 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
       return;
 #endif
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1024)   // diagnostic build: halo staged for t = 0, 1 only
+      if (t2 >= 2) return;
+#endif
       if (t2 < a.T) stage_expand();
       if (t2 + 1 < a.T) stage_load(t2 + 1);
     };
     auto stage_end = [&](int t2) {
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1024)
+      if (t2 >= 2) return;
+#endif
       if (t2 < a.T) stage_write(t2 & 1);
     };
     // one pipeline step: MFMA(t + 1) || epilogue(t); halo(t + 2) staged meanwhile.
@@ -440,7 +446,9 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       F6_MARK(2)
       stage_end(t + 2);
       F6_MARK(3)
+#if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 256))   // diagnostic build: no per-step barrier (races)
       lds_barrier();
+#endif
       F6_MARK(4)
     };
 
