@@ -242,16 +242,18 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     const int gy = y0 + s_hy - 1, gx = x0 + s_hx - 1;
     const bool s_valid = s_task && s_wi < wpm && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     const int64_t s_goff = (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * wpm + s_wi;
-    uint32_t stg = 0, stg_cur = 0;
-    auto stage_load = [&](int t) {
-      stg = s_valid ? xb[(int64_t)t * a.xs_t + s_goff] : 0u;
+    // the spike word of halo(t) is requested two steps before it is expanded (a step is about a
+    // microsecond, a loaded global round trip can be longer): two registers, by parity of t
+    uint32_t stgq[2] = {0, 0}, stg_cur = 0;
+    auto stage_load = [&](int t, int par) {
+      stgq[par] = s_valid ? xb[(int64_t)t * a.xs_t + s_goff] : 0u;
     };
     v4i s_exp = {0, 0, 0, 0};
-    auto stage_expand = [&]() {                  // table reads; consumed by stage_write
+    auto stage_expand = [&](int par) {           // table reads; consumed by stage_write
       if (I8) {
-        stg_cur = stg;
+        stg_cur = stgq[par];
       } else if (s_task) {
-        const uint32_t sw = stg;
+        const uint32_t sw = stgq[par];
         s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw << 2) & 0x3FCu));
         s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 6) & 0x3FCu));
         s_exp.z = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 14) & 0x3FCu));
@@ -415,15 +417,15 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // word of halo(t2 + 1) is requested as soon as its register is free (one step ahead is
     // enough: two steps ahead measured the same), the LDS
     // write comes after the step's MFMAs
-    auto stage_begin = [&](int t2) {
+    auto stage_begin = [&](int t2, int par) {    // par = t2 & 1, a constant at every call
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
       return;
 #endif
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1024)   // diagnostic build: halo staged for t = 0, 1 only
       if (t2 >= 2) return;
 #endif
-      if (t2 < a.T) stage_expand();
-      if (t2 + 1 < a.T) stage_load(t2 + 1);
+      if (t2 < a.T) stage_expand(par);
+      if (t2 + 2 < a.T) stage_load(t2 + 2, par);
     };
     auto stage_end = [&](int t2) {
 #if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1024)
@@ -434,13 +436,13 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // one pipeline step: MFMA(t + 1) || epilogue(t); halo(t + 2) staged meanwhile.
     // One barrier per step: inside it every wave reads halo(t + 1) and writes
     // halo(t + 2) into the other buffer.
-    auto step = [&](int t, acc_t &accN, const acc_t &accC) {
+    auto step = [&](int t, int par, acc_t &accN, const acc_t &accC) {
 #if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 8))   // diagnostic build: no flush
       if (t >= FL && t % FL == 0)                // steps < t are behind a barrier
         flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, t - FL, FL, b, y0, x0, tid);
 #endif
       F6_MARK(0)
-      stage_begin(t + 2);
+      stage_begin(t + 2, par);
       F6_MARK(1)
       fused_step((t + 1) & 1, accN, accC, t);
       F6_MARK(2)
@@ -454,11 +456,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
     // pipeline prologue: halo(0) staged; MFMA(0) while halo(1) is staged
     acc_t accA, accB;
-    stage_load(0);
-    stage_begin(0);
+    stage_load(0, 0);
+    if (a.T > 1) stage_load(1, 1);
+    stage_begin(0, 0);
     stage_end(0);
     lds_barrier();
-    stage_begin(1);
+    stage_begin(1, 1);
     mfma_only(0, accA);
     stage_end(1);
     lds_barrier();
@@ -466,11 +469,11 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // steady state, unrolled by two so the accumulator roles alternate
     int t = 0;
     for (; t + 2 < a.T; t += 2) {
-      step(t, accB, accA);
-      step(t + 1, accA, accB);
+      step(t, 0, accB, accA);
+      step(t + 1, 1, accA, accB);
     }
     if (t + 1 < a.T) {
-      step(t, accB, accA);
+      step(t, 0, accB, accA);
       epilogue(accB, t + 1);
     } else {
       epilogue(accA, t);
