@@ -353,11 +353,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           x = x * lc.bmul;
           x = x + lc.bbias;
         } else if (q == 2) {       // membrane update of the neuron form (conv_tile.h)
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 32)   // diagnostic build: FMA membrane update
-          uu = neuron_update<NF, true>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
-#else
           uu = neuron_update<NF, FMA, false>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
-#endif
           m0 = __ballot(uu.x >= a.nrn.vth);
           m1 = __ballot(uu.y >= a.nrn.vth);
         } else {
