@@ -8,16 +8,22 @@ already in HBM) + the all-gather of the logits.  Weak scaling: every rank owns
 its own B samples; value = N * B * K / max-over-ranks time.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus 8                   (spawns its own 8 rank processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
       --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed
 inside the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle in its
 reference-literal float mode on a bounded sample, host cores).
+
+Other BASELINE configs: C5 (mixed 2/4-bit, 95 % pruned, T = 50, 512 samples per GPU)
+  python bench.py --frames 50 --batch 512 --layer-bits 2,4,2,4 --prune 0.95 --classes 10
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,20 +31,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 # dense peaks, MI355X_MICROARCH.md: int8 MFMA 2x the ~2.5 PF bf16 rate; block-scaled
 # fp6/fp4 MFMA ~10 PF; HBM3E 8 TB/s
 INT8_MFMA_PEAK_TOPS = 5000.0
 FP6_MFMA_PEAK_TOPS = 10000.0
 HBM_PEAK_GBS = 8000.0
+# one wave64 VALU instruction per SIMD every 4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0 * 1e0   # G wave-instructions / s (x 64 lanes each)
 # HBM bytes per launch measured with rocprofv3 --pmc (separate passes of this same
 # command: tools/pmc_profile.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json",
+                                                           "r01_pmc_traffic.json")]
+# int-vs-float deviation of the numeric contract (tools/int_vs_float.py, CPU), committed
+PARITY_VS_FLOAT = os.path.join(ROOT, "profiles", "r02_int_vs_float.json")
 
 
-def parse():
+def parse(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=5)
@@ -46,6 +54,10 @@ def parse():
   ap.add_argument("--batch", type=int, default=1024, help="samples per GPU")
   ap.add_argument("--frames", type=int, default=20)
   ap.add_argument("--bits", type=int, default=4)
+  ap.add_argument("--layer-bits", type=str, default=None,
+                  help="per-layer bit widths conv0,conv1,conv2,dense (mixed precision, "
+                       "BASELINE config C5: 2,4,2,4); overrides --bits")
+  ap.add_argument("--classes", type=int, default=11, help="read-out = 10 neurons per class")
   ap.add_argument("--prune", type=float, default=0.9)
   ap.add_argument("--lam", type=float, default=0.1,
                   help="Poisson rate of the synthetic events; spikes are (Poisson(lam) > 0)")
@@ -63,20 +75,97 @@ def parse():
                   help="inspect the next batch on a side stream while this one computes")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  return ap.parse_args()
+  ap.add_argument("--allow-diag", action="store_true",
+                  help="accept a diagnostic libsnnqp (SNNQP_DIAG_LIB); the line is marked")
+  # test plumbing: the same step / fence / all-reduce code on CPU tensors over gloo with a
+  # stand-in for model.apply (tests/test_host_cpu.py); never a measurement
+  ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
+  ap.add_argument("--stand-in", action="store_true", help=argparse.SUPPRESS)
+  args = ap.parse_args(argv)
+  if args.layer_bits:
+    args.layer_bits = [int(b) for b in args.layer_bits.split(",")]
+    if len(args.layer_bits) != 4 or args.model != "c3":
+      ap.error("--layer-bits takes four widths (conv0,conv1,conv2,dense) of the c3 topology")
+  return args
+
+
+def layer_bits(args):
+  return list(args.layer_bits) if args.layer_bits else [args.bits] * 4
+
+
+def metric_name(args):
+  lb = layer_bits(args)
+  bits = "%d-bit" % lb[0] if len(set(lb)) == 1 else "mixed %s-bit" % "/".join(
+      str(b) for b in sorted(set(lb)))
+  return "samples/sec/node (DVS128 T=%d, %s/%.4g%%-pruned)" % (args.frames, bits, args.prune * 100)
+
+
+# ---------------------------------------------------------------------------
+# `python bench.py --gpus N` without a launcher: this process starts the N ranks
+# ---------------------------------------------------------------------------
+
+
+def launch_ranks(args, argv):
+  """Spawns one fresh process per rank (before anything here touched a GPU), relays rank
+  0's JSON line and exits non-zero if any rank failed.  Equivalent to
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>`."""
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  n = args.gpus
+  base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+              MASTER_PORT=str(port))
+  base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  import tempfile
+  procs = []
+  with tempfile.TemporaryFile() as out0:
+    for r in range(n):
+      env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+      procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                    env=env, stdout=out0 if r == 0 else subprocess.DEVNULL,
+                                    cwd=os.getcwd()))
+    deadline = time.time() + float(os.environ.get("SNNQP_BENCH_LAUNCH_TIMEOUT", "1500"))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+      for r, p in enumerate(procs):
+        if p.poll() not in (None, 0):
+          failed = (r, p.returncode)
+      if time.time() > deadline:
+        failed = (-1, 124)
+      time.sleep(0.1)
+    for r, p in enumerate(procs):
+      if failed is None and p.returncode != 0:
+        failed = (r, p.returncode)
+    if failed is not None:
+      for p in procs:                    # the exact children started above, nothing else
+        if p.poll() is None:
+          p.kill()
+      for p in procs:
+        try:
+          p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+          pass
+      print("bench.py: rank %d failed with exit code %d" % failed, file=sys.stderr)
+      return failed[1] if failed[1] > 0 else 1
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
+    sys.stdout.flush()
+  return 0
 
 
 def cpu_baseline(args, variables_np):
   """Reference-literal float mode of the CPU oracle (dense float32 fake-quantised
   weights, BLAS matmul on im2col, float32 spike tensors between layers, T
   sequential LIF steps) on a bounded sample of the same workload."""
+  import numpy as np
   from oracle import snn_oracle as o
   from snnquantprune_amd import synthetic as syn
   from tests.helpers import bn_of, qweight_of
   p = variables_np["params"]
-  cq = [qweight_of(o, p["QuantConv_%d" % i], args.bits) for i in range(3)]
+  lb = layer_bits(args)
+  cq = [qweight_of(o, p["QuantConv_%d" % i], lb[i]) for i in range(3)]
   bns = [bn_of(variables_np, i) for i in range(3)]
-  dq = qweight_of(o, p["QuantDense_0"], args.bits)
+  dq = qweight_of(o, p["QuantDense_0"], lb[3])
   n = max(1, args.cpu_samples)
   x = syn.poisson_spikes((n, args.frames, 128, 128, 2), args.lam, seed=4242).astype(np.float32)
   o.conv3_dense_forward(x[:1, :2], cq, bns, dq, mode="float")      # warm-up, discarded
@@ -115,17 +204,17 @@ def cpu_baseline(args, variables_np):
   best = max(by_threads, key=lambda t: by_threads[t]["value"])
   out = {"value": by_threads[best]["value"], "unit": "samples/s", "cores": int(best),
          "kind": "port", "cpu": cpu, "host_cores": int(cores),
-         "sample": "%d samples of the same C3 workload (T=%d, 128x128x2), oracle float mode "
+         "sample": "%d samples of the same workload (T=%d, 128x128x2), oracle float mode "
                    "(dense float32 fake-quantised weights, BLAS matmul on im2col), best of the "
                    "BLAS thread counts tried" % (by_threads[best]["samples"], args.frames),
          "by_threads": {str(k): v for k, v in sorted(by_threads.items())}}
   # the batch is embarrassingly parallel: W single-threaded worker processes, one slice of
   # samples each (fresh interpreters that never touch the GPU), W = the box's CPU share
   try:
-    import subprocess, tempfile
+    import tempfile
     W = int(min(16, cores))
-    per = 12                     # ~6-8 s of CPU work per worker
-    payload = {"bits": np.int32(args.bits),
+    per = max(2, int(round(12 * 20 / max(args.frames, 1))))     # ~6-8 s of CPU work per worker
+    payload = {"bits": np.int32(args.bits), "layer_bits": np.asarray(lb, np.int32),
                "x": syn.poisson_spikes((W * per, args.frames, 128, 128, 2), args.lam,
                                        seed=4243).astype(np.uint8)}
     for name, leaf in [("conv%d" % i, p["QuantConv_%d" % i]) for i in range(3)] + \
@@ -153,43 +242,80 @@ def cpu_baseline(args, variables_np):
                            "value": nproc / secs}
     if nproc / secs > out["value"]:
       out.update(value=nproc / secs, cores=W,
-                 sample="%d samples of the same C3 workload (T=%d, 128x128x2), oracle float mode, "
+                 sample="%d samples of the same workload (T=%d, 128x128x2), oracle float mode, "
                         "%d single-threaded worker processes" % (nproc, args.frames, W))
   except Exception as e:          # no subprocesses on this box: keep the in-process figure
     out["by_processes"] = {"value": None, "note": "not measured: %s" % type(e).__name__}
   return out
 
 
-def main():
-  args = parse()
-  from snnquantprune_amd import linen as nn
-  from snnquantprune_amd import models, ops, parallel, synthetic as syn
+def main(argv=None):
+  argv = sys.argv[1:] if argv is None else list(argv)
+  args = parse(argv)
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # no launcher around us: become one (nothing in this process has touched a GPU yet)
+    sys.exit(launch_ranks(args, argv))
 
-  rank, world, local = parallel.init_from_env("nccl")
-  assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
-  assert torch.cuda.is_available(), "bench.py needs a GPU"
-  torch.cuda.set_device(local)
-  dev = torch.device("cuda", local)
+  import numpy as np
+  import torch
+  from snnquantprune_amd import parallel
+
+  gpu = args.backend == "nccl"
+  rank, world, local = parallel.init_from_env(args.backend)
+  if world != args.gpus:
+    raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+  if gpu:
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+  else:
+    assert args.stand_in, "the gloo backend is test plumbing (--stand-in) only"
+    dev = torch.device("cpu")
 
   B, T = args.batch, args.frames
-  cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune)
-  if args.model == "cextnet":
-    model = models.CextNet(num_classes=11, config=cfg)
-    variables_np = syn.cextnet_variables(prune_p=args.prune)
+  lb = layer_bits(args)
+  build_flags = ""
+  if args.stand_in:
+    # stand-in for model.apply: a per-sample function of the input, so that the gathered
+    # logits identify every rank's shard (tests/test_host_cpu.py)
+    ops = None
+    variables_np = None
+
+    def apply_fn(xb):
+      f = xb.reshape(xb.shape[0], -1).to(torch.float32)
+      return torch.stack([f.sum(1) * (k + 1) for k in range(args.classes)], 1)
+    hw = 4
   else:
-    model = models.ConvDenseSNN(num_classes=11, config=cfg)
-    variables_np = syn.conv_net_variables(prune_p=args.prune)
-  variables = nn.tree_from_numpy(variables_np, dev)
+    from snnquantprune_amd import _lib, linen as nn
+    from snnquantprune_amd import models, ops, synthetic as syn
+    build_flags = _lib.build_flags()
+    if not args.allow_diag:
+      _lib.require_product_build()
+    cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune)
+    if args.layer_bits:
+      cfg.quant.layer_bits = tuple(args.layer_bits)
+    if args.model == "cextnet":
+      model = models.CextNet(num_classes=args.classes, config=cfg)
+      variables_np = syn.cextnet_variables(prune_p=args.prune, out=args.classes * 10)
+    else:
+      model = models.ConvDenseSNN(num_classes=args.classes, config=cfg)
+      variables_np = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10)
+    variables = nn.tree_from_numpy(variables_np, dev)
+
+    def apply_fn(xb):
+      (logits, _) = model.apply(variables, xb, trgt=None, train=False, rng=None)
+      return logits
+    hw = 128
 
   # synthetic Poisson-spike DVS frames, resident in HBM before the timed region
   gen = torch.Generator(device=dev)
   gen.manual_seed(8627169 + rank)
   p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
   if args.counts:
-    x = torch.poisson(torch.full((B, T, 128, 128, 2), float(args.lam), device=dev),
+    x = torch.poisson(torch.full((B, T, hw, hw, 2), float(args.lam), device=dev),
                       generator=gen).clamp_(max=255).to(torch.uint8)
   else:
-    x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
+    x = (torch.rand((B, T, hw, hw, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
   if args.input == "f32":
     x = x.to(torch.float32)
 
@@ -197,29 +323,24 @@ def main():
   counter = [0]
 
   def step():
-    ops.forget_inputs()       # a new batch: its inspection pass (max count) is timed too
+    if ops is not None:
+      ops.forget_inputs()     # a new batch: whatever is cached about the last one is dropped
     xb = batches[counter[0] % len(batches)]
     counter[0] += 1
-    if args.prefetch_inspect:
+    if args.prefetch_inspect and ops is not None:
       # the NEXT batch is resident too: its inspection pass goes to a side stream before this
       # batch's kernels are queued (one pass per step, inside the timed region, as without)
       ops.prefetch_input_bound(batches[counter[0] % len(batches)])
-    if os.environ.get("SNNQP_BENCH_TRACE") == "2":
-      ta = time.perf_counter()
-      xm = ops.input_max_bound(xb)
-      tb = time.perf_counter()
-      (logits, _) = model.apply(variables, xb, trgt=None, train=False, rng=None)
-      tc = time.perf_counter()
-      print("  step phases (ms): inspect %.2f apply-enqueue %.2f" % ((tb - ta) * 1e3, (tc - tb) * 1e3),
-            file=sys.stderr)
-      return parallel.all_gather_rows(logits)
-    (logits, _) = model.apply(variables, xb, trgt=None, train=False, rng=None)
-    return parallel.all_gather_rows(logits)
+    return parallel.all_gather_rows(apply_fn(xb))
 
   def fence():
     if world > 1:
-      torch.distributed.barrier(device_ids=[local])
-    torch.cuda.synchronize()
+      if gpu:
+        torch.distributed.barrier(device_ids=[local])
+      else:
+        torch.distributed.barrier()
+    if gpu:
+      torch.cuda.synchronize()
 
   # a full collection over everything imported and built so far, then park those objects in
   # the permanent generation: the interpreter's next full collection otherwise lands in one of
@@ -230,12 +351,15 @@ def main():
   gc.freeze()
   # the per-kernel HIP events are part of the timed steps: create them in the warm-up steps as
   # well (the first timing event of a process costs tens of milliseconds on a cold box)
-  ops.profile_start()
+  if ops is not None:
+    ops.profile_start()
+  out = None
   for _ in range(args.warmup):
     out = step()
   fence()
-  ops.profile_stop()
-  ops.profile_start()
+  if ops is not None:
+    ops.profile_stop()
+    ops.profile_start()
   t0 = time.perf_counter()
   trace = os.environ.get("SNNQP_BENCH_TRACE")      # diagnostic: host time of every step's enqueue
   marks = []
@@ -248,8 +372,16 @@ def main():
   if trace and rank == 0:
     print("enqueue done at (ms):", [round(m * 1e3, 2) for m in marks], "all done", round(dt * 1e3, 2),
           file=sys.stderr)
-  prof = ops.profile_stop()                       # {tag: (launches, total ms)}
-  assert out.shape == (world * B, 11)
+  prof = ops.profile_stop() if ops is not None else {}    # {tag: (launches, total ms)}
+  assert out.shape == (world * B, args.classes), out.shape
+  if args.stand_in:
+    # every rank's rows arrived, in rank order: row r*B of the gathered logits is rank r's first
+    # sample (seeded 8627169 + r)
+    for r in range(world):
+      g = torch.Generator(device=dev)
+      g.manual_seed(8627169 + r)
+      xr = (torch.rand((B, T, hw, hw, 2), device=dev, generator=g) < p_spike).to(torch.uint8)
+      assert torch.equal(out[r * B:(r + 1) * B], apply_fn(xr)), "gathered rows of rank %d" % r
 
   tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
   if world > 1:
@@ -260,28 +392,73 @@ def main():
     return
   value = world * B * args.steps / dt
 
-  # ---- per-kernel rooflines (HIP events on the launch stream, inside the timed region) ----
+  line = {
+      "metric": metric_name(args),
+      "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "int8",
+      "dtype_detail": "integer codes x integer inputs, exact sums: conv0/dense int8 x u8/binary -> "
+                      "int32 (i8 MFMA); conv1-2 the same integers as fp6 codes x fp4 spikes -> f32 "
+                      "(f8f6f4 MFMA, sums < 2^24 exact) when the codes fit (<= 4 bits), else int8; "
+                      "membrane potentials f32",
+      "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
+              % args.lam + ", N(0,1/fan_in) weights, random seeds fixed",
+      "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
+                              "qdense(2048->512->%d) + vote, " % (args.classes * 10)
+                              if args.model == "cextnet" else
+                              "C3 topology: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->%d)+LIF + vote, "
+                              % (args.classes * 10)) +
+                             "DVS128 128x128x2, T=%d, bits %s, %.4g%% pruned" %
+                             (T, "/".join(str(b) for b in lb), args.prune * 100),
+                 "batch_per_gpu": B, "global_batch": world * B, "frames": T,
+                 "parallelism": "dp%d (batch-sharded, all-gather logits)" % world},
+  }
+  if build_flags or os.environ.get("SNNQP_DIAG_LIB"):
+    line["DIAGNOSTIC_BUILD"] = build_flags or os.environ.get("SNNQP_DIAG_LIB")
+  if args.stand_in:
+    line["stand_in"] = True
+    print(json.dumps(line))
+    return
+  line.update(rooflines_of(args, prof, B, T, lb))
+  if os.path.exists(PARITY_VS_FLOAT):
+    with open(PARITY_VS_FLOAT) as f:
+      line["parity_vs_float"] = json.load(f).get("summary")
+  if world == 1 and not args.no_cpu_baseline and args.model == "c3":
+    line["cpu_baseline"] = cpu_baseline(args, variables_np)
+  print(json.dumps(line))
+
+
+def rooflines_of(args, prof, B, T, lb):
+  """Per-kernel rooflines from the HIP events recorded on the launch stream inside the timed
+  region: {roofline (dominant kernel), roofline_dense, rooflines, kernels}."""
   kern = {}
   for tag, (n, ms) in prof.items():
     kern[tag] = {"launches": n, "avg_ms": ms / max(n, 1)}
-  fp6 = args.bits <= 4        # codes of magnitude <= 7: fp4 x fp6 MFMA kernel for conv1/conv2
-  conv_peak = FP6_MFMA_PEAK_TOPS if fp6 else INT8_MFMA_PEAK_TOPS
+  nout = args.classes * 10
+
+  def conv_peak(bits):      # codes of magnitude <= 7: fp4 x fp6 MFMA kernel for conv1/conv2
+    return FP6_MFMA_PEAK_TOPS if bits <= 4 else INT8_MFMA_PEAK_TOPS
   # tag: (MACs per launch, algorithmic HBM bytes per launch in the formats the kernels
   #       really read / write, matrix peak of the instruction the kernel issues)
+  in_bytes = 128 * 128 * 2 * (4 if args.input == "f32" else 1)
   spec = {
       "conv3x3[128x128x2->128]": (B * T * 128 * 128 * 128 * 18,
-                                  B * T * (128 * 128 * 2 + 64 * 64 * 16), INT8_MFMA_PEAK_TOPS),
+                                  B * T * (in_bytes + 64 * 64 * 16), INT8_MFMA_PEAK_TOPS),
       "conv3x3[64x64x128->128]": (B * T * 64 * 64 * 128 * 1152,
-                                  B * T * (64 * 64 * 16 + 32 * 32 * 16), conv_peak),
+                                  B * T * (64 * 64 * 16 + 32 * 32 * 16), conv_peak(lb[1])),
       "conv3x3[32x32x128->128]": (B * T * 32 * 32 * 128 * 1152,
-                                  B * T * (32 * 32 * 16 + 16 * 16 * 16), conv_peak),
-      "dense[32768->110]": (B * T * 32768 * 110, B * T * (4096 + 16) + 32768 * 128,
-                            INT8_MFMA_PEAK_TOPS),
+                                  B * T * (32 * 32 * 16 + 16 * 16 * 16), conv_peak(lb[2])),
+      "dense[32768->%d]" % nout: (B * T * 32768 * nout, B * T * (4096 + 16) + 32768 * 128,
+                                  INT8_MFMA_PEAK_TOPS),
   }
   traffic = {}
-  if os.path.exists(PMC_TRAFFIC) and B == 1024 and T == 20:
-    with open(PMC_TRAFFIC) as f:
-      traffic = json.load(f).get("bytes_per_launch", {})
+  if B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3":
+    for path in PMC_TRAFFIC:
+      if os.path.exists(path):
+        with open(path) as f:
+          traffic = json.load(f).get("bytes_per_launch", {})
+        break
 
   def roofline_of(tag):
     k = kern[tag]
@@ -305,19 +482,25 @@ def main():
   # rocprofv3 --stats groups it (conv1 and conv2 are two launches of one kernel):
   # achieved = algorithmic ops (bytes) per launch / average launch duration
   conv_kernel = "conv3x3_bits_kernel"   # one device function, fp6 or int8 instruction inside
+  dense_tag = "dense[32768->%d]" % nout
   groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
             "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
-            "dense_mfma_kernel": ["dense[32768->110]"]}
+            "dense_mfma_kernel": [dense_tag]}
   gtime = {g: sum(kern[t]["avg_ms"] * kern[t]["launches"] for t in tags if t in kern)
            for g, tags in groups.items()}
+  out = {"kernels": kern}
+  if not any(gtime.values()):
+    return out
   dom = max(gtime, key=gtime.get)
   tags = [t for t in groups[dom] if t in kern]
   nl = sum(kern[t]["launches"] for t in tags)
   avg_ms = gtime[dom] / nl
-  ops = sum(2.0 * spec[t][0] * kern[t]["launches"] for t in tags) / nl
+  nops = sum(2.0 * spec[t][0] * kern[t]["launches"] for t in tags) / nl
   nbytes = sum(spec[t][1] * kern[t]["launches"] for t in tags) / nl
-  peak = spec[tags[0]][2]
-  tops, gbs = ops / (avg_ms * 1e-3) / 1e12, nbytes / (avg_ms * 1e-3) / 1e9
+  # launches of one device function may run on different instructions (mixed precision):
+  # the peak is the time-weighted one of the launches
+  peak = sum(spec[t][2] * kern[t]["avg_ms"] * kern[t]["launches"] for t in tags) / gtime[dom]
+  tops, gbs = nops / (avg_ms * 1e-3) / 1e12, nbytes / (avg_ms * 1e-3) / 1e9
   tr = [traffic.get(t) for t in tags]
   roofline = {"kernel": dom, "launches_per_step": len(tags), "layers": tags,
               "avg_launch_ms": avg_ms, "algorithmic_bytes": nbytes,
@@ -329,49 +512,42 @@ def main():
   else:
     roofline.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs / HBM_PEAK_GBS)
-  if "conv3x3[128x128x2->128]" in rooflines:
-    rooflines["conv3x3[128x128x2->128]"]["note"] = (
-        "conv0 does 18 MACs and 0.3 HBM bytes per neuron update; it is bound by VALU issue of "
-        "the neuron epilogue (DESIGN.md 4.2: 78 % of that bound), neither roofline")
-  dn = rooflines.get("dense[32768->110]")
+  c0 = rooflines.get("conv3x3[128x128x2->128]")
+  if c0 is not None:
+    # third, stated ceiling of conv0: VALU issue of the per-neuron epilogue.  updates per
+    # launch x wave-instructions per update (3.5 in the table variant on binary
+    # events) / 64 lanes, against one wave-instruction per SIMD every 4 cycles
+    updates = B * T * 128 * 128 * 128
+    instr_per_update = 3.5
+    ceiling_ms = updates * instr_per_update / 64.0 / (VALU_PEAK_GINSTR * 1e9) * 1e3
+    c0["valu_issue"] = {"updates": updates, "instr_per_update": instr_per_update,
+                        "peak_ginstr_per_s": VALU_PEAK_GINSTR, "ceiling_ms": ceiling_ms,
+                        "frac": ceiling_ms / c0["avg_launch_ms"]}
+    c0["note"] = ("conv0 does 18 MACs and 0.3 HBM bytes per neuron update; it is bound by VALU "
+                  "issue of the neuron epilogue (valu_issue.frac of that ceiling), neither roofline")
+  dn = rooflines.get(dense_tag)
   roofline_dense = None
   if dn is not None:
+    # the read-out cannot reach the HBM roof in a dense-MFMA formulation: at the int8 MFMA
+    # peak the launch would take ops / peak seconds, which caps the HBM fraction at
+    # ceiling_hbm_frac whatever the kernel does
+    macs, nbytes, peak = spec[dense_tag]
+    t_mfma = 2.0 * macs / (peak * 1e12)
     roofline_dense = {"kernel": dn["kernel"], "bound": "hbm",
                       "achieved": kern[dn["kernel"]]["hbm_gbs"], "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": dn["hbm_frac"], "traffic": dn["traffic"],
-                      "avg_launch_ms": dn["avg_launch_ms"], "mfma_frac": dn["mfma_frac"]}
-
-  line = {
-      "metric": "samples/sec/node (DVS128 T=20, 4-bit/90%-pruned)",
-      "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-      "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-      "dtype": "int8",
-      "dtype_detail": "integer codes x integer inputs, exact sums: conv0/dense int8 x u8/binary -> "
-                      "int32 (i8 MFMA); conv1-2 the same integers as fp6 codes x fp4 spikes -> f32 "
-                      "(f8f6f4 MFMA, sums < 2^24 exact); membrane potentials f32",
-      "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
-              % args.lam + ", N(0,1/fan_in) weights, random seeds fixed",
-      "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
-                              "qdense(2048->512->110) + vote, " if args.model == "cextnet" else
-                              "C3: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->110)+LIF + vote, ") +
-                             "DVS128 128x128x2, T=%d, %d-bit, %.0f%% pruned" %
-                             (T, args.bits, args.prune * 100),
-                 "batch_per_gpu": B, "global_batch": world * B, "frames": T,
-                 "parallelism": "dp%d (batch-sharded, all-gather logits)" % world},
-      "roofline": roofline,
-      "roofline_dense": roofline_dense,
-      "rooflines": [rooflines[k] for k in sorted(rooflines)],
-      "kernels": kern,
-  }
-  if world == 1 and not args.no_cpu_baseline and args.model == "c3":
-    line["cpu_baseline"] = cpu_baseline(args, variables_np)
-  print(json.dumps(line))
+                      "avg_launch_ms": dn["avg_launch_ms"], "mfma_frac": dn["mfma_frac"],
+                      "ceiling_hbm_frac": nbytes / t_mfma / 1e9 / HBM_PEAK_GBS,
+                      "ceiling": "int8 MFMA peak: %.3f ms per launch" % (t_mfma * 1e3)}
+  out.update(roofline=roofline, roofline_dense=roofline_dense,
+             rooflines=[rooflines[k] for k in sorted(rooflines)])
+  return out
 
 
 if __name__ == "__main__":
   try:
     main()
   finally:
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-      torch.distributed.destroy_process_group()
+    td = sys.modules.get("torch.distributed")
+    if td is not None and td.is_available() and td.is_initialized():
+      td.destroy_process_group()

@@ -132,6 +132,11 @@ typedef struct {
 
 int snnqp_version(void);
 const char *snnqp_last_error(void);
+/* Extra compiler flags the library was built with: "" for the product build
+ * (snnquantprune_amd/csrc/build.py); diagnostic builds (tools/diag_build.py, written
+ * under build/diag/, never in-tree) report their -D switches here.  Tests and bench.py
+ * refuse a library whose string is not empty. */
+const char *snnqp_build_flags(void);
 
 /* Output spatial size of `g` (same rule as lax.conv_general_dilated). */
 int snnqp_conv_out_shape(const snnqp_conv_geom_t *g, int32_t *OH, int32_t *OW);

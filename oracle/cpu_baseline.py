@@ -18,10 +18,12 @@ def main():
   from oracle import snn_oracle as o
   with np.load(path) as z:
     bits = int(z["bits"])
+    lb = [int(b) for b in z["layer_bits"]] if "layer_bits" in z.files else [bits] * 4
+    which = {"conv0": 0, "conv1": 1, "conv2": 2, "dense": 3}
     def qw(prefix):
       quant = None
       if float(z[prefix + "_a"]) != -1.0:
-        quant = {"kind": "duq", "bits": bits, "a": float(z[prefix + "_a"]), "c": float(z[prefix + "_c"])}
+        quant = {"kind": "duq", "bits": lb[which[prefix]], "a": float(z[prefix + "_a"]), "c": float(z[prefix + "_c"])}
       mask = z[prefix + "_mask"] if (prefix + "_mask") in z.files else None
       return o.QWeight(z[prefix + "_kernel"], quant, mask)
     cq = [qw("conv%d" % i) for i in range(3)]

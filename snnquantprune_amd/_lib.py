@@ -50,6 +50,7 @@ class ConvGeomT(Structure):
 _PROTOTYPES = {
     "snnqp_version": (c_int, []),
     "snnqp_last_error": (c_char_p, []),
+    "snnqp_build_flags": (c_char_p, []),
     "snnqp_conv_out_shape": (c_int, [POINTER(ConvGeomT), POINTER(c_int32),
                                      POINTER(c_int32)]),
     "snnqp_quantize": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_float,
@@ -105,21 +106,42 @@ class SnnqpError(RuntimeError):
 
 
 def lib():
-  """Loads libsnnqp.so once; raises if it is missing (no CPU fallback)."""
+  """Loads libsnnqp.so once; raises if it is missing (no CPU fallback).
+
+  SNNQP_DIAG_LIB=<path> loads a diagnostic build (tools/diag_build.py writes them under
+  build/diag/, never over the in-tree library) instead, and says so on stderr; such a
+  library reports its switches in snnqp_build_flags() and `require_product_build()`
+  (tests, bench.py's default run) refuses it."""
   global _lib
   if _lib is None:
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SNNQP_DIAG_LIB") or LIB_PATH
+    if not os.path.exists(path):
       raise ImportError(
           "HIP extension %s not found: build it with `python __graft_entry__.py` "
-          "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+          "(hipcc --offload-arch=gfx950); there is no CPU fallback." % path)
     import torch  # noqa: F401  (first: libsnnqp must share torch's HIP runtime)
-    handle = ctypes.CDLL(LIB_PATH)
+    handle = ctypes.CDLL(path)
+    if path != LIB_PATH:
+      import sys
+      print("snnquantprune_amd: DIAGNOSTIC library %s" % path, file=sys.stderr)
     for name, (res, args) in _PROTOTYPES.items():
       fn = getattr(handle, name)
       fn.restype = res
       fn.argtypes = args
     _lib = handle
   return _lib
+
+
+def build_flags() -> str:
+  return lib().snnqp_build_flags().decode("utf-8", "replace")
+
+
+def require_product_build():
+  """Raises unless the loaded library is the product build (no diagnostic switches)."""
+  flags = build_flags()
+  if flags or os.environ.get("SNNQP_DIAG_LIB"):
+    raise RuntimeError("libsnnqp is a diagnostic build (%s): rebuild with "
+                       "`python snnquantprune_amd/csrc/build.py --force`" % (flags or "SNNQP_DIAG_LIB"))
 
 
 def check(rc):

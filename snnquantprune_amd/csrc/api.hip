@@ -22,6 +22,11 @@ int snnqp_version(void) { return 100; }  // 0.1.0
 
 const char *snnqp_last_error(void) { return snnqp::g_last_error.c_str(); }
 
+#ifndef SNNQP_BUILD_FLAGS
+#define SNNQP_BUILD_FLAGS ""
+#endif
+const char *snnqp_build_flags(void) { return SNNQP_BUILD_FLAGS; }
+
 int snnqp_conv_out_shape(const snnqp_conv_geom_t *g, int32_t *OH, int32_t *OW) {
   SNNQP_REQUIRE(g && OH && OW, SNNQP_EINVAL, "conv_out_shape: null argument");
   SNNQP_REQUIRE(g->stride_h > 0 && g->stride_w > 0 && g->in_dil_h > 0 &&

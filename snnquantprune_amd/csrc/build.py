@@ -28,14 +28,10 @@ def _stale(out, deps):
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra_flags=()):
+def build(force=False, verbose=True):
+  """The product build: fixed flags, in-tree objects.  Diagnostic / A-B builds never come
+  through here (tools/diag_build.py compiles them into build/diag/<name>/)."""
   hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-  if os.environ.get("SNNQP_CXXFLAGS"):    # A/B experiments, e.g. -DSNNQP_U8C2_WPS=3
-    extra_flags = tuple(extra_flags) + tuple(os.environ["SNNQP_CXXFLAGS"].split())
-    force = True
-  if os.environ.get("SNNQP_PROBE"):       # diagnostic build: in-kernel clock stamps
-    extra_flags = tuple(extra_flags) + ("-DSNNQP_CLOCK_PROBE",)
-    force = True
   headers = [os.path.join(HERE, h) for h in ("common.h", "kernels.h", "conv_tile.h")]
   headers.append(os.path.join(HERE, "..", "..", "include", "snnqp.h"))
   headers.append(os.path.abspath(__file__))
@@ -45,7 +41,7 @@ def build(force=False, verbose=True, extra_flags=()):
     obj = os.path.join(HERE, s.replace(".hip", ".o"))
     objs.append(obj)
     if force or _stale(obj, [src] + headers):
-      jobs.append([hipcc, *FLAGS, *extra_flags, "-c", src, "-o", obj])
+      jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
 
   def run(cmd):
     if verbose:

@@ -299,11 +299,17 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // is negative for negative sums; the LDS address adder wraps, so base + LUT_ZERO is
     // the entry (the compiler folds LUT_ZERO into the offset field: ds_read_b32 ... offset:)
     auto lut_read = [&](auto a4) -> float {       // float accumulators: one v_cvt_i32_f32
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 64)   // diagnostic build: the cvt without the table read
+      return __int_as_float((int)a4);
+#endif
       return *(lds_cfloat_t *)((lds_cu8_t *)lds + LUT_ZERO + (int)a4);
     };
     auto dequant2 = [&](auto a0, auto a1) -> v2f {
       if (LUT) return v2f{lut_read(a0), lut_read(a1)};
       const v2f af = {(float)a0, (float)a1};     // exact integers: the division of common.h
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 512)   // diagnostic build: one-multiply division
+      return (af * a.dq.rL) * a.dq.m;
+#endif
       const v2f q = fma2(af, v2f{a.dq.rL, a.dq.rL}, af * a.dq.rLlo);
       return q * a.dq.m;
     };
@@ -349,9 +355,13 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         if (q == 0) {
           if (j + YD < 8) y[(j + YD) % (YD + 1)] = dequant2(accC[2 * (j + YD)], accC[2 * (j + YD) + 1]);
         } else if (q == 1) {
+#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 128)   // diagnostic build: BatchNorm = the multiply only
+          x = y[j % (YD + 1)] * lc.bmul;
+#else
           x = y[j % (YD + 1)] - lc.bmean;
           x = x * lc.bmul;
           x = x + lc.bbias;
+#endif
         } else if (q == 2) {       // membrane update of the neuron form (conv_tile.h)
           uu = neuron_update<NF, FMA, false>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
           m0 = __ballot(uu.x >= a.nrn.vth);

@@ -3,6 +3,7 @@ symbol include/snnqp.h declares (no compute without a GPU), the module
 protocol produces the reference's variable tree, argument errors surface as the
 reference's exceptions, and the data-parallel path works on gloo."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -35,6 +36,9 @@ def test_library_exports_every_declared_symbol():
     assert hasattr(lib, name), "libsnnqp.so does not export %s" % name
   assert declared == set(L.EXPORTED_SYMBOLS)
   assert lib.snnqp_version() >= 100
+  # the in-tree library is the product build: no diagnostic switch compiled in
+  assert L.build_flags() == ""
+  L.require_product_build()
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -263,3 +267,77 @@ def test_prune_utils_on_cpu_tensors():
   q = prune_utils.update_quant_params(params, gaussian_init, 4)
   np.testing.assert_allclose(float(q["QuantDense_0"]["DuQ_0"]["a"]),
                              float(o.gaussian_init(ks[0], 4)), rtol=2e-6)
+
+
+# ---------------------------------------------------------------------------
+# bench.py plumbing: self-launch, rank environment, metric label
+# ---------------------------------------------------------------------------
+
+
+def _bench(args, env=None, timeout=300):
+  p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+  return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_bench_gpus_2_starts_its_own_ranks_on_gloo():
+  """`python bench.py --gpus 2` with no launcher around it: the parent spawns the ranks, the
+  ranks run bench.py's own step / fence / all-gather / all_reduce(MAX) code (gloo, stand-in
+  for model.apply, which also checks the gathered rows rank by rank) and rank 0's line
+  comes back."""
+  env = {k: v for k, v in os.environ.items()
+         if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+  rc, out, err = _bench(["--gpus", "2", "--backend", "gloo", "--stand-in", "--batch", "6",
+                         "--frames", "3", "--steps", "3", "--warmup", "1"], env)
+  assert rc == 0, err
+  lines = [l for l in out.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, out
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+  assert d["config"]["global_batch"] == 12 and d["config"]["batch_per_gpu"] == 6
+  assert d["scaling"] == "weak" and d["unit"] == "samples/s"
+  assert abs(d["value"] - 12 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_under_an_external_launcher_env():
+  """The driver's form: WORLD_SIZE / RANK / MASTER_* come from torch.distributed.run."""
+  env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+  args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+          "--stand-in", "--batch", "4", "--frames", "2", "--steps", "2", "--warmup", "1"]
+  procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+  outs = [p.communicate(timeout=300) for p in procs]
+  for p, (o, e) in zip(procs, outs):
+    assert p.returncode == 0, e.decode()
+  d = json.loads([l for l in outs[0][0].decode().splitlines() if l.startswith("{")][0])
+  assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8
+  assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]   # rank 0 only
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+  """No GPU here: the nccl ranks die on their first assert and the parent must say so."""
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+  env["SNNQP_BENCH_LAUNCH_TIMEOUT"] = "240"
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("needs a box without a GPU")
+  rc, out, err = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2"], env)
+  assert rc != 0
+  assert "failed" in err and not out.strip()
+
+
+def test_bench_world_size_mismatch_is_an_error():
+  env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+  rc, out, err = _bench(["--gpus", "2", "--backend", "gloo", "--stand-in"], env)
+  assert rc != 0 and "WORLD_SIZE" in err
+
+
+def test_bench_metric_label_follows_the_arguments():
+  sys.path.insert(0, ROOT)
+  import bench
+  assert bench.metric_name(bench.parse([])) == "samples/sec/node (DVS128 T=20, 4-bit/90%-pruned)"
+  assert bench.metric_name(bench.parse(["--bits", "8", "--prune", "0.3"])) == \
+      "samples/sec/node (DVS128 T=20, 8-bit/30%-pruned)"
+  assert bench.metric_name(bench.parse(["--frames", "50", "--layer-bits", "2,4,2,4", "--prune",
+                                        "0.95"])) == \
+      "samples/sec/node (DVS128 T=50, mixed 2/4-bit/95%-pruned)"
