@@ -10,6 +10,7 @@ import torch
 from tests import cases
 
 F32 = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # ---- golden fixtures ---------------------------------------------------------
@@ -224,3 +225,31 @@ def test_masks(oracle):
   gm = oracle.global_prune_masks(ks, 0.5)
   tot = sum(k.size for k in ks)
   assert sum(x.sum() for x in gm) == tot - int(tot * 0.5)
+
+
+def test_int_contract_against_reference_literal_float_at_baseline_size(oracle):
+  """SURVEY 8c / north_star: the kernels' integer contract against the reference's literal
+  float32 arithmetic (flax_qconv.py:158-168, flax_qdense.py:87-89) at BASELINE size: spike
+  rasters equal, membrane potentials within 1e-5 of the threshold scale.  One full-size C3
+  sample (T = 20, 128x128x2: 55 M neuron-steps) and C2 at B = 64 here; the committed report
+  (python -m oracle.int_vs_float --samples 16 -> profiles/r02_int_vs_float.json) covers 16
+  samples and B = 256 and must satisfy the same bounds."""
+  import json
+  from oracle import int_vs_float as ivf
+  c3 = ivf.c3_report(samples=1)
+  c2 = ivf.c2_report(B=64)
+  live = ivf.summarize(c3, c2)
+  with open(os.path.join(ROOT, "profiles", "r02_int_vs_float.json")) as f:
+    committed = json.load(f)
+  assert committed["c3"]["samples"] >= 8
+  assert committed["c3"]["layers"]["conv0"]["neuron_steps"] == committed["c3"]["samples"] * 20 * 128 * 128 * 128
+  for s in (live, committed["summary"]):
+    assert s["max_forced_flip_rate"] <= 1e-6, s
+    assert s["max_free_flip_rate"] <= 1e-5, s
+    assert s["max_u_rel_to_threshold"] <= 1e-5, s      # north_star's 1e-5, on the scale that decides a spike
+    assert s["max_u_rel"] <= 1e-4, s                   # pure relative error where |u| >= 0.01
+  for rep in (c3, committed["c3"]):
+    for name, lay in rep["layers"].items():
+      assert 0.01 < lay["firing_rate"] < 0.5, (name, lay["firing_rate"])
+      assert lay["u_p999_rel"] <= 1e-5, (name, lay)
+  assert c3["argmax_equal"] == "1/1" and c2["argmax_equal"] == "64/64"

@@ -1181,6 +1181,71 @@ def test_full_batch_c3_properties(dev, oracle, bits, prune):
   np.testing.assert_array_equal(_np(sub), full[100:137])
 
 
+@pytest.mark.parametrize("random_bn", [False, True], ids=["bn_default", "bn_random"])
+def test_full_size_c5_against_oracle(dev, oracle, random_bn):
+  """BASELINE config 5 at its own geometry: 128x128x2 input, T = 50 (conv0 stages its halo in
+  chunks of fewer timesteps than T, the spike words are flushed several times per patch),
+  per-layer 2/4/2/4-bit weights (flax_qconv.py:89; 2-bit DuQ codes are {-1, 0, 1}, L = 1,
+  quant.py:458-461), 95 % unstructured prune, 10 classes (read-out 100): every pooled raster,
+  the read-out raster and the logits bit-exact against the int oracle, firing rates in band."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  lb = [2, 4, 2, 4]
+  c = cases.conv_net_case(T=50, B=1, hw=128, p=0.95, layer_bits=lb, out=100, random_bn=random_bn,
+                          gains=(4.0, 5.0, 4.0, 4.0))
+  e = cases.conv_net_expected(oracle, c)
+  assert np.all(e["rates"] > 0.01) and np.all(e["rates"] < 0.5), e["rates"]
+  cfg = syn.make_config(bits=4, prune_percentage=0.95)
+  cfg.quant.layer_bits = lb
+  model = models.ConvDenseSNN(num_classes=10, config=cfg)
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  for inp in (_t(c["x"], dev), _t(c["x"], dev).to(torch.float32)):
+    (logits, _), mut = model.apply(variables, inp, trgt=None, train=False, rng=None,
+                                   mutable=["intermediates"])
+    assert tuple(logits.shape) == (1, 10)
+    for i in range(3):
+      np.testing.assert_array_equal(_np(mut["intermediates"]["pool%d" % i][0]),
+                                    e["pool%d_bits" % i])
+    np.testing.assert_array_equal(
+        _np(mut["intermediates"]["dense_out"][0].to_dense()).astype(np.uint8), e["dense_s"])
+    np.testing.assert_array_equal(_np(logits), e["logits"])
+
+
+def test_full_batch_c5_properties(dev, oracle):
+  """BASELINE config 5 at its per-GPU bench size (B = 4096 / 8 = 512, T = 50, mixed 2/4-bit,
+  95 % pruned) through size-independent properties: batch independence (incl. a sample the
+  oracle also computes), permutation equivariance, repeatability."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  from tests.helpers import bn_of, qweight_of
+  B, T, lb = 512, 50, [2, 4, 2, 4]
+  cfg = syn.make_config(bits=4, prune_percentage=0.95)
+  cfg.quant.layer_bits = lb
+  model = models.ConvDenseSNN(num_classes=10, config=cfg)
+  v = syn.conv_net_variables(prune_p=0.95, out=100)
+  variables = nn.tree_from_numpy(v, dev)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(20261004)
+  x = (torch.rand((B, T, 128, 128, 2), device=dev, generator=gen) < 0.095).to(torch.uint8)
+  (full, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
+  full = _np(full)
+  assert full.shape == (B, 10) and np.isfinite(full).all() and full.std() > 0
+  (again, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(again), full)
+  for b in (0, 5, 300, 511):
+    (one, _) = model.apply(variables, x[b:b + 1], trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(one), full[b:b + 1])
+  perm = torch.randperm(B, device=dev, generator=gen)
+  (pl, _) = model.apply(variables, x[perm].contiguous(), trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(pl), full[perm.cpu().numpy()])
+  # one sample of the batch through the oracle as well
+  p = v["params"]
+  r = oracle.conv3_dense_forward(
+      _np(x[300:301]), [qweight_of(oracle, p["QuantConv_%d" % i], lb[i]) for i in range(3)],
+      [bn_of(v, i) for i in range(3)], qweight_of(oracle, p["QuantDense_0"], lb[3]), mode="int")
+  np.testing.assert_array_equal(full[300:301], r["logits"])
+
+
 def test_eval_step_metrics(dev, oracle):
   from snnquantprune_amd import linen as nn
   from snnquantprune_amd import models, synthetic as syn, train_utils
