@@ -101,11 +101,18 @@ typedef struct {
 
 /* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),
  * mul = rsqrt(var + eps) * scale (examples/tcja/models.py:101-107, applied at
- * spiking_learning.py:457-458).  All three device arrays have Cout entries. */
+ * spiking_learning.py:457-458).  All three device arrays have Cout entries.
+ * `flags`: facts the caller knows about the arrays (it folded them on the host):
+ * SNNQP_BN_MEAN_ZERO / SNNQP_BN_BIAS_ZERO = every mean / bias entry is +-0.0, so that
+ * fl(x - 0) and fl(x + 0) are x itself and a kernel may skip the instruction (a freshly
+ * initialised BatchNorm has both).  0 = nothing known. */
+#define SNNQP_BN_MEAN_ZERO 1
+#define SNNQP_BN_BIAS_ZERO 2
 typedef struct {
   const float *mean;
   const float *mul;
   const float *bias;
+  int32_t flags;
 } snnqp_bn_t;
 
 /* Neuron parameters.  `k`: tau for MULTI_STEP_LIF, sigmoid(tau_param) for

@@ -31,8 +31,11 @@ class WeightT(Structure):
               ("abs_sum_max", c_int32), ("code_max", c_int32), ("min_current_bits", c_uint32)]
 
 
+BN_MEAN_ZERO, BN_BIAS_ZERO = 1, 2
+
+
 class BnT(Structure):
-  _fields_ = [("mean", c_void_p), ("mul", c_void_p), ("bias", c_void_p)]
+  _fields_ = [("mean", c_void_p), ("mul", c_void_p), ("bias", c_void_p), ("flags", c_int32)]
 
 
 class NeuronT(Structure):

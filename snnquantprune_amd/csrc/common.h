@@ -128,6 +128,7 @@ __device__ __forceinline__ bool neuron_step(float &u, float x, const NeuronP &p,
 
 struct BnP {
   const float *mean, *mul, *bias;
+  int flags;            // SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO (caller-asserted)
 };
 
 inline BnP make_bn(const snnqp_bn_t *b) {
@@ -135,6 +136,7 @@ inline BnP make_bn(const snnqp_bn_t *b) {
   p.mean = b ? b->mean : nullptr;
   p.mul = b ? b->mul : nullptr;
   p.bias = b ? b->bias : nullptr;
+  p.flags = b ? b->flags : (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO);
   return p;
 }
 

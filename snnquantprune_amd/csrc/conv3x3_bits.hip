@@ -15,17 +15,21 @@
 // A workgroup is 4 waves on one 4x8-pixel tile (patch), two workgroups per CU = two waves
 // per SIMD: wave w owns output channels [32 w, +32) of the tile, its B fragments for
 // the whole launch (108 registers fp6, 144 int8), the tile's membrane potentials and two
-// accumulator sets.  (SNNQP_BITS_TILES = 2: 8 waves on an 8x8 patch, wave w on tile w >> 2.)  The loop is software-pipelined over t inside each wave: the
-// MFMAs of step t + 1 alternate with the instructions of the neuron epilogue of step
-// t; one workgroup barrier per step.  (Two waves per SIMD measured 10-20 % faster than
-// the one-wave, two-tiles-per-wave form of the int8 kernel this file replaced.)
+// accumulator sets.  The loop is software-pipelined over t inside each wave: step s runs
+// the MFMAs of timestep s + 1 interleaved, slot by slot, with the neuron epilogue of
+// timestep s (one slot = one MFMA, one A-fragment read a few slots ahead, an even share of
+// the epilogue's VALU instructions).
 //
-// The halo of step t + 1 (10 x 10 pixels x Cin spike bits) is expanded to the A format
-// (fp4 by a byte -> 8-nibble LDS table, bytes by arithmetic) and written to the other
-// LDS buffer during step t; its global load was issued a step earlier.  LDS image: one
-// plane per k-step of a tap (64 fp4 / 32 byte channels = 32 B per pixel), rows of 12
-// pixels, the two 16-byte lane halves swapped on odd rows: every tap/half offset is an
-// instruction immediate and the reads are bank-conflict free.
+// Halo images (10 x 6 pixels x Cin spike bits, expanded to the A format: fp4 through a
+// byte -> 8-nibble LDS table, bytes by arithmetic) live in a ring of THREE LDS buffers:
+// during step s the waves read halo(s + 1), write halo(s + 2) early in the step and meet at
+// ONE barrier a few slots later.  Nothing is read across that barrier that was written after
+// the previous one, so the A fragments of step s + 1 are requested during the last slots of
+// step s and the matrix pipe does not drain at a step boundary (with two buffers and the
+// barrier at the end of the step every step began with an LDS round trip).
+// LDS image: one plane per k-step of a tap (64 fp4 / 32 byte channels = 32 B per pixel),
+// rows of 12 pixels, the two 16-byte lane halves swapped on odd rows: every tap/half offset
+// is an instruction immediate and the reads are bank-conflict free.
 #include <type_traits>
 
 #include "conv_tile.h"
@@ -37,27 +41,14 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) const v4i lds_cv4i_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
 
-// k-steps of 64: (tap, 64-channel group); Cin = 64 or 128 (template parameter CIN)
 constexpr int F6_PITCH = HPITCH;             // pixels per LDS halo row (10 used)
-// 4x8-pixel tiles of a workgroup's patch.  1: a workgroup is 4 waves on a 4x8 patch and two
-// of them share a CU -- while one sits at its per-step barrier (the waves of a workgroup
-// drift apart; removing the barrier measured -7 %) the other's waves have the SIMDs: conv1
-// 6.68 -> 6.15 ms although the halo staged per output grows from 100/64 to 60/32 pixels.
-// 2: the 8-wave workgroup on an 8x8 patch, one per CU.
-#ifndef SNNQP_BITS_TILES
-#define SNNQP_BITS_TILES 1
-#endif
-constexpr int F6_TILES = SNNQP_BITS_TILES;
-constexpr int F6_ROWS = 4 * F6_TILES + 2;    // halo rows of a patch
-constexpr int F6_NT = 256 * F6_TILES;        // threads of a workgroup: 4 waves per tile
+constexpr int F6_ROWS = 6;                   // halo rows of a 4x8 patch
+constexpr int F6_NT = 256;                   // threads of a workgroup: 4 waves
 constexpr int F6_PLANE = F6_ROWS * HPITCH * 32;   // one k-step plane of a halo image
-constexpr int F6_TAB = 1024;                 // byte -> 8 fp4 nibbles
-#ifndef SNNQP_F6_PREFETCH
-#define SNNQP_F6_PREFETCH 4
-#endif
-#ifndef SNNQP_F6_YDIST
-#define SNNQP_F6_YDIST 2
-#endif
+constexpr int F6_NBUF = 3;                   // halo images in the ring
+// byte -> 8 fp4 nibbles, 32 interleaved copies: entry e of copy c at dword 32 e + c, so lane
+// l of a 32-lane group reads bank l whatever its byte is (ds_read_b32 banks: (a / 4) % 32)
+constexpr int F6_TAB = 256 * 32 * 4;
 
 // 4 int8 codes (|c| <= 7) -> 4 e2m3 codes, one per byte
 __device__ __forceinline__ uint32_t fp6_codes4(uint32_t x) {
@@ -90,57 +81,53 @@ __device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d
   }
 }
 
-#ifdef SNNQP_F6_TRACE
-// Diagnostic build only: clock stamps of waves 0 and 4 of workgroup 0 inside one
-// timestep (tools/f6_trace.py).  Never in the product.
-__device__ unsigned long long snnqp_f6_trace[2][8];
-extern "C" int snnqp_debug_read_f6_trace(unsigned long long *out16) {
-  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(snnqp_f6_trace), 128);
-}
-#define F6_MARK(i)                                                                  \
-  if (trace_on && t == 10) snnqp_f6_trace[role][i] = __builtin_amdgcn_s_memtime();
-#else
-#define F6_MARK(i)
-#endif
-
 // FMT: the matrix instruction the contraction runs on
 //   FMT_FP6: v_mfma_scale_f32_32x32x64_f8f6f4, fp4 spikes x fp6 codes (|code| <= 7), K = 64
 //   FMT_I8 : v_mfma_i32_32x32x32_i8, byte spikes x int8 codes (any 8-bit code), K = 32
-// Same workgroup shape, LDS image geometry (a plane = the 32 bytes a pixel contributes
-// to one k-step), pipeline and epilogue; the formats differ in the B fragments, the
-// bit -> operand expansion of the halo and the accumulator type.
+// DQ (conv_tile.h): how the accumulator becomes the current fl(fl(acc / L) * m)
+//   DQ_ARITH: three float32 instructions (the exact two-instruction division of common.h)
+//   DQ_ONE  : L == 1 (2-bit DuQ codes, the step quantisers): one multiply
+// (an LDS table indexed by the accumulator, the round-1 form, costs the same time: one v_cvt
+// and one ds_read_b32 per value against three VALU instructions, but its reads are gathers
+// -- 36 % of the kernel's LDS cycles were bank conflicts, 59 % of those from the table)
+// BNF: every BatchNorm mean and bias of the launch is zero (snnqp_bn_t.flags): x = y * mul
 enum { FMT_FP6 = 0, FMT_I8 = 1 };
 
-template <int FMT, int CIN, int NF, bool POOL, bool LUT, bool FMA = false>
-__global__ void __launch_bounds__(F6_NT, 2 / F6_TILES)
+#ifndef SNNQP_F6_WR_SLOT
+#define SNNQP_F6_WR_SLOT 2     // slot of a step after which the staged halo is written
+#endif
+#ifndef SNNQP_F6_BAR_SLOT
+#define SNNQP_F6_BAR_SLOT 4    // slot of a step after which the step's barrier sits
+#endif
+#ifndef SNNQP_F6_PF
+#define SNNQP_F6_PF 4          // A fragments in flight (ring of 6); 2 when a step has 9 slots
+#endif
+
+template <int FMT, int CIN, int NF, bool POOL, int DQ, bool FMA = false, bool BNF = false>
+__global__ void __launch_bounds__(F6_NT, 2)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
+  static_assert(DQ == DQ_ARITH || DQ == DQ_ONE, "dequantisation mode");
   constexpr bool I8 = FMT == FMT_I8;
   typedef typename std::conditional<I8, v16i, v16f>::type acc_t;
   constexpr int KCH = I8 ? 32 : 64;              // input channels of one k-step
   constexpr int BR = I8 ? 4 : 6;                 // registers of one B fragment
   constexpr int NP = CIN / KCH;                  // planes of the halo image
   constexpr int WPP = CIN / 32;                  // spike words per pixel
-  constexpr int F6_KS = 9 * NP;
-  constexpr int F6_HALO = NP * F6_PLANE;         // one fp4 halo image
-  constexpr int PPS = (32 + F6_KS - 1) / F6_KS;  // epilogue pieces per MFMA slot
+  constexpr int KS = 9 * NP;                     // MFMAs (slots) of one timestep
+  constexpr int HALO_B = NP * F6_PLANE;          // one halo image
   constexpr int FL = POOL ? 16 : 4;              // timesteps per flush block
   constexpr int SLOTS = 2 * FL;                  // ring of staged spike words
-  constexpr int NPIX = OutStage<POOL>::NPIX * F6_TILES / 2;
-  constexpr int TAB_OFF = 2 * F6_HALO;
-  constexpr int LUT_OFF = TAB_OFF + F6_TAB;
-  constexpr int LUT_BYTES = LUT ? (2 * LUT_CAP + 2) * 4 : 0;
-  constexpr int LUT_ZERO = LUT_OFF + 4 * LUT_CAP;
-  static_assert(LUT_ZERO < 65536, "the table's centre must be a ds_read immediate offset");
-  constexpr int OB_OFF = LUT_OFF + LUT_BYTES;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16 + 16];
+  constexpr int NPIX = OutStage<POOL>::NPIX / 2;
+  constexpr int TAB_OFF = F6_NBUF * HALO_B;
+  constexpr int OB_OFF = TAB_OFF + (I8 ? 0 : F6_TAB);
+  __shared__ __attribute__((aligned(128))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16 + 16];
   uint32_t *nxt = (uint32_t *)(lds + OB_OFF + SLOTS * NPIX * 16);   // claimed patch (PatchWalk)
   uint32_t *obuf = (uint32_t *)(lds + OB_OFF);
   const uint32_t lds0 = lds_addr(lds) & 0x3FFFFu;   // < 2^18: offsets fold into immediates
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
-  const int role = F6_TILES == 2 ? wave >> 2 : 0;   // the tile (4x8 pixels) of this wave
   const int cg = wave & 3;
   const int cout_base = blockIdx.y * 128 + cg * 32;
   const bool wave_on = cout_base < a.Cout;
@@ -148,26 +135,24 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
   const uint32_t cmask = chan_mask(cout_base, a.Cout);
 
-  // tables: byte -> 8 nibbles (bit i set -> 1.0 = 0x2 in nibble i); dequant table
-  if (!I8 && tid < 256) {                        // (int8: bits -> bytes by arithmetic)
-    uint32_t v = 0;
+  // table: byte -> 8 nibbles (bit i set -> 1.0 = 0x2 in nibble i), 32 copies
+  if (!I8) {                                     // (int8: bits -> bytes by arithmetic)
+    for (int i = tid; i < 256 * 32; i += F6_NT) {
+      const int e = i >> 5;
+      uint32_t v = 0;
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) v |= ((tid >> bit) & 1) ? (0x2u << (4 * bit)) : 0u;
-    ((uint32_t *)(lds + TAB_OFF))[tid] = v;
+      for (int bit = 0; bit < 8; ++bit) v |= ((e >> bit) & 1) ? (0x2u << (4 * bit)) : 0u;
+      ((uint32_t *)(lds + TAB_OFF))[i] = v;
+    }
   }
-  // the entry of acc = 0 sits at the fixed byte LUT_ZERO whatever the launch's bound is,
-  // so the table read takes the (signed) accumulator as its address register and
-  // LUT_ZERO as the instruction's immediate offset
-  if (LUT) build_lut((float *)(lds + LUT_OFF) + (LUT_CAP - a.lut_bound), a.lut_bound, a.dq, tid, F6_NT);
-
   // B operand: k-step ks = NP tap + kk covers channels 64 kk .. +63 of the tap; lane
   // (n, h) holds k = 32 h + j, i.e. both 16-byte halves of int8 tile WPP tap + 2 kk + h
   // (int8: k-step ks = WPP tap + kk is int8 tile ks as it is, lane (n, h) holds k = 16 h + j)
-  int bf[F6_KS][BR];
+  int bf[KS][BR];
   {
     const v4i *wtile = (const v4i *)a.wt + (int64_t)(cout_base >> 5) * (9 * WPP) * 64;
 #pragma unroll
-    for (int ks = 0; ks < F6_KS; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       if constexpr (I8) {
         const v4i t = wave_on ? wtile[ks * 64 + lane] : v4i{0, 0, 0, 0};
         bf[ks][0] = t.x; bf[ks][1] = t.y; bf[ks][2] = t.z; bf[ks][3] = t.w;
@@ -187,18 +172,15 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
   if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
-  // table mode: spikes count 4 (block scale 2^2 on A / spike bytes of 4), so the accumulator
-  // is the byte offset of its table entry from the entry of acc = 0.  The chain starts from
-  // the inline constant 0: no accumulator preload in either mode.
-  constexpr int SCALE_A = LUT ? 129 : 127;       // E8M0: 2^(s - 127)
+  constexpr int SCALE_A = 127;                   // E8M0: 2^(s - 127); the chain starts from
+                                                 // the inline constant 0: no accumulator preload
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
   const int tx = (n & 3) | (((n >> 3) & 1) << 2);
-  // A fragment of tap (dy, dx), half kk: pixel (4 role + ty + dy, tx + dx), 32 B per
-  // pixel, the two 16-byte lane halves swapped on odd halo rows.  With the 12-pixel
-  // row pitch this makes every ds_read_b128 of the wave bank-conflict free
-  // (tools/ubench/lds_conv_patterns.hip: 222 B/clk/CU against 63 for the plain layout).
-  const uint32_t pixb = lds0 + (uint32_t)(((role * 4 + ty) * F6_PITCH + tx) * 32);
+  // A fragment of tap (dy, dx), half kk: pixel (ty + dy, tx + dx), 32 B per pixel, the two
+  // 16-byte lane halves swapped on odd halo rows.  With the 12-pixel row pitch this makes
+  // every ds_read_b128 of the wave bank-conflict free (tools/ubench/lds_conv_patterns.hip).
+  const uint32_t pixb = lds0 + (uint32_t)((ty * F6_PITCH + tx) * 32);
   const uint32_t abase_even = pixb + (uint32_t)((h ^ (ty & 1)) * 16);       // dy = 0, 2
   const uint32_t abase_odd = pixb + (uint32_t)((h ^ (ty & 1) ^ 1) * 16);    // dy = 1
 
@@ -210,18 +192,16 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const int wpm = (a.Cin + 31) >> 5;
   const int s_hy = s_pix / HALO, s_hx = s_pix % HALO;
   // fp4: word wi = half wi & 1 of plane wi >> 1; bytes: word wi = both halves of plane wi
-  uint8_t *s_dst = lds + (I8 ? s_wi : s_wi >> 1) * F6_PLANE + (s_hy * F6_PITCH + s_hx) * 32 +
-                   ((((I8 ? 0 : s_wi) & 1) ^ (s_hy & 1)) * 16);
-  const uint32_t tab0 = lds0 + TAB_OFF;
+  const uint32_t s_dst = lds0 + (uint32_t)((I8 ? s_wi : s_wi >> 1) * F6_PLANE +
+                                           (s_hy * F6_PITCH + s_hx) * 32 +
+                                           ((((I8 ? 0 : s_wi) & 1) ^ (s_hy & 1)) * 16));
+  const uint32_t tabl = lds0 + TAB_OFF + (uint32_t)(lane & 31) * 4;   // this lane's table copy
   const uint32_t *xb = (const uint32_t *)a.x;
 
-  const int ob = out_pix<POOL>(role, lane) * 4 + cg;
+  const int ob = out_pix<POOL>(0, lane) * 4 + cg;
   const bool store_lane = POOL ? lane < 8 : lane < 32;
 
   lds_barrier();                                 // tables are visible
-#ifdef SNNQP_F6_TRACE
-  const bool trace_on = blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && cg == 0;
-#endif
 
   PatchWalk pw(a);
   int r = (int)pw.first;                 // patch indices fit 31 bits (launch check)
@@ -233,7 +213,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
     float u[16];
     if (a.u0 && wave_on) {
-      u_io_tile<true>(u, a, b, y0, x0, cout, h, role);
+      u_io_tile<true>(u, a, b, y0, x0, cout, h, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) u[i] = 0.0f;
@@ -254,30 +234,32 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         stg_cur = stgq[par];
       } else if (s_task) {
         const uint32_t sw = stgq[par];
-        s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw << 2) & 0x3FCu));
-        s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 6) & 0x3FCu));
-        s_exp.z = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 14) & 0x3FCu));
-        s_exp.w = (int)*(lds_cu32_t *)(uintptr_t)(tab0 + ((sw >> 22) & 0x3FCu));
+        // byte k of the word -> entry (byte << 7) of this lane's copy: conflict-free whatever
+        // the bytes of the 32 lanes are
+        s_exp.x = (int)*(lds_cu32_t *)(uintptr_t)(((sw & 0xFFu) << 7) + tabl);
+        s_exp.y = (int)*(lds_cu32_t *)(uintptr_t)((((sw >> 8) & 0xFFu) << 7) + tabl);
+        s_exp.z = (int)*(lds_cu32_t *)(uintptr_t)((((sw >> 16) & 0xFFu) << 7) + tabl);
+        s_exp.w = (int)*(lds_cu32_t *)(uintptr_t)(((sw >> 24) << 7) + tabl);
       }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](uint32_t bufoff) {
+      typedef __attribute__((address_space(3))) v4i lds_v4i_t;
       if (I8) {
         if (s_task) {
-          uint8_t *d = s_dst + buf * F6_HALO;
-          *(v4i *)d = expand16<LUT>(stg_cur & 0xFFFFu);                 // channels 0..15
-          *(v4i *)(d + (s_hy & 1 ? -16 : 16)) = expand16<LUT>(stg_cur >> 16);
+          const uint32_t d = s_dst + bufoff;
+          *(lds_v4i_t *)(uintptr_t)d = expand16<false>(stg_cur & 0xFFFFu);        // channels 0..15
+          *(lds_v4i_t *)(uintptr_t)(s_hy & 1 ? d - 16 : d + 16) = expand16<false>(stg_cur >> 16);
         }
       } else if (s_task) {
-        *(v4i *)(s_dst + buf * F6_HALO) = s_exp;
+        *(lds_v4i_t *)(uintptr_t)(s_dst + bufoff) = s_exp;
       }
     };
-    auto a_read = [&](int buf, int ks) -> v4i {
+    // A fragment of k-step ks from the halo image whose lane bases are (aeven, aodd)
+    auto a_read = [&](uint32_t aeven, uint32_t aodd, int ks) -> v4i {
       const int tap = ks / NP;
-      const uint32_t off = (uint32_t)(buf * F6_HALO + (ks % NP) * F6_PLANE +
-                                      ((tap / 3) * F6_PITCH + tap % 3) * 32);
-      return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? abase_odd : abase_even) + off);
+      const uint32_t off = (uint32_t)((ks % NP) * F6_PLANE + ((tap / 3) * F6_PITCH + tap % 3) * 32);
+      return *(lds_cv4i_t *)(uintptr_t)(((tap / 3) & 1 ? aodd : aeven) + off);
     };
-    constexpr int PF = SNNQP_F6_PREFETCH;        // A fragments in flight ahead of the MFMA
     auto mfma_acc = [&](int ks, const v4i &av, const acc_t &c) -> acc_t {
       if constexpr (I8) {
         return __builtin_amdgcn_mfma_i32_32x32x32_i8(
@@ -289,207 +271,246 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
             4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
       }
     };
-    auto mfma_one = [&](int ks, const v4i &av, acc_t &acc) { acc = mfma_acc(ks, av, acc); };
-    // the first MFMA of a chain takes C = 0 (an inline constant of the instruction)
-    auto mfma_first = [&](const v4i &av, acc_t &acc) {
-      const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      acc = mfma_acc(0, av, zero16);
-    };
-    // table entry of the accumulator value a4 = 4 acc: address register = (int)a4, which
-    // is negative for negative sums; the LDS address adder wraps, so base + LUT_ZERO is
-    // the entry (the compiler folds LUT_ZERO into the offset field: ds_read_b32 ... offset:)
-    auto lut_read = [&](auto a4) -> float {       // float accumulators: one v_cvt_i32_f32
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 64)   // diagnostic build: the cvt without the table read
-      return __int_as_float((int)a4);
-#endif
-      return *(lds_cfloat_t *)((lds_cu8_t *)lds + LUT_ZERO + (int)a4);
-    };
-    auto dequant2 = [&](auto a0, auto a1) -> v2f {
-      if (LUT) return v2f{lut_read(a0), lut_read(a1)};
-      const v2f af = {(float)a0, (float)a1};     // exact integers: the division of common.h
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 512)   // diagnostic build: one-multiply division
-      return (af * a.dq.rL) * a.dq.m;
-#endif
-      const v2f q = fma2(af, v2f{a.dq.rL, a.dq.rL}, af * a.dq.rLlo);
+    const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto dequant1 = [&](auto a0) -> float {
+      const float af = (float)a0;                // exact integer
+      if (DQ == DQ_ONE) return af * a.dq.m;      // L == 1
+      const float q = __builtin_fmaf(af, a.dq.rL, af * a.dq.rLlo);   // exact af / L (common.h)
       return q * a.dq.m;
     };
-    // MFMA(0) of a patch: nothing to overlap with
-    auto mfma_only = [&](int buf, acc_t &acc) {
-      v4i A[PF + 1];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < F6_KS; ++ks) {
-        if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
-        if (ks == 0) mfma_first(A[0], acc);
-        else mfma_one(ks, A[ks % (PF + 1)], acc);
-        __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the neuron epilogue of one timestep as a list of small stages -----------------
+    // pair j = accumulator registers 2j, 2j + 1 (two pixels of this lane's channel):
+    //   stage 0  dequantise
+    //   stage 1  BatchNorm sub, mul        stage 2  BatchNorm add, membrane update
+    //            (BNF: the multiply only)
+    //   stage 3  threshold                 stage 4  reset + spike word
+    // Executed strictly in order; the slots of a pipelined step take an even share each.
+    constexpr int NST = 5;
+    constexpr int YD = 0;                        // pairs the dequantisation runs ahead
+    // (the temporaries live inside a step: masks that crossed the loop's back edge would
+    // leave the scalar registers)
+#ifndef SNNQP_F6_ABL
+#define SNNQP_F6_ABL 0          // diagnostic builds only (tools/diag_build.py)
+#endif
+    // The spike word: the compare masks are wave-uniform 64-bit lane masks (lane = channel).
+    // Combining them is scalar work (s_or) that feeds a v_writelane; issued right behind the
+    // v_cmp that produced the masks, each of those hops stalls the wave (VALU -> SALU -> VALU
+    // round trips: 0.5 of 4.3 ms measured), so the masks of pair j are combined during pair
+    // j + 1 and written into the word during pair j + 2.
+    struct ETmp {
+      float ey[YD + 1][2], ex[2], euu[2];
+      unsigned long long m0[8], m1[8];
+      uint32_t pw[8];                            // pooled word of a pair (scalar)
+      uint32_t ew;
+    };
+    auto word_combine = [&](ETmp &e, int j) {    // scalar: masks of pair j -> its pooled word
+      if (POOL) {
+        const unsigned long long o = e.m0[j] | e.m1[j];
+        e.pw[j] = (uint32_t)o | (uint32_t)(o >> 32);
       }
     };
-    // One pipelined step in a hand-placed order: 9 NP slots, each = one A read PF
-    // k-steps ahead, one MFMA of step t + 1 and two quarter-pairs of the epilogue of
-    // step t (8 pairs x 4 pieces = 32 pieces), fenced so the order survives.  An MFMA
-    // that waits at the issue port (matrix pipe busy, or its accumulator not ready)
-    // blocks VALU issue for every wave of the SIMD -- another wave's VALU work does
-    // NOT overlap a back-to-back MFMA chain (tools/ubench/mfma_valu_2waves.hip: time =
-    // sum) -- so each wave spaces its MFMAs with its own epilogue instructions.
-    //   piece 0 (pair j + YD): dequantise (table reads or packed arithmetic), far enough
-    //                          ahead that the LDS round trip is over when piece 1 wants it
-    //   piece 1 (pair j)    : BatchNorm (3 packed ops)
-    //   piece 2 (pair j)    : membrane update (3 packed ops) + threshold compares
-    //   piece 3 (pair j)    : reset + spike word select
-    auto fused_step = [&](int buf, acc_t &accN, const acc_t &accC, int t) {
-      v4i A[PF + 1];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) A[i] = a_read(buf, i);
-      constexpr int YD = SNNQP_F6_YDIST;         // pairs the table reads run ahead
-      v2f y[YD + 1], x = {0.f, 0.f}, uu = {0.f, 0.f};
-      unsigned long long m0 = 0, m1 = 0;
-      uint32_t w = 0;
-#pragma unroll
-      for (int j = 0; j < YD; ++j) y[j] = dequant2(accC[2 * j], accC[2 * j + 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      auto piece = [&](int p) {
-        const int j = p >> 2, q = p & 3;
-        if (q == 0) {
-          if (j + YD < 8) y[(j + YD) % (YD + 1)] = dequant2(accC[2 * (j + YD)], accC[2 * (j + YD) + 1]);
-        } else if (q == 1) {
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 128)   // diagnostic build: BatchNorm = the multiply only
-          x = y[j % (YD + 1)] * lc.bmul;
-#else
-          x = y[j % (YD + 1)] - lc.bmean;
-          x = x * lc.bmul;
-          x = x + lc.bbias;
-#endif
-        } else if (q == 2) {       // membrane update of the neuron form (conv_tile.h)
-          uu = neuron_update<NF, FMA, false>(x, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
-          m0 = __ballot(uu.x >= a.nrn.vth);
-          m1 = __ballot(uu.y >= a.nrn.vth);
+    auto word_insert = [&](ETmp &e, int j) {     // v_writelane: pair j into the stored word
+      const int i = 2 * j;
+      if (POOL) {
+        e.ew = writelane_u32(e.pw[j], i >> 1, e.ew);
+      } else {
+        const int r0 = (i & 3) + 8 * (i >> 2);
+        e.ew = writelane_u32((uint32_t)e.m0[j], r0, e.ew);
+        e.ew = writelane_u32((uint32_t)(e.m0[j] >> 32), r0 + 4, e.ew);
+        e.ew = writelane_u32((uint32_t)e.m1[j], r0 + 1, e.ew);
+        e.ew = writelane_u32((uint32_t)(e.m1[j] >> 32), r0 + 5, e.ew);
+      }
+    };
+    auto estage = [&](const acc_t &accC, int st, ETmp &e) {
+      const int j = st / NST, q = st % NST;
+      if (q == 0) {
+        if (SNNQP_F6_ABL & 64) {          // diagnostic: no dequantisation
+          e.ey[(j + YD) % (YD + 1)][0] = accC[2 * j]; e.ey[(j + YD) % (YD + 1)][1] = accC[2 * j + 1];
+        } else
+        if (j + YD < 8) {
+          e.ey[(j + YD) % (YD + 1)][0] = dequant1(accC[2 * (j + YD)]);
+          e.ey[(j + YD) % (YD + 1)][1] = dequant1(accC[2 * (j + YD) + 1]);
+        }
+      } else if (q == 1) {
+        if (SNNQP_F6_ABL & 128) { e.ex[0] = e.ey[j % (YD + 1)][0]; e.ex[1] = e.ey[j % (YD + 1)][1]; }
+        else if (BNF) {                   // mean == 0: fl(y - 0) = y
+          e.ex[0] = e.ey[j % (YD + 1)][0] * lc.bmul;
+          e.ex[1] = e.ey[j % (YD + 1)][1] * lc.bmul;
         } else {
-          u[2 * j] = neuron_reset<NF>(uu.x, m0, lc);
-          u[2 * j + 1] = neuron_reset<NF>(uu.y, m1, lc);
-          const int i = 2 * j;
-          if (POOL) {
-            const unsigned long long o = m0 | m1;
-            w = writelane_u32((uint32_t)o | (uint32_t)(o >> 32), i >> 1, w);
-          } else {
-            const int r0 = (i & 3) + 8 * (i >> 2);
-            w = writelane_u32((uint32_t)m0, r0, w);
-            w = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, w);
-            w = writelane_u32((uint32_t)m1, r0 + 1, w);
-            w = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, w);
-          }
+          e.ex[0] = (e.ey[j % (YD + 1)][0] - lc.bmean) * lc.bmul;
+          e.ex[1] = (e.ey[j % (YD + 1)][1] - lc.bmean) * lc.bmul;
         }
-      };
-#pragma unroll
-      for (int ks = 0; ks < F6_KS; ++ks) {
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 32)   // diagnostic build: half of the A reads
-        if (ks + PF < F6_KS) {
-          if ((ks & 1) == 0) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
-          else A[(ks + PF) % (PF + 1)] = A[(ks + PF - 1) % (PF + 1)];
+      } else if (q == 2) {                // (bias == 0: fl(x + 0) = x)
+        const v2f xx = ((SNNQP_F6_ABL & 128) || BNF) ? v2f{e.ex[0], e.ex[1]}
+                                                     : v2f{e.ex[0] + lc.bbias, e.ex[1] + lc.bbias};
+        const v2f uu = neuron_update<NF, FMA, false>(xx, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
+        e.euu[0] = uu.x; e.euu[1] = uu.y;
+      } else if (q == 3) {
+        if (SNNQP_F6_ABL & 256) return;   // diagnostic: no threshold / reset / spike word
+        e.m0[j] = __ballot(e.euu[0] >= a.nrn.vth);
+        e.m1[j] = __ballot(e.euu[1] >= a.nrn.vth);
+      } else {
+        if (SNNQP_F6_ABL & 256) { u[2 * j] = e.euu[0]; u[2 * j + 1] = e.euu[1]; return; }
+        u[2 * j] = neuron_reset<NF>(e.euu[0], e.m0[j], lc);
+        u[2 * j + 1] = neuron_reset<NF>(e.euu[1], e.m1[j], lc);
+        if (SNNQP_F6_ABL & 512) return;   // diagnostic: no spike word
+        if (j >= 1) word_combine(e, j - 1);
+        if (j >= 2) word_insert(e, j - 2);
+        if (j == 7) {                     // drain
+          word_insert(e, 6);
+          word_combine(e, 7);
+          word_insert(e, 7);
         }
-#else
-        if (ks + PF < F6_KS) A[(ks + PF) % (PF + 1)] = a_read(buf, ks + PF);
-#endif
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1)   // diagnostic build: 2 of 18 MFMAs
-        if (ks < 2)
-#endif
-        if (ks == 0) mfma_first(A[0], accN);
-        else mfma_one(ks, A[ks % (PF + 1)], accN);
-#if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 2))   // diagnostic build: no epilogue
-#pragma unroll
-        for (int q = 0; q < PPS; ++q)
-          if (ks * PPS + q < 32) piece(ks * PPS + q);
-#endif
-        // pin the slot: everything it produced is an operand of an (empty) volatile
-        // asm, so neither the MFMA nor the pieces can drift to another slot (the
-        // scheduling fence alone does not stop earlier passes from clustering the
-        // MFMAs at the end of the step)
-        // (the table reads stay free: tying them would wait out an LDS round trip)
-        asm volatile("" : "+v"(accN), "+v"(x), "+v"(uu), "+v"(w), "+s"(m0), "+s"(m1));
-        __builtin_amdgcn_sched_barrier(0);
       }
-      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
     };
-    auto epilogue = [&](const acc_t &acc, int t) {
-      v2f y[8];
+    auto estage_head = [&](const acc_t &accC, ETmp &e) {   // the dequantisations that run ahead
+      e.ew = 0;
+      e.ex[0] = e.ex[1] = e.euu[0] = e.euu[1] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = dequant2(acc[2 * j], acc[2 * j + 1]);
-      const uint32_t w = tile_neurons<NF, POOL, false, FMA>(y, u, lc, a.nrn);
-      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = w & cmask;
+      for (int j = 0; j <= YD; ++j) e.ey[j][0] = e.ey[j][1] = 0.f;
+#pragma unroll
+      for (int j = 0; j < YD; ++j) {
+        e.ey[j][0] = dequant1(accC[2 * j]);
+        e.ey[j][1] = dequant1(accC[2 * j + 1]);
+      }
     };
-    // staging of halo(t2) into its buffer around a step: the table reads go first, the
-    // word of halo(t2 + 1) is requested as soon as its register is free (one step ahead is
-    // enough: two steps ahead measured the same), the LDS
-    // write comes after the step's MFMAs
-    auto stage_begin = [&](int t2, int par) {    // par = t2 & 1, a constant at every call
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 4)   // diagnostic build: no halo staging
-      return;
-#endif
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1024)   // diagnostic build: halo staged for t = 0, 1 only
-      if (t2 >= 2) return;
-#endif
-      if (t2 < a.T) stage_expand(par);
-      if (t2 + 2 < a.T) stage_load(t2 + 2, par);
-    };
-    auto stage_end = [&](int t2) {
-#if defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 1024)
-      if (t2 >= 2) return;
-#endif
-      if (t2 < a.T) stage_write(t2 & 1);
-    };
-    // one pipeline step: MFMA(t + 1) || epilogue(t); halo(t + 2) staged meanwhile.
-    // One barrier per step: inside it every wave reads halo(t + 1) and writes
-    // halo(t + 2) into the other buffer.
-    auto step = [&](int t, int par, acc_t &accN, const acc_t &accC) {
-#if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 8))   // diagnostic build: no flush
-      if (t >= FL && t % FL == 0)                // steps < t are behind a barrier
-        flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, t - FL, FL, b, y0, x0, tid);
-#endif
-      F6_MARK(0)
-      stage_begin(t + 2, par);
-      F6_MARK(1)
-      fused_step((t + 1) & 1, accN, accC, t);
-      F6_MARK(2)
-      stage_end(t + 2);
-      F6_MARK(3)
-#if !(defined(SNNQP_F6_ABL) && (SNNQP_F6_ABL & 256))   // diagnostic build: no per-step barrier (races)
-      lds_barrier();
-#endif
-      F6_MARK(4)
+    constexpr int NSTAGES = 8 * NST;             // 40 stages per timestep
+    auto store_word = [&](int t, uint32_t ew) {
+      if (store_lane) obuf[(t % SLOTS) * (NPIX * 4) + ob] = ew & cmask;
     };
 
-    // pipeline prologue: halo(0) staged; MFMA(0) while halo(1) is staged
+    // ---- A-fragment ring: PF fragments in flight, across step boundaries ----------------
+    constexpr int RING = KS % 6 == 0 ? 6 : 3;    // divides KS (9, 18, 36): static indices
+    constexpr int PF = RING == 6 ? (SNNQP_F6_PF < 6 ? SNNQP_F6_PF : 5) : 2;
+    static_assert(KS % RING == 0 && PF < RING, "ring indices must repeat every step");
+    v4i A[RING];
+
+    // One pipelined step s: MFMA(s + 1) from the image (rd_e, rd_o) while the epilogue of
+    // timestep s runs on accC; halo(s + 2) is written early, the barrier follows two slots
+    // later; the last PF slots request the first fragments of the NEXT step from (rn_e, rn_o).
+    constexpr int WR_SLOT = SNNQP_F6_WR_SLOT < KS - PF - 2 ? SNNQP_F6_WR_SLOT : 1;
+    constexpr int BAR_SLOT = SNNQP_F6_BAR_SLOT < KS - PF ? (SNNQP_F6_BAR_SLOT > WR_SLOT ? SNNQP_F6_BAR_SLOT : WR_SLOT + 1) : WR_SLOT + 1;
+    static_assert(BAR_SLOT < KS - PF, "the next step's fragments are read after the barrier");
+    auto fused_step = [&](acc_t &accN, const acc_t &accC, int s, uint32_t rd_e, uint32_t rd_o,
+                          uint32_t rn_e, uint32_t rn_o, uint32_t wr_off, int par, bool more) {
+      if (!(SNNQP_F6_ABL & 4)) {
+      if (s + 2 < a.T) stage_expand(par);
+      if (s + 4 < a.T) stage_load(s + 4, par);
+      }
+      ETmp e;
+      estage_head(accC, e);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks == 0) accN = mfma_acc(0, A[0], zero16);    // C = inline 0: no preload
+        else if (!(SNNQP_F6_ABL & 1) || ks < 2) accN = mfma_acc(ks, A[ks % RING], accN);
+        __builtin_amdgcn_sched_barrier(0);
+        // the slot's A read: PF slots ahead, wrapping into the next step's image
+        if (!(SNNQP_F6_ABL & 32)) {
+        if (ks + PF < KS) A[(ks + PF) % RING] = a_read(rd_e, rd_o, ks + PF);
+        else if (more) A[(ks + PF) % RING] = a_read(rn_e, rn_o, ks + PF - KS);
+        }
+        // an even share of the epilogue stages
+        {
+          const int lo = ks * NSTAGES / KS, hi = (ks + 1) * NSTAGES / KS;
+          if (!(SNNQP_F6_ABL & 2))
+#pragma unroll
+          for (int st = lo; st < hi; ++st) estage(accC, st, e);
+        }
+        if (!(SNNQP_F6_ABL & 4))
+        if (ks == WR_SLOT && s + 2 < a.T) stage_write(wr_off);
+        if (ks == BAR_SLOT) {
+          if (!(SNNQP_F6_ABL & 16)) {
+#ifdef SNNQP_F6_FULL_BARRIER
+          lds_barrier();
+#else
+          // The barrier publishes the halo image written in slot WR_SLOT (and the spike word
+          // stored at the end of the previous step).  LDS operations of a wave complete in
+          // order, and at least BAR_SLOT - WR_SLOT of them (the A reads of the slots in
+          // between) were issued after that write: waiting until so many are outstanding
+          // retires the write without draining the A fragments in flight across the barrier
+          // (lgkmcnt(0), which a release fence emits, cost an LDS round trip per step).  No
+          // scalar load is in flight here (they return out of order): the loop has none.
+          asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_SLOT - WR_SLOT) : "memory");
+#endif
+          }
+          if (!(SNNQP_F6_ABL & 8))
+          if (s >= FL && s % FL == 0)              // timesteps < s are behind this barrier
+            flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, s - FL, FL, b, y0, x0, tid);
+        }
+        // pin the slot: what it produced is an operand of an (empty) volatile asm, so neither
+        // the MFMA nor the stages drift into another slot
+        asm volatile("" : "+v"(accN), "+v"(e.ey[0][0]), "+v"(e.ey[0][1]), "+v"(e.ex[0]), "+v"(e.ex[1]),
+                     "+v"(e.euu[0]), "+v"(e.euu[1]), "+v"(e.ew));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      store_word(s, e.ew);
+    };
+    auto epilogue = [&](const acc_t &acc, int t) {
+      ETmp e;
+      estage_head(acc, e);
+#pragma unroll
+      for (int st = 0; st < NSTAGES; ++st) estage(acc, st, e);
+      store_word(t, e.ew);
+    };
+
+    // lane bases of the halo images: halo(t) lives in image t % 3 of the ring
+    auto img_e = [&](int k) { return abase_even + (uint32_t)(k * HALO_B); };
+    auto img_o = [&](int k) { return abase_odd + (uint32_t)(k * HALO_B); };
+
+    // pipeline prologue: halo(0), halo(1) staged; MFMA(0) alone
     acc_t accA, accB;
     stage_load(0, 0);
     if (a.T > 1) stage_load(1, 1);
-    stage_begin(0, 0);
-    stage_end(0);
-    lds_barrier();
-    stage_begin(1, 1);
-    mfma_only(0, accA);
-    stage_end(1);
-    lds_barrier();
-
-    // steady state, unrolled by two so the accumulator roles alternate
-    int t = 0;
-    for (; t + 2 < a.T; t += 2) {
-      step(t, 0, accB, accA);
-      step(t + 1, 1, accA, accB);
+    stage_expand(0);
+    if (a.T > 2) stage_load(2, 0);
+    stage_write(0u);
+    if (a.T > 1) {
+      stage_expand(1);
+      if (a.T > 3) stage_load(3, 1);
+      stage_write((uint32_t)HALO_B);
     }
-    if (t + 1 < a.T) {
-      step(t, 0, accB, accA);
-      epilogue(accB, t + 1);
+    lds_barrier();
+    {
+      const uint32_t e0 = img_e(0), o0 = img_o(0), e1 = img_e(1), o1 = img_o(1);
+#pragma unroll
+      for (int i = 0; i < PF; ++i) A[i] = a_read(e0, o0, i);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks == 0) accA = mfma_acc(0, A[0], zero16);
+        else accA = mfma_acc(ks, A[ks % RING], accA);
+        if (ks + PF < KS) A[(ks + PF) % RING] = a_read(e0, o0, ks + PF);
+        else if (a.T > 1) A[(ks + PF) % RING] = a_read(e1, o1, ks + PF - KS);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // steady state, unrolled by two so the accumulator roles alternate; the image indices
+    // (s + 1) % 3, (s + 2) % 3 rotate in scalar registers
+    int s = 0;
+    int k1 = 1, k2 = 2;                  // images of halo(s + 1), halo(s + 2)
+    for (; s + 2 < a.T; s += 2) {
+      fused_step(accB, accA, s, img_e(k1), img_o(k1), img_e(k2), img_o(k2), (uint32_t)(k2 * HALO_B),
+                 0, true);
+      const int k3 = k1 == 0 ? 2 : k1 - 1;        // image of halo(s + 3)
+      fused_step(accA, accB, s + 1, img_e(k2), img_o(k2), img_e(k3), img_o(k3),
+                 (uint32_t)(k3 * HALO_B), 1, s + 3 < a.T);
+      k1 = k3;
+      k2 = k3 == 2 ? 0 : k3 + 1;
+    }
+    if (s + 1 < a.T) {
+      fused_step(accB, accA, s, img_e(k1), img_o(k1), img_e(k2), img_o(k2), (uint32_t)(k2 * HALO_B),
+                 0, false);
+      epilogue(accB, s + 1);
     } else {
-      epilogue(accA, t);
+      epilogue(accA, s);
     }
     lds_barrier();
     {
       const int done = a.T >= 2 ? ((a.T - 2) / FL) * FL : 0;
       flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, done, a.T - done, b, y0, x0, tid);
     }
-    if (a.u_out && wave_on) u_io_tile<false>(u, a, b, y0, x0, cout, h, role);
+    if (a.u_out && wave_on) u_io_tile<false>(u, a, b, y0, x0, cout, h, 0);
     if (pw.queue) {                      // the claimed patch, to the whole workgroup
       if (tid == 0) nxt[0] = (uint32_t)r_next;
       lds_barrier();
@@ -500,57 +521,67 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   if (pw.queue && tid == 0) pw.finish();
 }
 
-template <int FMT, int CIN, int NF>
-static void launch_fp6_nf(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy,
-                          hipStream_t st) {
-  if (pool && lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, true>, a, gy, st, 0, F6_NT);
-  else if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, false>, a, gy, st, 0, F6_NT);
-  else if (lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, true>, a, gy, st, 0, F6_NT);
-  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, false>, a, gy, st, 0, F6_NT);
+#ifdef SNNQP_BITS_HEADLINE_ONLY
+// diagnostic builds (tools/diag_build.py): only the instances the headline workload launches
+void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, int dq, bool fma,
+                         bool bnf, unsigned gy, hipStream_t st) {
+  ConvMfmaArgs a = a0;
+  a.patch_h = 4;
+  a.tiles_y = (a.H + 3) / 4;
+  a.npatch = (int64_t)a.B * a.tiles_y * a.tiles_x;
+  if (bnf) launch_persistent(conv3x3_bits_kernel<FMT_FP6, 128, NF_MUL0, true, DQ_ARITH, true, true>, a, gy, st, 0, F6_NT);
+  else launch_persistent(conv3x3_bits_kernel<FMT_FP6, 128, NF_MUL0, true, DQ_ARITH, true, false>, a, gy, st, 0, F6_NT);
+}
+#else
+
+template <int FMT, int CIN, int NF, int DQ, bool FMA, bool BNF>
+static void launch_bits_pool(const ConvMfmaArgs &a, bool pool, unsigned gy, hipStream_t st) {
+  if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, DQ, FMA, BNF>, a, gy, st, 0, F6_NT);
+  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, DQ, FMA, BNF>, a, gy, st, 0, F6_NT);
 }
 
+// The general instance of a neuron form (three-instruction dequantisation, full BatchNorm,
+// two-rounding membrane update) serves every launch; multi_step_LIF / PLIF with v_reset = 0
+// (NF_MUL0, what every shipped config uses) additionally has the shortcuts the launch may
+// prove: fused membrane update (fma), multiply-only BatchNorm (bnf), and on the fp6
+// instruction the one-multiply dequantisation (L == 1).
 template <int FMT, int CIN>
-static void launch_fp6_cin(const ConvMfmaArgs &a, int nf, bool pool, bool lut, unsigned gy,
-                           hipStream_t st) {
-  if (nf == NF_MUL0) launch_fp6_nf<FMT, CIN, NF_MUL0>(a, pool, lut, gy, st);
-  else if (nf == NF_MUL) launch_fp6_nf<FMT, CIN, NF_MUL>(a, pool, lut, gy, st);
-  else if (nf == NF_DIV) launch_fp6_nf<FMT, CIN, NF_DIV>(a, pool, lut, gy, st);
-  else launch_fp6_nf<FMT, CIN, NF_DECAY>(a, pool, lut, gy, st);
+static void launch_bits_nf(const ConvMfmaArgs &a, int nf, bool pool, int dq, bool fma, bool bnf,
+                           unsigned gy, hipStream_t st) {
+  if (nf == NF_MUL) return launch_bits_pool<FMT, CIN, NF_MUL, DQ_ARITH, false, false>(a, pool, gy, st);
+  if (nf == NF_DIV) return launch_bits_pool<FMT, CIN, NF_DIV, DQ_ARITH, false, false>(a, pool, gy, st);
+  if (nf == NF_DECAY) return launch_bits_pool<FMT, CIN, NF_DECAY, DQ_ARITH, false, false>(a, pool, gy, st);
+  if constexpr (FMT == FMT_FP6) {
+    if (dq == DQ_ONE) {
+      if (fma && bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ONE, true, true>(a, pool, gy, st);
+      if (fma) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ONE, true, false>(a, pool, gy, st);
+      if (bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ONE, false, true>(a, pool, gy, st);
+      return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ONE, false, false>(a, pool, gy, st);
+    }
+  }
+  if (fma && bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ARITH, true, true>(a, pool, gy, st);
+  if (fma) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ARITH, true, false>(a, pool, gy, st);
+  if (bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ARITH, false, true>(a, pool, gy, st);
+  launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ARITH, false, false>(a, pool, gy, st);
 }
 
 // i8: codes wider than fp6 holds (|code| > 7) -> the int8 instruction
-// NF_MUL0 with the fused membrane update
-template <int FMT, int CIN>
-static void launch_fp6_fma(const ConvMfmaArgs &a, bool pool, bool lut, unsigned gy, hipStream_t st) {
-  if (pool && lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, true, true, true>, a, gy, st, 0, F6_NT);
-  else if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, true, false, true>, a, gy, st, 0, F6_NT);
-  else if (lut) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, false, true, true>, a, gy, st, 0, F6_NT);
-  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF_MUL0, false, false, true>, a, gy, st, 0, F6_NT);
-}
-
-void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, bool lut, bool fma,
-                         unsigned gy, hipStream_t st) {
-  ConvMfmaArgs a = a0;                       // this kernel's patch: F6_TILES tiles of 4x8 pixels
-  a.patch_h = 4 * F6_TILES;
-  a.tiles_y = (a.H + a.patch_h - 1) / a.patch_h;
+// dq: DQ_ARITH / DQ_ONE (conv_tile.h; ONE is a shortcut, ARITH with L = 1 computes the same);
+// fma: NF_MUL0 with the fused membrane update; bnf: BatchNorm means and biases all zero
+void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, int dq, bool fma,
+                         bool bnf, unsigned gy, hipStream_t st) {
+  ConvMfmaArgs a = a0;                       // this kernel's patch: one tile of 4x8 pixels
+  a.patch_h = 4;
+  a.tiles_y = (a.H + 3) / 4;
   a.npatch = (int64_t)a.B * a.tiles_y * a.tiles_x;
-  if (fma && nf == NF_MUL0) {
-    if (i8) {
-      if (a.Cin <= 64) launch_fp6_fma<FMT_I8, 64>(a, pool, lut, gy, st);
-      else launch_fp6_fma<FMT_I8, 128>(a, pool, lut, gy, st);
-    } else {
-      if (a.Cin <= 64) launch_fp6_fma<FMT_FP6, 64>(a, pool, lut, gy, st);
-      else launch_fp6_fma<FMT_FP6, 128>(a, pool, lut, gy, st);
-    }
-    return;
-  }
   if (i8) {
-    if (a.Cin <= 64) launch_fp6_cin<FMT_I8, 64>(a, nf, pool, lut, gy, st);
-    else launch_fp6_cin<FMT_I8, 128>(a, nf, pool, lut, gy, st);
+    if (a.Cin <= 64) launch_bits_nf<FMT_I8, 64>(a, nf, pool, dq, fma, bnf, gy, st);
+    else launch_bits_nf<FMT_I8, 128>(a, nf, pool, dq, fma, bnf, gy, st);
   } else {
-    if (a.Cin <= 64) launch_fp6_cin<FMT_FP6, 64>(a, nf, pool, lut, gy, st);
-    else launch_fp6_cin<FMT_FP6, 128>(a, nf, pool, lut, gy, st);
+    if (a.Cin <= 64) launch_bits_nf<FMT_FP6, 64>(a, nf, pool, dq, fma, bnf, gy, st);
+    else launch_bits_nf<FMT_FP6, 128>(a, nf, pool, dq, fma, bnf, gy, st);
   }
 }
+#endif
 
 }  // namespace snnqp

@@ -460,11 +460,14 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     // (min_current_bits covers |acc| <= abs_sum_max, table or not)
     const bool fma = nf == NF_MUL0 && w->min_current_bits != 0 && w->abs_sum_max > 0 &&
                      lif_fma_is_exact(w->min_current_bits, a.nrn.k_log2, T, u0 != nullptr);
-#ifdef SNNQP_X_NOLUT                    // diagnostic build: arithmetic dequantisation
-    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, false, fma, gy, st);
-#else
-    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, lut, fma, gy, st);
-#endif
+    // dequantisation of the bits kernel: one multiply when L == 1 (2-bit DuQ, the step
+    // quantisers), else the three-instruction form; BatchNorm is the multiply alone when the
+    // caller knows every mean and bias is zero
+    const int dq = w->L == 1.0f ? DQ_ONE : DQ_ARITH;
+    const bool bnf = (a.bn.flags & (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO)) ==
+                     (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO);
+    a.lut_bound = 0;
+    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, dq, fma, bnf, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
     // LDS decides how many workgroups share a CU (every variant needs < 128 VGPRs: up to four

@@ -427,9 +427,13 @@ class BatchNorm(Module):
       mul = mul * scale.detach().cpu().numpy().astype(np.float32)
     b = (bias.detach().cpu().numpy().astype(np.float32) if bias is not None
          else np.zeros_like(m))
+    from . import _lib as L
+    # a freshly initialised BatchNorm has zero running mean and zero bias: fl(x - 0) and
+    # fl(x + 0) are x, and the fused kernels may skip those two instructions
+    flags = (0 if m.any() else L.BN_MEAN_ZERO) | (0 if b.any() else L.BN_BIAS_ZERO)
     out = ops.BnCoeffs(torch.from_numpy(m).to(dev),
                        torch.from_numpy(mul.astype(np.float32)).to(dev),
-                       torch.from_numpy(b).to(dev))
+                       torch.from_numpy(b).to(dev), flags)
     return _bn_cache.put((mean, var, scale, bias), float(self.epsilon), out)
 
   def __call__(self, x, use_running_average: Optional[bool] = None):
