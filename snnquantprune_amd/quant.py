@@ -54,7 +54,11 @@ round_multi_gaussian = _make_round("round_multi_gaussian")
 
 
 # ---------------------------------------------------------------------------
-# Calibration functions (quant.py:296-314) -- pack-time, torch reductions.
+# Calibration functions (quant.py:296-314) -- pack-time, once per model.  The value
+# sits inside round(clip(W / a) * L): an `a` one ulp off flips codes at ties, so the
+# statistics are evaluated in ONE defined way -- float32 NumPy reductions on the host
+# (pairwise sums), the same ops the CPU oracle runs -- rather than with whatever
+# reduction order the device library picks for the tensor's size.
 # ---------------------------------------------------------------------------
 
 
@@ -71,11 +75,15 @@ def gaussian_init(x, bits, sign, axis=None):
   x = torch.as_tensor(x, dtype=torch.float32)
   if axis is not None:
     raise NotImplementedError("per-axis calibration")
-  if float(x.max()) == 0:
+  import numpy as np
+  xn = x.detach().cpu().numpy()
+  if np.max(xn) == 0:
     return torch.tensor(1 / 2 ** bits, dtype=torch.float32, device=x.device)
-  mu = x.mean()
-  sigma = x.std(unbiased=False)
-  return torch.maximum((mu - 3 * sigma).abs(), (mu + 3 * sigma).abs())
+  mu = np.mean(xn, dtype=np.float32)
+  sigma = np.std(xn, dtype=np.float32)
+  three = np.float32(3)
+  v = np.float32(np.maximum(np.abs(mu - three * sigma), np.abs(mu + three * sigma)))
+  return torch.tensor(float(v), dtype=torch.float32, device=x.device)
 
 
 def percentile_init(x, bits, sign, perc, axis=None):

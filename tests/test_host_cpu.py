@@ -265,8 +265,12 @@ def test_prune_utils_on_cpu_tensors():
   for name, m in zip(("QuantDense_0", "QuantDense_1"), o.global_prune_masks(ks, 0.5)):
     np.testing.assert_array_equal(g[name]["prune_0"]["mask"].numpy(), m)
   q = prune_utils.update_quant_params(params, gaussian_init, 4)
-  np.testing.assert_allclose(float(q["QuantDense_0"]["DuQ_0"]["a"]),
-                             float(o.gaussian_init(ks[0], 4)), rtol=2e-6)
+  # bit-equal: `a` sits inside round(), a one-ulp difference flips codes at ties
+  for name, k in zip(("QuantDense_0", "QuantDense_1"), ks):
+    a = q[name]["DuQ_0"]["a"].numpy()
+    assert a.dtype == np.float32 and a.shape == (1,)
+    np.testing.assert_array_equal(a[0], np.float32(o.gaussian_init(k, 4)))
+    np.testing.assert_array_equal(q[name]["DuQ_0"]["c"].numpy(), a)
 
 
 # ---------------------------------------------------------------------------
@@ -341,3 +345,48 @@ def test_bench_metric_label_follows_the_arguments():
   assert bench.metric_name(bench.parse(["--frames", "50", "--layer-bits", "2,4,2,4", "--prune",
                                         "0.95"])) == \
       "samples/sec/node (DVS128 T=50, mixed 2/4-bit/95%-pruned)"
+
+
+def _flax_blob_module():
+  import importlib.util
+  path = os.path.join(ROOT, "tests", "golden", "make_flax_blob.py")
+  spec = importlib.util.spec_from_file_location("make_flax_blob", path)
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def test_flax_checkpoint_importer_against_independent_bytes():
+  """F2: tests/golden/flax_checkpoint_tiny.msgpack was assembled byte by byte from the
+  msgpack spec and flax.serialization's ext layout (tests/golden/make_flax_blob.py uses
+  neither the msgpack package nor this package's writer).  The committed file is what the
+  generator produces, and the importer reads every leaf back bit for bit, fills the leaves
+  an unpruned run does not save (mask = 1) and ignores the optimiser state."""
+  from snnquantprune_amd import checkpoint
+  mk = _flax_blob_module()
+  with open(mk.OUT, "rb") as f:
+    blob = f.read()
+  assert blob == mk.p_map(mk.state_dict()), "committed blob is stale: run tests/golden/make_flax_blob.py"
+  got = checkpoint.load_flax_checkpoint(mk.OUT)
+  want = mk.tree()
+  assert list(got["params"]) == sorted(want["params"]) and sorted(got) == ["batch_stats", "params"]
+  for name, leaf in want["params"].items():
+    for k, v in leaf.items():
+      if isinstance(v, dict):
+        for kk, vv in v.items():
+          np.testing.assert_array_equal(got["params"][name][k][kk], vv)
+      else:
+        np.testing.assert_array_equal(got["params"][name][k], v)
+        assert got["params"][name][k].dtype == np.float32
+  for name, leaf in want["batch_stats"].items():
+    for k, v in leaf.items():
+      np.testing.assert_array_equal(got["batch_stats"][name][k], v)
+  q1 = got["params"]["QuantConv_1"]
+  assert float(q1["DuQ_0"]["a"][0]) != float(q1["DuQ_0"]["c"][0]) > 0      # learnt a != c survive
+  assert q1["prune_0"]["mask"].shape == (3, 3, 32, 32) and q1["prune_0"]["mask"].min() == 1.0
+  # the msgpack package, a third implementation, reads the same framing
+  import msgpack
+  raw = msgpack.unpackb(blob, raw=False, strict_map_key=False,
+                        ext_hook=lambda code, data: (code, len(data)))
+  assert raw["step"] == 1234 and raw["weight_size"][0] == 3
+  assert raw["params"]["params"]["QuantDense_1"]["kernel"][0] == 1

@@ -1109,7 +1109,7 @@ def test_prepare_params_masks_and_ac(dev, oracle):
   for k in names:
     a = float(q[k]["DuQ_0"]["a"])
     assert q[k]["DuQ_0"]["a"].shape == (1,)
-    np.testing.assert_allclose(a, float(oracle.gaussian_init(v["params"][k]["kernel"], 4)), rtol=2e-6)
+    np.testing.assert_array_equal(np.float32(a), np.float32(oracle.gaussian_init(v["params"][k]["kernel"], 4)))
     assert float(q[k]["DuQ_0"]["c"]) == a
   cfg = syn.make_config(bits=4, prune_percentage=0.9)
   cfg.quant.prune_global = True
@@ -1244,6 +1244,51 @@ def test_full_batch_c5_properties(dev, oracle):
       _np(x[300:301]), [qweight_of(oracle, p["QuantConv_%d" % i], lb[i]) for i in range(3)],
       [bn_of(v, i) for i in range(3)], qweight_of(oracle, p["QuantDense_0"], lb[3]), mode="int")
   np.testing.assert_array_equal(full[300:301], r["logits"])
+
+
+@pytest.mark.parametrize("prepare", [False, True], ids=["as_saved", "prune_quant_joint"])
+def test_flax_checkpoint_through_the_kernels(dev, oracle, golden_dir, prepare):
+  """F2 end to end: the independent-bytes Flax checkpoint (tests/golden/make_flax_blob.py) ->
+  load_flax_checkpoint -> [prepare_params as configs/prune_quant_joint.py does: global
+  magnitude mask, a = c = gaussian_init] -> CextNet.apply, against the oracle fed the same
+  tree (tcja_load_pretrained_weights.py:39-167, train_inpt_spikingjelly.py:159-223,
+  train_utils.py:30-41).  as_saved keeps the checkpoint's learnt a != c and no pruning."""
+  from snnquantprune_amd import checkpoint, linen as nn
+  from snnquantprune_amd import models, prune_utils, synthetic as syn
+  from snnquantprune_amd.quant import gaussian_init
+  path = os.path.join(golden_dir, "flax_checkpoint_tiny.msgpack")
+  tree = checkpoint.load_flax_checkpoint(path)
+  cfg = syn.make_config(bits=4, prune_percentage=0.6 if prepare else -1.0, channels=32)
+  cfg.quant.prune_global = True
+  cfg.quant.start_epoch = -1
+  cfg.quant.init_fn = gaussian_init
+  variables = nn.tree_from_numpy(tree, dev)
+  np_tree = {"params": {k: dict(v) for k, v in tree["params"].items()},
+             "batch_stats": tree["batch_stats"]}
+  if prepare:
+    variables = dict(variables, params=prune_utils.prepare_params(variables["params"], cfg))
+    names = [k for k in tree["params"] if k.startswith("Quant")]
+    masks = oracle.global_prune_masks([tree["params"][k]["kernel"] for k in names], 0.6)
+    for k, m in zip(names, masks):
+      a = np.array([oracle.gaussian_init(tree["params"][k]["kernel"], 4)], F32)
+      np_tree["params"][k] = dict(tree["params"][k], prune_0={"mask": m}, DuQ_0={"a": a, "c": a})
+      np.testing.assert_array_equal(_np(variables["params"][k]["prune_0"]["mask"]), m)
+      np.testing.assert_array_equal(_np(variables["params"][k]["DuQ_0"]["a"]), a)
+  x = syn.poisson_spikes((2, 4, 32, 32, 2), 0.15, seed=424242)
+  e = cases.cextnet_expected(oracle, {"vars": np_tree, "x": x, "bits": 4})
+  model = models.CextNet(num_classes=11, config=cfg)
+  (logits, _), mut = model.apply(variables, _t(x, dev), trgt=None, train=False, rng=None,
+                                 mutable=["intermediates"])
+  im = mut["intermediates"]
+  for i in range(3):
+    np.testing.assert_array_equal(_np(im["pool%d" % i][0]), e["pool%d_bits" % i])
+  for i in range(2):
+    np.testing.assert_array_equal(_np(im["tcja_gate_%d" % i][0]), e["gate%d" % i])
+  d2 = im["dense2_out"][0]
+  d2 = d2.to_dense() if hasattr(d2, "to_dense") else d2
+  np.testing.assert_array_equal(_np(d2).astype(np.uint8), e["dense2_s"])
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+  assert e["dense2_s"].mean() > 0.005, e["dense2_s"].mean()
 
 
 def test_eval_step_metrics(dev, oracle):
