@@ -295,7 +295,7 @@ int snnqp_events_to_frames(const int32_t *ex, const int32_t *ey, const int32_t *
                            int32_t *counts, uint8_t *frames_u8, snnqp_stream_t stream);
 /* replaces: the activation-density probes sown at examples/tcja/models.py:128-142
  *           (consumed by examples/sparsity.py:143-170): non-zero count of each of
- *           NB slices of n elements (C innermost; F32 or BITS). */
+ *           NB slices of n elements (C innermost; F32, U8 or BITS). */
 int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int32_t *nnz,
                   snnqp_stream_t stream);
 

@@ -746,7 +746,7 @@ def density(x, lead_dims=2):
   return (np.sum(flat != 0, axis=-1) / F32(flat.shape[-1])).astype(F32)
 
 
-def tcja(x_seq, qw_t: QWeight, qw_c: QWeight):
+def tcja(x_seq, qw_t: QWeight, qw_c: QWeight, probes: Optional[dict] = None, tag: str = ""):
   """TCJA gate, examples/tcja/models.py:41-99, on x_seq [T, B, H, W, C].
 
   Channel means are sequential float32 sums / (H*W); the two 1-D QuantConvs
@@ -763,6 +763,11 @@ def tcja(x_seq, qw_t: QWeight, qw_c: QWeight):
   x_c = np.ascontiguousarray(np.transpose(x, (0, 2, 1)))  # [B, C, T]
   conv_t = quant_conv(x_c, qw_t, None, "SAME", mode="fseq")   # [B, C, T]
   conv_c = quant_conv(x, qw_c, None, "SAME", mode="fseq")     # [B, T, C]
+  if probes is not None:                                 # models.py:45-91, per sample
+    probes["conv_tcja1_%s_inpt" % tag] = density(x_c, 1)
+    probes["conv_tcja1_%s_out" % tag] = density(conv_t, 1)
+    probes["conv_tcja2_%s_inpt" % tag] = density(x, 1)
+    probes["conv_tcja2_%s_out" % tag] = density(conv_c, 1)
   conv_t = np.transpose(conv_t, (2, 0, 1))               # [T, B, C]
   conv_c = np.transpose(conv_c, (1, 0, 2))               # [T, B, C]
   z = (conv_c * conv_t).astype(F32)
@@ -772,27 +777,41 @@ def tcja(x_seq, qw_t: QWeight, qw_c: QWeight):
 
 def cextnet_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
                     tcja_qw: Sequence[Tuple[QWeight, QWeight]], dense_qw: Sequence[QWeight],
-                    neuron_cfg=None, group=10):
+                    neuron_cfg=None, group=10, probes: Optional[dict] = None):
   """Full CextNet (models.py:31-257), eval.  conv_qw: the five 3x3 kernels;
   tcja_qw: [(conv_t, conv_c)] x 2; dense_qw: the two dense kernels.  Integer
-  mode while activations are spikes, 'fseq' once they are real-valued."""
+  mode while activations are spikes, 'fseq' once they are real-valued.
+  probes: dict that receives the per-slice densities (`sparse_nums`) the model sows
+  (models.py:128-142 and the like), keyed `<name>_inpt` / `<name>_out`."""
   x = np.swapaxes(np.asarray(inputs), 0, 1)
   out = {}
+
+  def probe(name, v, lead=2):
+    if probes is not None:
+      probes[name] = density(v, lead)
   for i in range(3):
+    probe("conv_%d_inpt" % i, x)
     _, s = conv_block(x, conv_qw[i], bns[i], neuron_cfg, "int")
+    probe("conv_%d_out" % i, s)
     x = max_pool_2x2(s)
     out["pool%d" % i] = x
   mode = "int"
   for i in range(2):
+    probe("conv_t_%d_inpt" % i, x)
     _, s = conv_block(x, conv_qw[3 + i], bns[3 + i], neuron_cfg, mode)
+    probe("conv_t_%d_out" % i, s)
     out["conv_t_%d" % i] = s
-    y, gate = tcja(s, *tcja_qw[i])
+    y, gate = tcja(s, *tcja_qw[i], probes=probes, tag=str(i))
     out["gate%d" % i] = gate
     x = max_pool_2x2(y)
     mode = "fseq"
   xf = flatten_channel_major(x)
+  probe("dense1_inpt", xf)
   _, s1 = dense_block(xf, dense_qw[0], neuron_cfg, "fseq")
+  probe("dense1_out", s1)
+  probe("dense2_inpt", s1)
   _, s2 = dense_block(s1, dense_qw[1], neuron_cfg, "int")
+  probe("dense2_out", s2)
   out["dense1_s"], out["dense2_s"] = s1, s2
   out["logits"] = vote(s2, group)
   return out

@@ -303,18 +303,19 @@ i32_to_u8_sat_kernel(const int32_t *__restrict__ x, uint8_t *__restrict__ y, int
 
 // Activation density probe (examples/tcja/models.py:128-142): fraction of non-zero
 // entries of each of the NB leading slices of n elements.  One wave per slice chunk.
-template <bool BITS>
+template <int TYPE>
 __global__ void __launch_bounds__(256)
 density_kernel(const void *__restrict__ x, int64_t NB, int64_t n, int32_t C,
                int32_t *__restrict__ nnz) {
   // BITS: the slice is n / C rows of ceil(C / 32) words (padding bits are zero)
-  const int64_t units = BITS ? (n / C) * ((C + 31) / 32) : n;
+  const int64_t units = TYPE == SNNQP_BITS ? (n / C) * ((C + 31) / 32) : n;
   const int64_t total = NB * units;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t img = i / units;
     int32_t c;
-    if (BITS) c = __popc(((const uint32_t *)x)[i]);
+    if (TYPE == SNNQP_BITS) c = __popc(((const uint32_t *)x)[i]);
+    else if (TYPE == SNNQP_U8) c = ((const uint8_t *)x)[i] != 0;
     else c = ((const float *)x)[i] != 0.0f;
     if (c) atomicAdd(&nnz[img], c);
   }
@@ -503,18 +504,21 @@ int snnqp_events_to_frames(const int32_t *ex, const int32_t *ey, const int32_t *
 int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int32_t *nnz,
                   snnqp_stream_t stream) {
   SNNQP_REQUIRE(NB >= 0 && n > 0 && C > 0 && n % C == 0, SNNQP_EINVAL, "density: bad shape");
-  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
-                "density: type must be F32 or BITS");
+  SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS || type == SNNQP_U8, SNNQP_EINVAL,
+                "density: type must be F32, U8 or BITS");
   if (NB == 0) return SNNQP_OK;
   SNNQP_REQUIRE(x && nnz, SNNQP_EINVAL, "density: null argument");
   hipStream_t st = (hipStream_t)stream;
   SNNQP_HIP(hipMemsetAsync(nnz, 0, NB * 4, st));
   const int64_t units = type == SNNQP_BITS ? (n / C) * ((C + 31) / 32) : n;
   if (type == SNNQP_BITS)
-    hipLaunchKernelGGL(density_kernel<true>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(density_kernel<SNNQP_BITS>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
+                       NB, n, C, nnz);
+  else if (type == SNNQP_U8)
+    hipLaunchKernelGGL(density_kernel<SNNQP_U8>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
                        NB, n, C, nnz);
   else
-    hipLaunchKernelGGL(density_kernel<false>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(density_kernel<SNNQP_F32>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,
                        NB, n, C, nnz);
   SNNQP_CHECK_LAUNCH("density_kernel");
   return SNNQP_OK;

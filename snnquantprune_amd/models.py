@@ -65,6 +65,23 @@ def _require_eval(train):
         "package implements the eval forward pass (train=False)")
 
 
+def _probing(mod, cfg):
+  """Density probes are sown under the reference's names (models.py:45-51,128-142) when the
+  caller both asks for them (config.density_probes) and made 'intermediates' mutable.  The
+  reference sows them unconditionally -- under jit an unread probe costs nothing; here each
+  probe is a kernel launch, and the `*_out_*` probes need the UNPOOLED raster, so the blocks
+  then run with the 2x2 max-pool as a separate pass."""
+  return bool(cfg.get("density_probes", False)) and mod.is_mutable_collection("intermediates")
+
+
+def _sow_density(mod, name, x, lead_dims=2):
+  """sparse_nums = nnz / size per leading slice; `<name>_min` is its MAXIMUM (the reference's
+  naming, models.py:131-133) and `<name>_mean` its mean, float32 device scalars."""
+  d = ops.density(x, lead_dims=lead_dims).reshape(-1)
+  mod.sow("intermediates", name + "_min", d.max())
+  mod.sow("intermediates", name + "_mean", d.mean())
+
+
 def _as_input(inputs):
   if isinstance(inputs, ops.PackedSpikes):
     return inputs
@@ -86,13 +103,19 @@ class DenseSNN(nn.Module):
     cfg = self.config
     x = _as_input(inputs)
     hidden = cfg.hidden if "hidden" in cfg else cfg.channels * 2 * 2
+    probe = _probing(self, cfg)
     layer = SpikingBlock(
         connection_fn=QuantDense(hidden, use_bias=False, dtype=self.dtype,
                                  config=cfg.quant, bits=_layer_bits(cfg, 0),
                                  g_scale=cfg.quant.g_scale),
         neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
         return_state=False, batch_major_input=True)
+    if probe:
+      _sow_density(self, "dense1_inpt", x)
     _, x = layer(None, x)
+    if probe:
+      _sow_density(self, "dense1_out", x)
+      _sow_density(self, "dense2_inpt", x)
     layer = SpikingBlock(
         connection_fn=QuantDense(self.num_classes * 10, use_bias=False,
                                  dtype=self.dtype, config=cfg.quant,
@@ -101,6 +124,8 @@ class DenseSNN(nn.Module):
         return_state=False)
     _, x = layer(None, x)
     self.sow("intermediates", "dense2_out", x)
+    if probe:
+      _sow_density(self, "dense2_out", x)
     return ops.vote(x, 10), None                       # models.py:253-255
 
 
@@ -119,6 +144,7 @@ class ConvDenseSNN(nn.Module):
     norm = lambda: nn.BatchNorm(use_running_average=not train, momentum=0.9,  # noqa: E731
                                 epsilon=1e-5, use_bias=True, use_scale=True,
                                 dtype=self.dtype)
+    probe = _probing(self, cfg)
     for i in range(nblocks):
       layer = SpikingBlock(
           connection_fn=QuantConv(features=cfg.channels, kernel_size=(3, 3),
@@ -127,12 +153,19 @@ class ConvDenseSNN(nn.Module):
                                   bits=_layer_bits(cfg, i), g_scale=cfg.quant.g_scale),
           neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype),
           norm_fn=norm(),
-          pool=2,                       # the reduce_window max of models.py:145-147
+          pool=1 if probe else 2,       # the reduce_window max of models.py:145-147
           return_state=False,
           batch_major_input=(i == 0))   # models.py:109 swapaxes, done by strides
+      if probe:
+        _sow_density(self, "conv_%d_inpt" % i, x)
       _, x = layer(None, x)
+      if probe:
+        _sow_density(self, "conv_%d_out" % i, x)
+        x = ops.maxpool2x2(x)
       self.sow("intermediates", "pool%d" % i, x)
     x = flatten_channel_major(x)
+    if probe:
+      _sow_density(self, "dense1_inpt", x)
     layer = SpikingBlock(
         connection_fn=QuantDense(self.num_classes * 10, use_bias=False,
                                  dtype=self.dtype, config=cfg.quant,
@@ -141,6 +174,8 @@ class ConvDenseSNN(nn.Module):
         return_state=False)
     _, x = layer(None, x)
     self.sow("intermediates", "dense_out", x)
+    if probe:
+      _sow_density(self, "dense1_out", x)
     return ops.vote(x, 10), None
 
 
@@ -166,6 +201,8 @@ class CextNet(nn.Module):
                        dtype=self.dtype, config=cfg.quant, bits=cfg.quant.bits,
                        g_scale=cfg.quant.g_scale)(x)
 
+    probe = _probing(self, cfg)
+
     def TCJA(x_seq, i=0):                               # models.py:41-99
       T, C = x_seq.shape[0], x_seq.shape[-1]
       m = ops.spatial_mean(x_seq)                       # [T, B, C]
@@ -174,6 +211,11 @@ class CextNet(nn.Module):
       with packing.integer_inputs(False):               # channel means are real-valued
         conv_t_out = qconv1d(T, x_c)                    # [B, C, T]
         conv_c_out = qconv1d(C, x)                      # [B, T, C]
+      if probe:                                         # per sample, models.py:45-91
+        _sow_density(self, "conv_tcja1_%d_inpt" % i, x_c, 1)
+        _sow_density(self, "conv_tcja1_%d_out" % i, conv_t_out, 1)
+        _sow_density(self, "conv_tcja2_%d_inpt" % i, x, 1)
+        _sow_density(self, "conv_tcja2_%d_out" % i, conv_c_out, 1)
       conv_t_out = conv_t_out.permute(2, 0, 1).contiguous()   # [T, B, C]
       conv_c_out = conv_c_out.transpose(0, 1).contiguous()    # [T, B, C]
       gate = ops.sigmoid_gate(conv_c_out, conv_t_out)
@@ -206,20 +248,36 @@ class CextNet(nn.Module):
 
     x = _as_input(inputs)
     for i in range(3):                                  # models.py:111-147
-      x = conv_block(x, first=(i == 0), pool=2)
+      if probe:
+        _sow_density(self, "conv_%d_inpt" % i, x)
+      x = conv_block(x, first=(i == 0), pool=1 if probe else 2)
+      if probe:
+        _sow_density(self, "conv_%d_out" % i, x)
+        x = ops.maxpool2x2(x)
       self.sow("intermediates", "pool%d" % i, x)
     real_valued = False
     for i in range(2):                                  # models.py:149-187
+      if probe:
+        _sow_density(self, "conv_t_%d_inpt" % i, x)
       with packing.integer_inputs(not real_valued):
         # TCJA needs the unpooled raster; bit-packed also when the input is real-valued
         x = conv_block(x, first=False, pool=1, packed=True)
       self.sow("intermediates", "conv_t_%d" % i, x)
+      if probe:
+        _sow_density(self, "conv_t_%d_out" % i, x)
       x = TCJA(x, i)                                    # gated and pooled
       real_valued = True
     x = flatten_channel_major(x)                        # models.py:189-190
+    if probe:
+      _sow_density(self, "dense1_inpt", x)
     with packing.integer_inputs(False):
       x = dense_block(x, cfg.channels * 2 * 2)          # models.py:200-216
     self.sow("intermediates", "dense1_out", x)
+    if probe:
+      _sow_density(self, "dense1_out", x)
+      _sow_density(self, "dense2_inpt", x)
     x = dense_block(x, self.num_classes * 10)           # models.py:231-246
     self.sow("intermediates", "dense2_out", x)
+    if probe:
+      _sow_density(self, "dense2_out", x)
     return ops.vote(x, 10), None

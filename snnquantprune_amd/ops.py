@@ -682,6 +682,8 @@ def density(x, lead_dims: int = 2, counts: bool = False) -> torch.Tensor:
   (or the exact int32 non-zero counts with counts=True)."""
   if isinstance(x, PackedSpikes):
     t, typ, C, shape = x.bits, L.BITS, x.channels, x.shape
+  elif x.dtype == torch.uint8:
+    t, typ, C, shape = x.contiguous(), L.U8, x.shape[-1], tuple(x.shape)
   else:
     t, typ, C, shape = _f32c(x), L.F32, x.shape[-1], tuple(x.shape)
   _require_gpu(t)

@@ -390,3 +390,40 @@ def test_flax_checkpoint_importer_against_independent_bytes():
                         ext_hook=lambda code, data: (code, len(data)))
   assert raw["step"] == 1234 and raw["weight_size"][0] == 3
   assert raw["params"]["params"]["QuantDense_1"]["kernel"][0] == 1
+
+
+def test_workload_tables_reproduce_the_reference_geometry_columns(tmp_path):
+  """F4: the geometry columns of examples/sparsity.py:172-230 (literals for DVS128, T = 20,
+  128 channels) come out of the parametric rows; values are formatted with str() like there."""
+  from snnquantprune_amd import sparsity
+  ref_geometry = {                                   # data: the reference's own literals
+      "Conv1": "20,2,128,128,128,3,3,1,1", "Conv2": "20,128,128,64,64,3,3,1,1",
+      "Conv3": "20,128,128,32,32,3,3,1,1", "Conv4": "20,128,128,16,16,3,3,1,1",
+      "TCJA11": "20,20,20,1,256,1,4,1,1", "TCJA12": "128,128,20,1,256,1,4,1,1",
+      "Conv5": "20,128,128,8,8,3,3,1,1", "TCJA21": "20,20,20,1,64,1,4,1,1",
+      "TCJA22": "128,128,20,1,64,1,4,1,1", "Dense1": "20,2048,512,1,1,1,1,1,1",
+      "Dense2": "20,512,110,1,1,1,1,1,1"}
+  layers = ["QuantConv_%d" % i for i in range(9)] + ["QuantDense_0", "QuantDense_1"]
+  ls = {n: 0.1 + 0.01 * i for i, n in enumerate(layers)}
+  probes = ["conv_0", "conv_1", "conv_2", "conv_t_0", "conv_t_1", "conv_tcja1_0", "conv_tcja2_0",
+            "conv_tcja1_1", "conv_tcja2_1", "dense1", "dense2"]
+  acc = {}
+  for i, p in enumerate(probes):
+    for io in ("inpt", "out"):
+      acc["%s_%s_mean" % (p, io)] = np.array([0.1 * (i + 1), 0.3 * (i + 1)], np.float32)
+      acc["%s_%s_min" % (p, io)] = np.array([0.2, 0.5 + 0.01 * i], np.float32)
+  mean_lines, min_lines = sparsity.workload_tables(ls, acc, frames=20, channels=128)
+  assert mean_lines[0] == "name,weights,inputs,outputs,T,C,M,P,Q,R,S,HS,WS\n" == min_lines[0]
+  assert [l.split(",")[0] for l in mean_lines[1:]] == list(ref_geometry)
+  for line in mean_lines[1:] + min_lines[1:]:
+    name, w, i, o, geom = line.rstrip("\n").split(",", 4)
+    assert geom == ref_geometry[name], (name, geom)
+  assert mean_lines[1].split(",")[1:4] == [str(0.1), str(np.mean(acc["conv_0_inpt_mean"])),
+                                           str(np.mean(acc["conv_0_out_mean"]))]
+  assert min_lines[11].split(",")[2] == str(np.max(acc["dense2_inpt_min"]))
+  paths = sparsity.write_workload(str(tmp_path / "workload_run"), ls, acc, frames=20, channels=128)
+  assert open(paths[0]).readlines() == mean_lines and open(paths[1]).readlines() == min_lines
+  # the C3 topology: three conv rows and the read-out
+  m3, _ = sparsity.workload_tables(ls, acc, frames=20, channels=128, full=False)
+  assert [l.split(",")[0] for l in m3[1:]] == ["Conv1", "Conv2", "Conv3", "Dense1"]
+  assert m3[4].rstrip("\n").split(",", 4)[4] == "20,32768,110,1,1,1,1,1,1"

@@ -1291,6 +1291,84 @@ def test_flax_checkpoint_through_the_kernels(dev, oracle, golden_dir, prepare):
   assert e["dense2_s"].mean() > 0.005, e["dense2_s"].mean()
 
 
+def test_density_probes_and_workload_tables(dev, oracle, tmp_path):
+  """F4: with config.density_probes the models sow the reference's probe names
+  (examples/tcja/models.py:45-91,128-142; `<name>_min` is the MAXIMUM of the per-slice
+  densities, as there) from snnqp_density on the packed rasters; checked against the
+  oracle's densities of the same tensors, with the logits unchanged by probing; then the
+  weight densities (sparsity.py:109-122) and both workload files."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, sparsity, synthetic as syn
+  c = cases.cextnet_case()
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  cfg.density_probes = True
+  model = models.CextNet(num_classes=11, config=cfg)
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+  (plain, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
+  (logits, _), mut = model.apply(variables, x, trgt=None, train=False, rng=None,
+                                 mutable=["intermediates"])
+  np.testing.assert_array_equal(_np(logits), _np(plain))           # probing changes nothing
+  p, b = c["vars"]["params"], c["bits"]
+  probes = {}
+  oracle.cextnet_forward(
+      c["x"], [qweight_of(oracle, p["QuantConv_%d" % i], b) for i in (0, 1, 2, 3, 6)],
+      [bn_of(c["vars"], i) for i in range(5)],
+      [(qweight_of(oracle, p["QuantConv_4"], b), qweight_of(oracle, p["QuantConv_5"], b)),
+       (qweight_of(oracle, p["QuantConv_7"], b), qweight_of(oracle, p["QuantConv_8"], b))],
+      [qweight_of(oracle, p["QuantDense_0"], b), qweight_of(oracle, p["QuantDense_1"], b)],
+      probes=probes)
+  im = mut["intermediates"]
+  assert len(probes) == 22
+  for name, d in probes.items():
+    got_max, got_mean = float(im[name + "_min"][0]), float(im[name + "_mean"][0])
+    assert abs(got_max - float(d.max())) <= 1e-7 * max(1.0, float(d.max())), name
+    assert abs(got_mean - float(np.mean(d, dtype=np.float64))) <= 2e-7, name
+  assert 0.0 < float(im["conv_1_out_mean"][0]) < 0.5 and float(im["conv_0_inpt_min"][0]) < 0.2
+  # exact non-zero counts of a uint8 tensor (new input type of snnqp_density)
+  from snnquantprune_amd import ops
+  cnt = _np(ops.density(x, lead_dims=2, counts=True))
+  np.testing.assert_array_equal(cnt, (c["x"] != 0).reshape(c["x"].shape[:2] + (-1,)).sum(-1))
+  # weight densities: kernel * mask through DuQ, fraction of non-zeros
+  ls = sparsity.weight_density(variables["params"], cfg)
+  for name in ("QuantConv_1", "QuantConv_4", "QuantDense_0"):
+    q = qweight_of(oracle, p[name], b)
+    assert ls[name] == float(np.count_nonzero(q.w_fq) / q.w_fq.size), name
+  acc = sparsity.ProbeAccumulator()
+  acc.append(im)
+  (_, _), mut2 = model.apply(variables, _t(c["x"][::-1].copy(), dev), trgt=None, train=False,
+                             rng=None, mutable=["intermediates"])
+  acc.append(mut2["intermediates"])
+  st = acc.stacked()
+  assert st["dense2_out_mean"].shape == (2,)
+  paths = sparsity.write_workload(str(tmp_path / "workload_tiny"), ls, st, frames=4, channels=128,
+                                  hw=(64, 64))
+  lines = open(paths[0]).read().splitlines()
+  assert lines[0] == "name,weights,inputs,outputs,T,C,M,P,Q,R,S,HS,WS" and len(lines) == 12
+  assert lines[1].startswith("Conv1,%s," % str(ls["QuantConv_0"]))
+  assert lines[1].endswith(",4,2,128,64,64,3,3,1,1") and lines[11].endswith(",4,512,110,1,1,1,1,1,1")
+  # the C3 model sows its four layers under the same names
+  c3 = cases.conv_net_case()
+  cfg3 = syn.make_config(bits=4, prune_percentage=0.9)
+  cfg3.density_probes = True
+  m3 = models.ConvDenseSNN(num_classes=11, config=cfg3)
+  (l3, _), mut3 = m3.apply(nn.tree_from_numpy(c3["vars"], dev), _t(c3["x"], dev), trgt=None,
+                           train=False, rng=None, mutable=["intermediates"])
+  e3 = cases.conv_net_expected(oracle, c3)
+  np.testing.assert_array_equal(_np(l3), e3["logits"])
+  p3 = c3["vars"]["params"]
+  r3 = oracle.conv3_dense_forward(
+      c3["x"], [qweight_of(oracle, p3["QuantConv_%d" % i], 4) for i in range(3)],
+      [bn_of(c3["vars"], i) for i in range(3)], qweight_of(oracle, p3["QuantDense_0"], 4),
+      mode="int", keep=True)
+  for i in range(3):
+    d = oracle.density(r3["conv%d_s" % i])
+    assert abs(float(mut3["intermediates"]["conv_%d_out_min" % i][0]) - float(d.max())) < 1e-7
+    np.testing.assert_array_equal(_np(mut3["intermediates"]["pool%d" % i][0]), e3["pool%d_bits" % i])
+  d = oracle.density(r3["dense_s"])
+  assert abs(float(mut3["intermediates"]["dense1_out_mean"][0]) - float(d.mean())) < 2e-7
+
+
 def test_eval_step_metrics(dev, oracle):
   from snnquantprune_amd import linen as nn
   from snnquantprune_amd import models, synthetic as syn, train_utils
