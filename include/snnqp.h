@@ -11,10 +11,11 @@
  * Conventions
  *  - every pointer named x/w/y/u/s/... is a DEVICE pointer owned by the caller
  *    (torch); the library allocates nothing that outlives a call, with one exception:
- *    the fused conv kernels keep 32 KiB of work-queue counters per device (allocated and
- *    zeroed on the first conv launch on that device -- the only call that synchronises
- *    `stream`, so make one launch before capturing a graph -- and handed out in 64
- *    round-robin slots, i.e. up to 64 conv launches may be in flight per device);
+ *    the fused conv kernels keep 32 KiB of work-queue counters per device (the device of
+ *    `stream`), in 64 round-robin slots.  A slot is zeroed on `stream` right before its
+ *    launch and guarded by an event: a launch that finds its slot still in flight (more
+ *    than 64 conv launches outstanding on the device), or whose stream is being captured
+ *    into a graph, walks its patches statically instead -- same results, no queue;
  *  - descriptor structs (snnqp_*_t) are HOST structs read during the call;
  *  - all work is enqueued on `stream` (a hipStream_t); no call synchronises;
  *  - return value: 0 on success, <0 on error (SNNQP_E*); the message is

@@ -93,15 +93,9 @@ __device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d
 // BNF: every BatchNorm mean and bias of the launch is zero (snnqp_bn_t.flags): x = y * mul
 enum { FMT_FP6 = 0, FMT_I8 = 1 };
 
-#ifndef SNNQP_F6_WR_SLOT
-#define SNNQP_F6_WR_SLOT 2     // slot of a step after which the staged halo is written
-#endif
-#ifndef SNNQP_F6_BAR_SLOT
-#define SNNQP_F6_BAR_SLOT 4    // slot of a step after which the step's barrier sits
-#endif
-#ifndef SNNQP_F6_PF
-#define SNNQP_F6_PF 4          // A fragments in flight (ring of 6); 2 when a step has 9 slots
-#endif
+constexpr int F6_WR_SLOT = 2;    // slot of a step after which the staged halo is written
+constexpr int F6_BAR_SLOT = 4;   // slot of a step after which the step's barrier sits
+constexpr int F6_PF = 4;         // A fragments in flight (ring of 6); 2 when a step has 9 slots
 
 template <int FMT, int CIN, int NF, bool POOL, int DQ, bool FMA = false, bool BNF = false>
 __global__ void __launch_bounds__(F6_NT, 2)
@@ -290,9 +284,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     constexpr int YD = 0;                        // pairs the dequantisation runs ahead
     // (the temporaries live inside a step: masks that crossed the loop's back edge would
     // leave the scalar registers)
-#ifndef SNNQP_F6_ABL
-#define SNNQP_F6_ABL 0          // diagnostic builds only (tools/diag_build.py)
-#endif
     // The spike word: the compare masks are wave-uniform 64-bit lane masks (lane = channel).
     // Combining them is scalar work (s_or) that feeds a v_writelane; issued right behind the
     // v_cmp that produced the masks, each of those hops stalls the wave (VALU -> SALU -> VALU
@@ -325,16 +316,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     auto estage = [&](const acc_t &accC, int st, ETmp &e) {
       const int j = st / NST, q = st % NST;
       if (q == 0) {
-        if (SNNQP_F6_ABL & 64) {          // diagnostic: no dequantisation
-          e.ey[(j + YD) % (YD + 1)][0] = accC[2 * j]; e.ey[(j + YD) % (YD + 1)][1] = accC[2 * j + 1];
-        } else
         if (j + YD < 8) {
           e.ey[(j + YD) % (YD + 1)][0] = dequant1(accC[2 * (j + YD)]);
           e.ey[(j + YD) % (YD + 1)][1] = dequant1(accC[2 * (j + YD) + 1]);
         }
       } else if (q == 1) {
-        if (SNNQP_F6_ABL & 128) { e.ex[0] = e.ey[j % (YD + 1)][0]; e.ex[1] = e.ey[j % (YD + 1)][1]; }
-        else if (BNF) {                   // mean == 0: fl(y - 0) = y
+        if (BNF) {                   // mean == 0: fl(y - 0) = y
           e.ex[0] = e.ey[j % (YD + 1)][0] * lc.bmul;
           e.ex[1] = e.ey[j % (YD + 1)][1] * lc.bmul;
         } else {
@@ -342,19 +329,15 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           e.ex[1] = (e.ey[j % (YD + 1)][1] - lc.bmean) * lc.bmul;
         }
       } else if (q == 2) {                // (bias == 0: fl(x + 0) = x)
-        const v2f xx = ((SNNQP_F6_ABL & 128) || BNF) ? v2f{e.ex[0], e.ex[1]}
-                                                     : v2f{e.ex[0] + lc.bbias, e.ex[1] + lc.bbias};
+        const v2f xx = BNF ? v2f{e.ex[0], e.ex[1]} : v2f{e.ex[0] + lc.bbias, e.ex[1] + lc.bbias};
         const v2f uu = neuron_update<NF, FMA, false>(xx, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
         e.euu[0] = uu.x; e.euu[1] = uu.y;
       } else if (q == 3) {
-        if (SNNQP_F6_ABL & 256) return;   // diagnostic: no threshold / reset / spike word
         e.m0[j] = __ballot(e.euu[0] >= a.nrn.vth);
         e.m1[j] = __ballot(e.euu[1] >= a.nrn.vth);
       } else {
-        if (SNNQP_F6_ABL & 256) { u[2 * j] = e.euu[0]; u[2 * j + 1] = e.euu[1]; return; }
         u[2 * j] = neuron_reset<NF>(e.euu[0], e.m0[j], lc);
         u[2 * j + 1] = neuron_reset<NF>(e.euu[1], e.m1[j], lc);
-        if (SNNQP_F6_ABL & 512) return;   // diagnostic: no spike word
         if (j >= 1) word_combine(e, j - 1);
         if (j >= 2) word_insert(e, j - 2);
         if (j == 7) {                     // drain
@@ -382,48 +365,39 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
     // ---- A-fragment ring: PF fragments in flight, across step boundaries ----------------
     constexpr int RING = KS % 6 == 0 ? 6 : 3;    // divides KS (9, 18, 36): static indices
-    constexpr int PF = RING == 6 ? (SNNQP_F6_PF < 6 ? SNNQP_F6_PF : 5) : 2;
+    constexpr int PF = RING == 6 ? F6_PF : 2;
     static_assert(KS % RING == 0 && PF < RING, "ring indices must repeat every step");
     v4i A[RING];
 
     // One pipelined step s: MFMA(s + 1) from the image (rd_e, rd_o) while the epilogue of
     // timestep s runs on accC; halo(s + 2) is written early, the barrier follows two slots
     // later; the last PF slots request the first fragments of the NEXT step from (rn_e, rn_o).
-    constexpr int WR_SLOT = SNNQP_F6_WR_SLOT < KS - PF - 2 ? SNNQP_F6_WR_SLOT : 1;
-    constexpr int BAR_SLOT = SNNQP_F6_BAR_SLOT < KS - PF ? (SNNQP_F6_BAR_SLOT > WR_SLOT ? SNNQP_F6_BAR_SLOT : WR_SLOT + 1) : WR_SLOT + 1;
-    static_assert(BAR_SLOT < KS - PF, "the next step's fragments are read after the barrier");
+    constexpr int WR_SLOT = F6_WR_SLOT < KS - PF - 2 ? F6_WR_SLOT : 1;
+    constexpr int BAR_SLOT = F6_BAR_SLOT < KS - PF ? F6_BAR_SLOT : WR_SLOT + 1;
+    static_assert(WR_SLOT < BAR_SLOT && BAR_SLOT < KS - PF,
+                  "the halo is written before the barrier, the next step's fragments read after it");
     auto fused_step = [&](acc_t &accN, const acc_t &accC, int s, uint32_t rd_e, uint32_t rd_o,
                           uint32_t rn_e, uint32_t rn_o, uint32_t wr_off, int par, bool more) {
-      if (!(SNNQP_F6_ABL & 4)) {
       if (s + 2 < a.T) stage_expand(par);
       if (s + 4 < a.T) stage_load(s + 4, par);
-      }
       ETmp e;
       estage_head(accC, e);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks == 0) accN = mfma_acc(0, A[0], zero16);    // C = inline 0: no preload
-        else if (!(SNNQP_F6_ABL & 1) || ks < 2) accN = mfma_acc(ks, A[ks % RING], accN);
+        else accN = mfma_acc(ks, A[ks % RING], accN);
         __builtin_amdgcn_sched_barrier(0);
         // the slot's A read: PF slots ahead, wrapping into the next step's image
-        if (!(SNNQP_F6_ABL & 32)) {
         if (ks + PF < KS) A[(ks + PF) % RING] = a_read(rd_e, rd_o, ks + PF);
         else if (more) A[(ks + PF) % RING] = a_read(rn_e, rn_o, ks + PF - KS);
-        }
         // an even share of the epilogue stages
         {
           const int lo = ks * NSTAGES / KS, hi = (ks + 1) * NSTAGES / KS;
-          if (!(SNNQP_F6_ABL & 2))
 #pragma unroll
           for (int st = lo; st < hi; ++st) estage(accC, st, e);
         }
-        if (!(SNNQP_F6_ABL & 4))
         if (ks == WR_SLOT && s + 2 < a.T) stage_write(wr_off);
         if (ks == BAR_SLOT) {
-          if (!(SNNQP_F6_ABL & 16)) {
-#ifdef SNNQP_F6_FULL_BARRIER
-          lds_barrier();
-#else
           // The barrier publishes the halo image written in slot WR_SLOT (and the spike word
           // stored at the end of the previous step).  LDS operations of a wave complete in
           // order, and at least BAR_SLOT - WR_SLOT of them (the A reads of the slots in
@@ -432,9 +406,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           // (lgkmcnt(0), which a release fence emits, cost an LDS round trip per step).  No
           // scalar load is in flight here (they return out of order): the loop has none.
           asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_SLOT - WR_SLOT) : "memory");
-#endif
-          }
-          if (!(SNNQP_F6_ABL & 8))
           if (s >= FL && s % FL == 0)              // timesteps < s are behind this barrier
             flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, s - FL, FL, b, y0, x0, tid);
         }
@@ -521,19 +492,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   if (pw.queue && tid == 0) pw.finish();
 }
 
-#ifdef SNNQP_BITS_HEADLINE_ONLY
-// diagnostic builds (tools/diag_build.py): only the instances the headline workload launches
-void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, int dq, bool fma,
-                         bool bnf, unsigned gy, hipStream_t st) {
-  ConvMfmaArgs a = a0;
-  a.patch_h = 4;
-  a.tiles_y = (a.H + 3) / 4;
-  a.npatch = (int64_t)a.B * a.tiles_y * a.tiles_x;
-  if (bnf) launch_persistent(conv3x3_bits_kernel<FMT_FP6, 128, NF_MUL0, true, DQ_ARITH, true, true>, a, gy, st, 0, F6_NT);
-  else launch_persistent(conv3x3_bits_kernel<FMT_FP6, 128, NF_MUL0, true, DQ_ARITH, true, false>, a, gy, st, 0, F6_NT);
-}
-#else
-
 template <int FMT, int CIN, int NF, int DQ, bool FMA, bool BNF>
 static void launch_bits_pool(const ConvMfmaArgs &a, bool pool, unsigned gy, hipStream_t st) {
   if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, DQ, FMA, BNF>, a, gy, st, 0, F6_NT);
@@ -582,6 +540,5 @@ void launch_conv3x3_bits(const ConvMfmaArgs &a0, bool i8, int nf, bool pool, int
     else launch_bits_nf<FMT_FP6, 128>(a, nf, pool, dq, fma, bnf, gy, st);
   }
 }
-#endif
 
 }  // namespace snnqp

@@ -338,25 +338,64 @@ current_min_kernel(Dequant dq, BnP bn, int bound, int Cout, uint32_t *out) {
   if ((threadIdx.x & 63) == 0 && mb != 0x7F800000u) atomicMin(out, mb);
 }
 
-uint32_t *sched_slot(int dev, hipStream_t st) {
-  static std::mutex mu;
-  static uint32_t *pool[64] = {nullptr};
-  static unsigned next[64] = {0};
+namespace {
+struct SchedPool {
+  uint32_t *words = nullptr;
+  hipEvent_t busy[SCHED_SLOTS] = {};
+  bool has_event[SCHED_SLOTS] = {};
+  unsigned next = 0;
+};
+std::mutex g_sched_mu;
+SchedPool g_sched[64];
+}  // namespace
+
+uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
+  int dev = 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  hipDevice_t sdev;
+  if (hipStreamGetDevice(st, &sdev) == hipSuccess) dev = (int)sdev;
+  else if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   if (dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!pool[dev]) {
-    uint32_t *p = nullptr;
-    const size_t bytes = (size_t)SCHED_SLOTS * SCHED_WORDS * sizeof(uint32_t);
-    if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
-    // zeroed on the launch stream's device before the first user; the memset is ordered
-    // before that launch on `st`, later launches find the slots zeroed by their last users
-    if (hipMemsetAsync(p, 0, bytes, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-      (void)hipFree(p);
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  SchedPool &p = g_sched[dev];
+  if (!p.words) {
+    uint32_t *w = nullptr;
+    if (hipMalloc((void **)&w, (size_t)SCHED_SLOTS * SCHED_WORDS * sizeof(uint32_t)) != hipSuccess) {
+      (void)hipGetLastError();
       return nullptr;
     }
-    pool[dev] = p;
+    p.words = w;
   }
-  return pool[dev] + (size_t)(next[dev]++ % SCHED_SLOTS) * SCHED_WORDS;
+  const int slot = (int)(p.next++ % SCHED_SLOTS);
+  if (p.has_event[slot] && hipEventQuery(p.busy[slot]) != hipSuccess) {
+    (void)hipGetLastError();            // hipErrorNotReady: the slot's last launch is in flight
+    return nullptr;
+  }
+  uint32_t *words = p.words + (size_t)slot * SCHED_WORDS;
+  if (hipMemsetAsync(words, 0, SCHED_WORDS * sizeof(uint32_t), st) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *dev_out = dev;
+  *slot_out = slot;
+  return words;
+}
+
+void sched_release(int dev, int slot, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  SchedPool &p = g_sched[dev];
+  if (!p.has_event[slot]) {
+    if (hipEventCreateWithFlags(&p.busy[slot], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      // no event: the slot cannot be proven free again, so retire it from the rotation by
+      // leaving has_event false and never reusing it while anything may be in flight
+      p.has_event[slot] = false;
+      return;
+    }
+    p.has_event[slot] = true;
+  }
+  if (hipEventRecord(p.busy[slot], st) != hipSuccess) (void)hipGetLastError();
 }
 
 int run_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound, int32_t Cout,

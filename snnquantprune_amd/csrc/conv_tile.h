@@ -536,17 +536,27 @@ __device__ __forceinline__ v16i splat16(int v) {
   return v16i{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
 }
 
-// Work-queue words for a launch: a per-device pool of zeroed slots, handed out round-robin
-// (a launch leaves its slot zeroed; SCHED_SLOTS launches may be in flight per device).
-// Allocated once per device and kept for the life of the process.  null -> static walk.
-uint32_t *sched_slot(int dev, hipStream_t st);
+// Work-queue words for a launch: a per-device pool of SCHED_SLOTS slots handed out round-robin,
+// allocated once per device and kept for the life of the process.  A slot is self-validating:
+//  * it is zeroed on the launch's stream right before the launch (so whatever an earlier,
+//    possibly aborted, launch left in it cannot be walked), and
+//  * an event recorded after the launch marks it busy: when the round-robin pointer comes
+//    back to a slot whose last launch has not completed (more than SCHED_SLOTS launches in
+//    flight across streams / threads), or the stream is being captured into a graph (events
+//    cannot be queried there), the launch takes the static walk instead (sched = nullptr),
+//    which is always correct, only less well balanced.
+// sched_acquire returns the slot's words (or nullptr) and its index; sched_release records
+// the event.  The device comes from the stream, not from the calling thread's current device.
+uint32_t *sched_acquire(hipStream_t st, int *dev, int *slot);
+void sched_release(int dev, int slot, hipStream_t st);
 
 template <typename K>
 static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st,
                                      size_t dyn_lds = 0, int threads = 256) {
-  int dev = 0, cus = 256, occ = 2;
-  if (hipGetDevice(&dev) == hipSuccess)
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int dev = 0, cus = 256, occ = 2, slot = -1;
+  a.sched = gy <= (unsigned)SCHED_Y && a.npatch < (1ll << 30) ? sched_acquire(st, &dev, &slot) : nullptr;
+  if (!a.sched && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, dyn_lds) != hipSuccess ||
       occ < 1)
     occ = 1;
@@ -558,12 +568,8 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
     gx &= ~7u;
     a.xcd_split = 1;
   }
-#ifdef SNNQP_STATIC_WALK          // diagnostic build: the static patch walk
-  a.sched = nullptr;
-#else
-  a.sched = gy <= (unsigned)SCHED_Y && a.npatch < (1ll << 30) ? sched_slot(dev, st) : nullptr;
-#endif
   hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(threads), dyn_lds, st, a);
+  if (a.sched) sched_release(dev, slot, st);
 }
 
 // conv3x3_bits.hip: bit-packed input, Cin <= 128; i8 = codes wider than fp6 holds

@@ -17,7 +17,6 @@ import math
 from typing import Any, Callable, Optional
 
 import numpy as np
-import os
 
 import torch
 
@@ -318,8 +317,7 @@ class SpikingBlock(nn.Module):
       if u0 is not None:
         u0 = u0.unsqueeze(1)
     if (isinstance(x, ops.PackedSpikes) and w.is_int and w.min_current_bits == 0
-        and 0 < w.abs_sum_max < (1 << 22) and impl != L.IMPL_GENERIC and u0 is None
-        and not os.environ.get("SNNQP_NO_FUSED_UPDATE")):        # (A/B switch)
+        and 0 < w.abs_sum_max < (1 << 22) and impl != L.IMPL_GENERIC and u0 is None):
       # let the kernel fuse the membrane update where BatchNorm of every reachable
       # dequantised accumulator value proves that exact (snnqp.h, min_current_bits)
       import dataclasses

@@ -1369,6 +1369,61 @@ def test_density_probes_and_workload_tables(dev, oracle, tmp_path):
   assert abs(float(mut3["intermediates"]["dense1_out_mean"][0]) - float(d.mean())) < 2e-7
 
 
+def test_work_queue_slots_with_many_launches_in_flight_and_graph_capture(dev, oracle):
+  """The fused conv kernels claim patches from per-launch work-queue slots (64 per device,
+  snnqp.h).  96 launches enqueued on 8 streams without a synchronisation in between (more
+  than there are slots: the launches that find their slot busy walk statically), both conv
+  kernels, must all produce the result of a lone launch; and a launch captured into a HIP
+  graph (no queue inside a capture) replays bit-identically."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  outs = {}
+  jobs = []
+  for name, c in (("bits", cases.conv_block_case(T=6, B=16, hw=16)),
+                  ("u8c2", cases.conv_block_case(T=6, B=16, hw=16, cin=2, seed=961, gain=4.0))):
+    e = cases.conv_block_expected(oracle, c)
+    w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+    bn = _bn(c["bn"], dev)
+    nrn = _mslif()
+    g = ops.ConvGeom(16, 16, c["x"].shape[-1], 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+    x = _t(c["x"], dev)
+    xin = ops.pack_bits(x) if name == "bits" else x
+    x_max = 1 if name == "bits" else ops.input_max_bound(x)
+    jobs.append((name, xin, g, w, nrn, bn, x_max, e))
+  torch.cuda.synchronize()
+  streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+  results = []
+  for rep in range(6):
+    for st in streams:
+      for (name, xin, g, w, nrn, bn, x_max, e) in jobs:
+        with torch.cuda.stream(st):
+          _, s = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                                      impl=L.IMPL_MFMA, x_max=x_max)
+        results.append((name, s, e))
+  torch.cuda.synchronize()
+  assert len(results) == 96
+  for name, s, e in results:
+    np.testing.assert_array_equal(_np(s), e["pooled_bits"], err_msg=name)
+  # graph capture: the launch inside the capture takes the static walk
+  name, xin, g, w, nrn, bn, x_max, e = jobs[0]
+  out = torch.zeros_like(results[0][1].bits)
+  graph = torch.cuda.CUDAGraph()
+  cap = torch.cuda.Stream(device=dev)
+  with torch.cuda.stream(cap):
+    ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                         impl=L.IMPL_MFMA, x_max=x_max)          # warm (allocations) outside capture
+    cap.synchronize()
+    with torch.cuda.graph(graph, stream=cap):
+      _, s = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                                  impl=L.IMPL_MFMA, x_max=x_max)
+      out.copy_(s.bits)
+  for _ in range(3):
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(out).view(np.uint32), e["pooled_bits"])
+
+
 def test_eval_step_metrics(dev, oracle):
   from snnquantprune_amd import linen as nn
   from snnquantprune_amd import models, synthetic as syn, train_utils

@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench.py per-kernel times of diagnostic variants: tools/r02_variants.sh OUTDIR name1 name2 ...
+# bench.py per-kernel times of diagnostic variants: tools/variants_bench.sh OUTDIR name1 name2 ...
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
 for v in "$@"; do
