@@ -71,8 +71,6 @@ def parse(argv=None):
                   help="resident input dtype: uint8 event frames (default) or the float32 "
                        "frames the reference's pipeline hands over (inspected and narrowed "
                        "on device inside the step)")
-  ap.add_argument("--prefetch-inspect", action="store_true",
-                  help="inspect the next batch on a side stream while this one computes")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--allow-diag", action="store_true",
@@ -319,19 +317,10 @@ def main(argv=None):
   if args.input == "f32":
     x = x.to(torch.float32)
 
-  batches = [x, x.clone()] if args.prefetch_inspect else [x]
-  counter = [0]
-
   def step():
     if ops is not None:
       ops.forget_inputs()     # a new batch: whatever is cached about the last one is dropped
-    xb = batches[counter[0] % len(batches)]
-    counter[0] += 1
-    if args.prefetch_inspect and ops is not None:
-      # the NEXT batch is resident too: its inspection pass goes to a side stream before this
-      # batch's kernels are queued (one pass per step, inside the timed region, as without)
-      ops.prefetch_input_bound(batches[counter[0] % len(batches)])
-    return parallel.all_gather_rows(apply_fn(xb))
+    return parallel.all_gather_rows(apply_fn(x))
 
   def fence():
     if world > 1:

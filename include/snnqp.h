@@ -220,16 +220,21 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       a pixel keeps its ceil(Cin / 32) spike words, zero bits beyond Cin --
  *       or U8 input with Cin == 2, any count 0..255), s_type BITS;
  *       any H, W, Cout and neuron kind.  SNNQP_IMPL_AUTO picks MFMA when it can.
- * x_max an upper bound of the input values if known (1 for spikes), else 0: with
- *       weights' abs_sum_max it bounds |acc| and lets the MFMA kernels dequantise
- *       through an LDS table instead of arithmetic. */
+ * x_max the largest input value the caller EXPECTS (1 for spikes and binary event frames;
+ *       0 = unknown, taken as 1): with the weights' abs_sum_max it sizes the LDS tables the
+ *       MFMA kernels dequantise through.  It is a hint, not a promise: the U8 kernel takes
+ *       the maximum of every chunk of input it stages and runs the general path (any count up
+ *       to 255, arithmetic dequantisation) for a chunk that exceeds it -- same results, slower.
+ * x_seen nullable device word (the caller zeroes it): atomically max-ed with the largest U8
+ *       input value the launch met, so the caller can refine its next hint asynchronously;
+ *       nothing ever waits for it. */
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
                            const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                            const int8_t *wt, const snnqp_bn_t *bn,
                            const snnqp_neuron_t *nrn, const float *u0,
                            float *u_out, void *s_out, int s_type, int pool,
-                           int impl, int x_max, snnqp_stream_t stream);
+                           int impl, int x_max, int32_t *x_seen, snnqp_stream_t stream);
 
 /* Smallest non-zero |BatchNorm_c(fl(fl(acc / L) * m))| over |acc| <= bound and the Cout
  * channels (bn nullable: identity), as float32 bits, atomically min-ed into *out_bits

@@ -72,7 +72,7 @@ _PROTOTYPES = {
     "snnqp_conv_lif_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
-        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "snnqp_dense_lif_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,

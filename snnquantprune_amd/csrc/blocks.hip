@@ -13,7 +13,7 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            const int8_t *wt, const snnqp_bn_t *bn,
                            const snnqp_neuron_t *nrn,
                            const float *u0, float *u_out, void *s_out,
-                           int s_type, int pool, int impl, int x_max,
+                           int s_type, int pool, int impl, int x_max, int32_t *x_seen,
                            snnqp_stream_t stream) {
   SNNQP_REQUIRE(g && w && nrn, SNNQP_EINVAL, "conv_lif_forward: null descriptor");
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
@@ -28,7 +28,7 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
     SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "conv_lif_forward: MFMA kernel: %s", why);
   if (!why && impl != SNNQP_IMPL_GENERIC)
     return run_conv3x3_mfma(x, in_type, x_stride_t, x_stride_b, T, B, g, w, wt, bn,
-                            nrn, u0, u_out, (uint32_t *)s_out, pool, x_max,
+                            nrn, u0, u_out, (uint32_t *)s_out, pool, x_max, x_seen,
                             (hipStream_t)stream);
   SNNQP_REQUIRE(pool == 1, SNNQP_EUNSUPPORTED,
                 "conv_lif_forward: the direct-form kernel does not fuse the "

@@ -17,56 +17,6 @@
 
 namespace snnqp {
 
-#ifdef SNNQP_CLOCK_PROBE
-// Diagnostic build only (python csrc/build.py with SNNQP_PROBE=1): shader-clock
-// and 100 MHz real-time stamps of workgroup 0 around the persistent loop, to
-// read the clock the chip sustains inside this kernel.  Never in the product.
-__device__ unsigned long long snnqp_clock_probe[5];
-__device__ unsigned int snnqp_wg_span[2 * 4096];   // per workgroup: start, end (100 MHz ticks, low 32 bits)
-extern "C" int snnqp_debug_read_wg_span(unsigned int *out8192) {
-  return (int)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(snnqp_wg_span), 8192 * 4);
-}
-extern "C" int snnqp_debug_read_probe(unsigned long long *out5) {
-  return (int)hipMemcpyFromSymbol(out5, HIP_SYMBOL(snnqp_clock_probe), 40);
-}
-#define PROBE_BEGIN()                                                        \
-  unsigned long long pc0 = 0, pr0 = 0;                                       \
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)              \
-    snnqp_wg_span[2 * blockIdx.x] = (unsigned int)__builtin_amdgcn_s_memrealtime(); \
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {              \
-    pc0 = __builtin_amdgcn_s_memtime();                                      \
-    pr0 = __builtin_amdgcn_s_memrealtime();                                  \
-  }
-#define PROBE_END()                                                          \
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)              \
-    snnqp_wg_span[2 * blockIdx.x + 1] = (unsigned int)__builtin_amdgcn_s_memrealtime(); \
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {              \
-    snnqp_clock_probe[0] = __builtin_amdgcn_s_memtime() - pc0;               \
-    snnqp_clock_probe[4] = __builtin_amdgcn_s_memrealtime() - pr0;           \
-  }
-#define PHASE_DECL() unsigned long long ph_t = 0, ph_acc[3] = {0, 0, 0};
-#define PHASE_START() ph_t = __builtin_amdgcn_s_memtime();
-#define PHASE_MARK(i)                                         \
-  {                                                           \
-    const unsigned long long n__ = __builtin_amdgcn_s_memtime(); \
-    ph_acc[i] += n__ - ph_t;                                  \
-    ph_t = n__;                                               \
-  }
-#define PHASE_DUMP()                                                    \
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {         \
-    snnqp_clock_probe[1] = ph_acc[0];                                   \
-    snnqp_clock_probe[2] = ph_acc[1];                                   \
-    snnqp_clock_probe[3] = ph_acc[2];                                   \
-  }
-#else
-#define PROBE_BEGIN()
-#define PROBE_END()
-#define PHASE_DECL()
-#define PHASE_START()
-#define PHASE_MARK(i)
-#define PHASE_DUMP()
-#endif
-
 // ---------------------------------------------------------------------------
 // u8 event-count input with Cin = 2 (the DVS polarity pair, conv0): K = 18 of
 // one 32-deep MFMA step.  One MFMA feeds 1024 neuron updates, so the kernel is
@@ -82,12 +32,23 @@ extern "C" int snnqp_debug_read_probe(unsigned long long *out5) {
 //    bytes 6, 7 of a row read belong to the next pixel; their B rows are zero;
 //  * the constant k rows carry the table address: B rows 24..28 of a channel sum
 //    to the byte address of its entry of acc = 0 (C = 0, no accumulator preload).
+//
+// The table modes (LUTM, sized by the host for the input values it EXPECTS: the hint
+// x_limit) are valid only while every staged input value is <= x_limit.  Nothing is
+// trusted: while a chunk's halo sits in registers on its way to LDS the workgroup takes
+// its maximum, and a chunk that holds a larger value (a hot pixel, event counts where
+// binary frames were expected, a stale hint) runs the general path -- input as x - 128,
+// arithmetic dequantisation, any count up to 255 -- for that chunk only.  The largest
+// value a launch saw goes to *x_seen, from which the caller refines its next hint without
+// ever waiting for it (no inspection pass, no host synchronisation before the launch).
 // ---------------------------------------------------------------------------
 constexpr int HROW2 = 24;                 // LDS bytes per halo row
 constexpr int HCOPY2 = HALO * HROW2;      // one copy of one timestep
 constexpr int HCONST2 = 2 * HCOPY2;       // the 8 constant bytes
 constexpr int HIMG2 = 496;                // one timestep image
 constexpr int TCHUNK = 32;                // most timesteps staged per pass
+constexpr int U8C2_WPS = 4;               // waves per SIMD the kernel is compiled for (128 VGPRs)
+constexpr int STG_N = TCHUNK / 2;           // timesteps a staging thread loads per chunk (every other one)
 
 typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((address_space(3))) const v2i_a4 lds_cv2i_t;
@@ -100,7 +61,7 @@ __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
 }
 
 template <int NF, bool POOL, int LUTM>
-__global__ void __launch_bounds__(256, SNNQP_U8C2_WPS)
+__global__ void __launch_bounds__(256, U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
@@ -115,41 +76,41 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int cout = wave_on ? cout_base + n : n;
   const int cpar = cout < a.Cout ? cout : a.Cout - 1;      // parameter loads
   const uint32_t cmask = chan_mask(cout_base, a.Cout);
-  // smallest non-zero |input current| of this workgroup's channels (table kernels):
-  // decides whether the membrane update may be one fused multiply-add
-  uint32_t *wgmin = obuf + OutStage<POOL>::BYTES / 4;
-  if (LUTM != LUT_NONE) {
-    if (tid == 0) *wgmin = 0x7F800000u;
-    lds_barrier();
-  }
+  // workgroup words behind the spike-word ring:
+  //   [0] smallest non-zero |input current| of this workgroup's channels (table kernels):
+  //       decides whether the membrane update may be one fused multiply-add
+  //   [1] largest input value of the chunk being staged   [2] the claimed next patch
+  uint32_t *wgw = obuf + OutStage<POOL>::BYTES / 4;
+  if (tid == 0) { wgw[0] = 0x7F800000u; wgw[1] = 0u; }
+  if (LUTM != LUT_NONE) lds_barrier();
   // tables and constants become visible with the first staging barrier
   if (LUTM == LUT_SHARED) {
     build_lut((float *)(lds + lut_off), a.lut_bound, a.dq, tid);
     if (NF == NF_MUL0) {             // BatchNorm of every entry, per channel: may the update fuse?
       lds_barrier();
-      atomicMin(wgmin, lut_bn_min_bits((const float *)(lds + lut_off), a.lut_bound, a.bn,
-                                       blockIdx.y * 128, a.Cout, tid, 256));
+      atomicMin(wgw, lut_bn_min_bits((const float *)(lds + lut_off), a.lut_bound, a.bn,
+                                     blockIdx.y * 128, a.Cout, tid, 256));
     }
   }
   if (LUTM == LUT_CHANNEL) {
     const uint32_t mb = build_lut_channel((float *)(lds + lut_off), a.lut_bound, a.dq, a.bn,
                                           blockIdx.y * 128, a.Cout, tid);
-    atomicMin(wgmin, mb);
+    atomicMin(wgw, mb);
   }
   if (tid < tc) {
     *(uint32_t *)(lds + tid * HIMG2 + HCONST2) = 0x7F7F7F7Fu;
     *(uint32_t *)(lds + tid * HIMG2 + HCONST2 + 4) = 0x00000001u;
   }
 
-  // without a table the input is taken as x - 128 (a signed int8 for every count up to
-  // 255; padding pixels are x = 0 like any other) and 128 * sum_k w[k] is added back to
-  // the accumulator in the epilogue (an integer below 2^24: exact in float32)
-  constexpr bool OFFS = LUTM == LUT_NONE;
+  // B operands.  Table path (`bf`): the codes (x 8 for per-channel tables) and, over the
+  // constant k rows, the byte address of this lane's table entry of acc = 0 as 127 q + r
+  // (rows 24..27 take q in parts of at most 127, row 28 takes r).  General path (`bfg`): the
+  // plain codes; the input is taken as x - 128 (a signed int8 for every count up to 255;
+  // padding pixels are x = 0 like any other) and 128 * sum_k w[k] is added back to the
+  // accumulator in the epilogue (an integer below 2^24: exact in float32).
   float acc_off = 0.0f;
-  v4i bf;
+  v4i bf, bfg;
   {
-    // byte address of this lane's table entry of acc = 0, as 127 * q + r over the
-    // constant k rows: rows 24..27 take q in parts of at most 127, row 28 takes r
     int bias = 0;
     if (LUTM == LUT_SHARED) bias = (int)lds_addr(lds) + lut_off + 4 * a.lut_bound;
     if (LUTM == LUT_CHANNEL)     // the wave's block, row of acc = 0, this lane's channel
@@ -158,19 +119,20 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     int q = bias / 127;
     const int r = bias - 127 * q;
     int wsum = 0;
-    int v[4];
+    int v[4], vg[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      uint32_t pk = 0;
+      uint32_t pk = 0, pkg = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = 16 * h + 4 * d + j;
-        uint32_t bv = 0;
+        uint32_t bv = 0, bg = 0;
         if (k < 24) {
           const int dy = k >> 3, b = k & 7;
           if (b < 6 && cout < a.Cout) {   // HWIO with Cin = 2: row (3 dy + dx) * 2 + cin = 6 dy + b
             const int code = a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
             wsum += code;
+            bg = (uint8_t)code;
             bv = (uint8_t)(LUTM == LUT_CHANNEL ? code * 8 : code);   // see build_lut_channel
           }
         } else if (k < 28) {
@@ -181,12 +143,15 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
           bv = (uint32_t)r;
         }
         pk |= bv << (8 * j);
+        pkg |= bg << (8 * j);
       }
       v[d] = (int)pk;
+      vg[d] = (int)pkg;
     }
     bf = v4i{v[0], v[1], v[2], v[3]};
+    bfg = v4i{vg[0], vg[1], vg[2], vg[3]};
     // the two lane halves hold k 0..15 and 16..23 of the same channel
-    if (OFFS) acc_off = 128.0f * (float)(wsum + __shfl_xor(wsum, 32));
+    acc_off = 128.0f * (float)(wsum + __shfl_xor(wsum, 32));
   }
 
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
@@ -208,9 +173,11 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int ob0 = out_pix<POOL>(0, lane) * 4 + wave;
   const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
   const bool store_lane = POOL ? lane < 8 : lane < 32;
+  uint32_t seen = 0;                       // largest input value this thread's waves met
+  const bool s_task = tid < 2 * HALO * HALO;
+  const int s_half = tid >= HALO * HALO ? 1 : 0, s_pix = tid - s_half * HALO * HALO;
+  const int s_dst = (s_pix / HALO) * HROW2 + (s_pix % HALO) * 2;
 
-  PHASE_DECL()
-  PROBE_BEGIN()
   PatchWalk pw(a);
   int r = (int)pw.first;                 // patch indices fit 31 bits (launch check)
   while (r < (int)pw.count) {
@@ -222,46 +189,64 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     float u[2][16];
     if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
     else zero_u(u);
+    uint32_t pseen = 0;                  // largest input value of this patch so far
+    // staging task: halo pixel tid % 100 of the timesteps of parity tid / 100
+    const int s_gy = y0 + s_pix / HALO - 1, s_gx = x0 + s_pix % HALO - 1;
+    const bool s_valid = s_task && s_gy >= 0 && s_gy < a.H && s_gx >= 0 && s_gx < a.W;
+    const uint8_t *s_src = xb + (int64_t)b * a.xs_b + ((int64_t)s_gy * a.W + s_gx) * 2;
 
     for (int t0 = 0; t0 < a.T; t0 += tc) {
       const int nt = min(tc, a.T - t0);
-      PHASE_START()
+      // ---- stage the chunk: load, take the maximum, choose the path, write ----
+      // Thread = one halo pixel (both polarities: 2 bytes) of every other timestep: its only
+      // per-patch state is one source pointer, so nothing else is live while the byte pairs
+      // wait in registers for the workgroup to agree on the path.
+      uint16_t v[STG_N];
+      uint32_t mx = 0;
+#pragma unroll
+      for (int i = 0; i < STG_N; ++i) {    // all loads first
+        const int tt = 2 * i + s_half;
+        v[i] = 0;
+        if (s_valid && tt < nt) v[i] = *(const uint16_t *)(s_src + (int64_t)(t0 + tt) * a.xs_t);
+      }
+#pragma unroll
+      for (int i = 0; i < STG_N; ++i)
+        mx = max(mx, max((uint32_t)(v[i] & 0xFFu), (uint32_t)(v[i] >> 8)));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
       lds_barrier();                       // previous readers of the LDS images are done
-      for (int tb = 0; tb < nt * (HALO * HALO); tb += 8 * 256) {
-        uint16_t v[8];
+      if (lane == 0 && mx != 0) atomicMax(&wgw[1], mx);
+      lds_barrier();
+      const uint32_t cmax = wgw[1];        // uniform: every wave reads the same word
+      seen = max(seen, cmax);
+      pseen = max(pseen, cmax);
+      const bool general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
+      if (s_task) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {        // all loads first, then all LDS writes
-          const int task = tb + tid + k * 256;
-          const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
-          const int gy = y0 + pix / HALO - 1, gx = x0 + pix % HALO - 1;
-          v[k] = 0;
-          if (tt < nt && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            v[k] = *(const uint16_t *)(xb + (int64_t)(t0 + tt) * a.xs_t +
-                                       (int64_t)b * a.xs_b + ((int64_t)gy * a.W + gx) * 2);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int task = tb + tid + k * 256;
-          const int tt = task / (HALO * HALO), pix = task % (HALO * HALO);
+        for (int i = 0; i < STG_N; ++i) {
+          const int tt = 2 * i + s_half;
           if (tt < nt) {    // table modes: both bytes scale without a carry (counts <= 31 / 7)
-            const uint16_t val = LUTM == LUT_CHANNEL  ? (uint16_t)(v[k] << 4)
-                                 : LUTM == LUT_SHARED ? (uint16_t)(v[k] << 2)
-                                                      : (uint16_t)(v[k] ^ 0x8080u);   // x - 128
-            uint8_t *p = lds + tt * HIMG2 + (pix / HALO) * HROW2 + (pix % HALO) * 2;
+            const uint16_t val = general               ? (uint16_t)(v[i] ^ 0x8080u)    // x - 128
+                                 : LUTM == LUT_CHANNEL ? (uint16_t)(v[i] << 4)
+                                                       : (uint16_t)(v[i] << 2);
+            uint8_t *p = lds + tt * HIMG2 + s_dst;
             *(uint16_t *)p = val;
             *(uint16_t *)(p + HCOPY2 + 2) = val;
           }
         }
       }
       lds_barrier();
-      PHASE_MARK(0)
-      // the FL-step blocks of the chunk, with the membrane update as a fused
-      // multiply-add where that is proven bit-identical for this launch
-      auto run_chunk = [&](auto fma_tag) {
+      if (tid == 0) wgw[1] = 0u;           // for the next chunk (read above, behind a barrier)
+      // the FL-step blocks of the chunk: table path (with the membrane update as a fused
+      // multiply-add where that is proven bit-identical for this launch) or general path
+      auto run_chunk = [&](auto mode_tag, auto fma_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
       constexpr bool FMA = decltype(fma_tag)::value;
+      constexpr bool OFFS = MODE == LUT_NONE;
+      const v4i bw = OFFS ? bfg : bf;
       for (int tf = 0; tf < nt; tf += FL) {          // FL steps, then flush
         const int nf = min(FL, nt - tf);
-#pragma unroll SNNQP_U8C2_UNROLL
+#pragma unroll 1
         for (int tt = tf; tt < tf + nf; ++tt) {
           const uint32_t img = (uint32_t)(tt * HIMG2);
           uint32_t words[2];
@@ -270,13 +255,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             const v2i_a4 lo = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offA[tl]);
             const v2i_a4 hi = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offB[tl]);
             v16i acc = splat16(0);
-#if defined(SNNQP_ABL) && (SNNQP_ABL & 2)   // diagnostic build: no MFMA
-            acc[0] = bf.w + ((lo.x ^ lo.y ^ hi.x) & 4);
-#else
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bf, acc,
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bw, acc,
                                                         0, 0, 0);
-#endif
-            words[tl] = tile_epilogue<NF, POOL, LUTM, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
+            words[tl] = tile_epilogue<NF, POOL, MODE, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
                                                                    lane, acc_off);
           }
           if (store_lane) {
@@ -285,30 +266,33 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             o[ob1] = words[1] & cmask;
           }
         }
-        PHASE_MARK(1)
         lds_barrier();
         flush_out<POOL>(obuf, a, t0 + tf, nf, b, y0, x0, tid);
         lds_barrier();
-        PHASE_MARK(2)
       }
       };
-      bool fma_ok = false;
-      if (NF == NF_MUL0 && LUTM != LUT_NONE)
-        fma_ok = lif_fma_is_exact(*wgmin, a.nrn.k_log2, a.T, a.u0 != nullptr);
-      if (NF == NF_MUL0 && LUTM != LUT_NONE && fma_ok) run_chunk(std::true_type{});
-      else run_chunk(std::false_type{});
+      if (general) {
+        run_chunk(std::integral_constant<int, LUT_NONE>{}, std::false_type{});
+      } else if constexpr (LUTM != LUT_NONE) {
+        // a patch whose earlier chunk took the general path holds potentials the table
+        // path's power-of-two argument does not cover: fused only while the whole patch
+        // so far stayed within the tables
+        const bool fma_ok = NF == NF_MUL0 && pseen <= (uint32_t)a.x_limit &&
+                            lif_fma_is_exact(wgw[0], a.nrn.k_log2, a.T, a.u0 != nullptr);
+        if (fma_ok) run_chunk(std::integral_constant<int, LUTM>{}, std::true_type{});
+        else run_chunk(std::integral_constant<int, LUTM>{}, std::false_type{});
+      }
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
     if (pw.queue) {                      // the claimed patch, to the whole workgroup
-      if (tid == 0) wgmin[2] = (uint32_t)r_next;
+      if (tid == 0) wgw[2] = (uint32_t)r_next;
       lds_barrier();
-      r_next = __builtin_amdgcn_readfirstlane((int)wgmin[2]);
+      r_next = __builtin_amdgcn_readfirstlane((int)wgw[2]);
     }
     r = r_next;
   }
+  if (a.x_seen && tid == 0 && seen != 0) atomicMax(a.x_seen, seen);
   if (pw.queue && tid == 0) pw.finish();
-  PROBE_END()
-  PHASE_DUMP()
 }
 
 // ---------------------------------------------------------------------------
@@ -444,7 +428,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     int x_max, hipStream_t st) {
+                     int x_max, int32_t *x_seen, hipStream_t st) {
   SNNQP_REQUIRE(x && w->w && s_out, SNNQP_EINVAL, "conv3x3 mfma: null pointer");
   SNNQP_REQUIRE(in_type != SNNQP_BITS || wt, SNNQP_EINVAL,
                 "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
@@ -462,6 +446,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.bn = make_bn(bn);
   a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
+  a.x_seen = x_seen;
   a.patch_h = 8;
   a.tiles_y = (g->H + 7) / 8; a.tiles_x = (g->W + 7) / 8;
   a.npatch = (int64_t)B * a.tiles_y * a.tiles_x;
@@ -469,8 +454,11 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const bool pl = pool == 2;
   const unsigned gy = (unsigned)((g->Cout + 127) / 128);
   // |acc| <= abs_sum_max * x_max; small enough -> dequantise through an LDS table
-  // (the A operand then carries 4 * x, which must stay an int8)
-  const int64_t xm = in_type == SNNQP_BITS ? 1 : x_max;
+  // (the A operand then carries 4 * x, which must stay an int8).  For U8 input x_max is the
+  // value the caller EXPECTS not to be exceeded (0 / unknown: binary events); the kernel
+  // checks every chunk it stages and runs the general path where the hint does not hold
+  const int64_t xm = in_type == SNNQP_BITS ? 1 : (x_max > 0 ? x_max : 1);
+  a.x_limit = (int32_t)(xm > 255 ? 255 : xm);
   const int64_t bound = (int64_t)w->abs_sum_max * xm;
   const bool lut = w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
   a.lut_bound = lut ? (int32_t)bound : 0;

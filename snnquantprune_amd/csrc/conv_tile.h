@@ -14,11 +14,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // two passes anyway and, unlike scalar VALU ops, do not overlap with an MFMA in flight
 // (tools/ubench/mfma_overlap_classes.hip: 4 v_pk_fma + 1 MFMA = 25.5 ns against 9.7 +
 // 13.9 apart; 8 v_fma_f32 + 1 f8f6f4 MFMA = 21.7 ns against 18.4 + 15.3).
-// -DSNNQP_PACKED_F32 brings the packed forms back for A/B runs.
-#ifdef SNNQP_PACKED_F32
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-#else
 struct v2f {
   float x, y;
 };
@@ -32,14 +27,7 @@ __device__ __forceinline__ v2f operator-(v2f a) { return v2f{-a.x, -a.y}; }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
   return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
 }
-#endif
 
-#ifndef SNNQP_U8C2_UNROLL
-#define SNNQP_U8C2_UNROLL 1
-#endif
-#ifndef SNNQP_U8C2_WPS
-#define SNNQP_U8C2_WPS 4    // waves per SIMD the conv0 kernel is compiled for (128 VGPRs)
-#endif
 
 // Dequantisation by LDS table (fast neuron path only).  The accumulator is made
 // to BE the table address: the A operand carries 4x the input (spike bytes {0,4},
@@ -54,10 +42,7 @@ enum { LUT_NONE = 0, LUT_SHARED = 1, LUT_CHANNEL = 2 };
 // thousand) then still dequantises by table and keeps three workgroups per CU; in the bits
 // kernel the entry of acc = 0 stays an instruction immediate (< 64 KiB from the LDS base).
 constexpr int LUT_CAP = 4095;
-#ifndef SNNQP_LUT2_CAP
-#define SNNQP_LUT2_CAP 40
-#endif
-constexpr int LUT2_CAP = SNNQP_LUT2_CAP;
+constexpr int LUT2_CAP = 40;
 constexpr int LUT_XMAX = 31;                    // 4 * x must stay an int8
 template <int LUTM>
 struct LutBytes {
@@ -90,7 +75,9 @@ struct ConvMfmaArgs {
   int32_t pool;
   int32_t tiles_y, tiles_x;
   int64_t npatch;
-  int32_t lut_bound;  // > 0: |acc| <= lut_bound guaranteed, dequant by LDS table
+  int32_t lut_bound;  // > 0: |acc| <= lut_bound while inputs <= x_limit, dequant by LDS table
+  int32_t x_limit;    // u8c2 kernel: largest input value the table mode is sized for
+  int32_t *x_seen;    // u8c2 kernel: (nullable) atomically max-ed with the largest input seen
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
   uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk
@@ -339,7 +326,6 @@ __device__ __forceinline__ v2f neuron_update(v2f x, v2f u, const LaneConsts &lc,
     return ud + x;
   }
   // u - 0 == u exactly, so NF_MUL0 skips the subtraction
-#ifndef SNNQP_PACKED_F32
   if (FMA && PACKED) {
     // conv0's table kernel: no MFMA worth overlapping (one per 1024 updates), and one
     // v_pk_add + one v_pk_fma per pair issue in fewer slots than four scalar ops
@@ -350,7 +336,6 @@ __device__ __forceinline__ v2f neuron_update(v2f x, v2f u, const LaneConsts &lc,
     const v2fp r = __builtin_elementwise_fma(dp, v2fp{nrn.inv_k, nrn.inv_k}, up);
     return v2f{r.x, r.y};
   }
-#endif
   const v2f d = NF == NF_MUL0 ? x - u : x - (u - lc.vr);
   if (NF == NF_DIV) return u + v2f{d.x / nrn.k, d.y / nrn.k};
   if (FMA) return fma2(d, v2f{nrn.inv_k, nrn.inv_k}, u);
@@ -376,11 +361,6 @@ __device__ __forceinline__ void neuron_pair(v2f y, float &u0, float &u1,
                                             const LaneConsts &lc, const NeuronP &nrn,
                                             unsigned long long &m0,
                                             unsigned long long &m1) {
-#if defined(SNNQP_ABL) && (SNNQP_ABL & 1)   // diagnostic build: no BN / neuron math
-  m0 = __ballot(y.x > u0);
-  m1 = __ballot(y.y > u1);
-  return;
-#endif
   v2f x = y;
   if (!BNDONE) {
     x = x - lc.bmean;

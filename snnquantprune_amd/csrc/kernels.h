@@ -21,7 +21,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     int x_max, hipStream_t st);
+                     int x_max, int32_t *x_seen, hipStream_t st);
 
 // float32 x float32 connection on the f32 MFMA (fseq_gemm.hip)
 const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,

@@ -329,6 +329,46 @@ def input_max_bound(x) -> int:
   return v
 
 
+class CountHint:
+  """What the first layer's kernel should size its tables for: the largest event count it
+  is likely to meet on this device (1 = binary frames).  The kernel never trusts it -- it
+  checks every chunk of input it stages and falls back per chunk (snnqp.h, x_max) -- and
+  reports the largest value it saw into `word`; that word is copied back with a
+  non-blocking copy and looked at on a later call, when the copy has long finished, so
+  the host never waits for the device to learn about its input."""
+
+  def __init__(self, device):
+    self.value = 1
+    self.word = torch.zeros(1, dtype=torch.int32, device=device)
+    self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    self._event = None
+
+  def current(self) -> int:
+    if self._event is not None and self._event.query():
+      self._event = None
+      self.value = max(1, int(self._host[0]))
+    return self.value
+
+  def launched(self):
+    """After a launch that was given `word`: start its read-back (at most one in flight)."""
+    if self._event is None:
+      self._host.copy_(self.word, non_blocking=True)
+      self.word.zero_()
+      self._event = torch.cuda.Event()
+      self._event.record()
+
+
+_count_hints = {}
+
+
+def count_hint(device) -> CountHint:
+  key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+  h = _count_hints.get(key)
+  if h is None:
+    h = _count_hints[key] = CountHint(device)
+  return h
+
+
 def f32_to_u8(x: torch.Tensor) -> torch.Tensor:
   x = _f32c(x)
   _require_gpu(x)
@@ -488,9 +528,12 @@ def _tb_strides(x, T, B, time_major: bool, unit: int):
 def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
                      bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
                      want_u: bool = True, packed_out: bool = False, pool: int = 1,
-                     impl: int = L.IMPL_AUTO, time_major: bool = True, x_max: int = 0):
+                     impl: int = L.IMPL_AUTO, time_major: bool = True, x_max: int = 0,
+                     x_seen: Optional[torch.Tensor] = None):
   """x [T, B, H, W, Cin] (or [B, T, ...] with time_major=False) ->
-  (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout])."""
+  (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout]).
+  x_max: the largest input value expected (a hint, snnqp.h); x_seen: int32 device word that
+  receives the largest uint8 input value the launch met."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
@@ -517,7 +560,7 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
         _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
         _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
         _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
-        int(x_max), _stream()))
+        int(x_max), _ptr(x_seen), _stream()))
   return u_out, (PackedSpikes(s, geom.Cout) if packed_out else s)
 
 

@@ -302,7 +302,15 @@ class SpikingBlock(nn.Module):
       raise ValueError("QuantConv block expects [T, B, spatial..., C] inputs, got %s"
                        % (x.shape,))
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
-    x_max = ops.input_max_bound(x) if integer else 0
+    hint = None
+    if (integer and isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and cin == 2
+        and nsp == 2):
+      # the 2-channel event layer: the kernel checks its input itself and only wants to know
+      # what to expect -- no inspection pass, no read-back in front of the launch
+      hint = ops.count_hint(x.device)
+      x_max = hint.current()
+    else:
+      x_max = ops.input_max_bound(x) if integer else 0
     impl = self.impl
     if x_max > 127 and impl == L.IMPL_AUTO and cin != 2:
       impl = L.IMPL_GENERIC            # only the 2-channel event kernel takes counts > 127
@@ -323,18 +331,22 @@ class SpikingBlock(nn.Module):
       import dataclasses
       w = dataclasses.replace(w, min_current_bits=ops.current_min_bits(
           w, bn, int(w.abs_sum_max), geom.Cout))
+    x_seen = hint.word if hint is not None else None
     try:
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,
                                       pool=self.pool, impl=impl, time_major=tm,
-                                      x_max=x_max)
+                                      x_max=x_max, x_seen=x_seen)
     except L.SnnqpError as e:
       if e.code != L.EUNSUPPORTED or self.pool != 2 or impl == L.IMPL_MFMA:
         raise
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,
-                                      pool=1, impl=impl, time_major=tm, x_max=x_max)
+                                      pool=1, impl=impl, time_major=tm, x_max=x_max,
+                                      x_seen=x_seen)
       s = ops.maxpool2x2(s)
+    if hint is not None:
+      hint.launched()
     if nsp == 1:
       if isinstance(s, ops.PackedSpikes):
         s = s.reshape_leading(T, B, s.shape[3])

@@ -1424,6 +1424,55 @@ def test_work_queue_slots_with_many_launches_in_flight_and_graph_capture(dev, or
     np.testing.assert_array_equal(_np(out).view(np.uint32), e["pooled_bits"])
 
 
+def test_event_layer_checks_its_input_instead_of_trusting_the_hint(dev, oracle):
+  """conv0 (uint8 event frames, Cin = 2): `x_max` only says what the tables are sized for.
+  Binary frames with one hot pixel (count 200) and real count frames, launched with the
+  hint 1 (per-channel tables), with a hint in the shared-table range and with an exact one:
+  every result equals the oracle's (the chunks that exceed the hint run the general path),
+  and x_seen reports the largest value met.  Then through the model: the adaptive hint
+  (ops.count_hint) never makes the host wait and never changes a result."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.conv_block_case(T=9, B=5, hw=24, cin=2, seed=961, gain=4.0)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  bn, nrn = _bn(c["bn"], dev), _mslif()
+  g = ops.ConvGeom(24, 24, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  rng = np.random.Generator(np.random.PCG64(5))
+  binary = (rng.random((9, 5, 24, 24, 2)) < 0.1).astype(np.uint8)
+  hot = binary.copy()
+  hot[3, 2, 7, 11, 1] = 200                                   # one hot pixel in one patch
+  counts = np.minimum(rng.poisson(0.4, (9, 5, 24, 24, 2)), 255).astype(np.uint8)
+  for name, x in (("binary", binary), ("hot", hot), ("counts", counts)):
+    cc = dict(c, x=x)
+    e = cases.conv_block_expected(oracle, cc)
+    for hint in (1, 4, int(x.max())):
+      seen = torch.zeros(1, dtype=torch.int32, device=dev)
+      _, s = ops.conv_lif_forward(_t(x, dev), g, w, nrn, bn=bn, want_u=False, packed_out=True,
+                                  pool=2, impl=L.IMPL_MFMA, x_max=hint, x_seen=seen)
+      np.testing.assert_array_equal(_np(s), e["pooled_bits"], err_msg="%s hint %d" % (name, hint))
+      assert int(seen.item()) == int(x.max()), (name, hint)
+  # the model path: hints adapt from what the kernel reports, results never change
+  cm = cases.conv_net_case(counts=True)
+  em = cases.conv_net_expected(oracle, cm)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(cm["vars"], dev)
+  hint = ops.count_hint(dev)
+  for i in range(4):
+    (logits, _) = model.apply(variables, _t(cm["x"], dev), trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(logits), em["logits"])
+    torch.cuda.synchronize()
+  assert hint.current() == int(cm["x"].max()) > 1          # learnt without a blocking read
+  cb = cases.conv_net_case()
+  eb = cases.conv_net_expected(oracle, cb)
+  vb = nn.tree_from_numpy(cb["vars"], dev)
+  for i in range(3):                                         # back to binary frames
+    (logits, _) = model.apply(vb, _t(cb["x"], dev), trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(logits), eb["logits"])
+    torch.cuda.synchronize()
+  assert hint.current() == 1
+
+
 def test_eval_step_metrics(dev, oracle):
   from snnquantprune_amd import linen as nn
   from snnquantprune_amd import models, synthetic as syn, train_utils
