@@ -71,6 +71,11 @@ def parse(argv=None):
                   help="resident input dtype: uint8 event frames (default) or the float32 "
                        "frames the reference's pipeline hands over (inspected and narrowed "
                        "on device inside the step)")
+  ap.add_argument("--random-bn", action="store_true",
+                  help="BatchNorm with random running statistics / scale / bias (a trained "
+                       "model) instead of the freshly initialised one (mean 0, var 1, scale 1, "
+                       "bias 0) of a random-init model: the kernels then run all three "
+                       "BatchNorm instructions instead of the multiply alone")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--allow-diag", action="store_true",
@@ -294,10 +299,12 @@ def main(argv=None):
       cfg.quant.layer_bits = tuple(args.layer_bits)
     if args.model == "cextnet":
       model = models.CextNet(num_classes=args.classes, config=cfg)
-      variables_np = syn.cextnet_variables(prune_p=args.prune, out=args.classes * 10)
+      variables_np = syn.cextnet_variables(prune_p=args.prune, out=args.classes * 10,
+                                           random_bn=args.random_bn)
     else:
       model = models.ConvDenseSNN(num_classes=args.classes, config=cfg)
-      variables_np = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10)
+      variables_np = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10,
+                                            random_bn=args.random_bn)
     variables = nn.tree_from_numpy(variables_np, dev)
 
     def apply_fn(xb):
@@ -392,7 +399,9 @@ def main(argv=None):
                       "(f8f6f4 MFMA, sums < 2^24 exact) when the codes fit (<= 4 bits), else int8; "
                       "membrane potentials f32",
       "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
-              % args.lam + ", N(0,1/fan_in) weights, random seeds fixed",
+              % args.lam + ", N(0,1/fan_in) weights, " +
+              ("random BatchNorm statistics" if args.random_bn else "BatchNorm as initialised") +
+              ", random seeds fixed",
       "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
                               "qdense(2048->512->%d) + vote, " % (args.classes * 10)
                               if args.model == "cextnet" else

@@ -180,10 +180,18 @@ class ZeroCarry:
     return "ZeroCarry(shape=%s)" % (self.shape,)
 
 
+_flat_perm_cache = {}
+
+
 def _flat_perm(c, h, w, device):
-  """row_perm[k_nhwc] = k_channel_major for a [h, w, c] block flattened NHWC."""
-  idx = torch.arange(c * h * w, device=device).reshape(c, h, w)   # value = k_cm
-  return idx.permute(1, 2, 0).reshape(-1).contiguous()           # position = k_nhwc
+  """row_perm[k_nhwc] = k_channel_major for a [h, w, c] block flattened NHWC (built once per
+  shape and device: the read-out asks for it on every step)."""
+  key = (int(c), int(h), int(w), str(device))
+  perm = _flat_perm_cache.get(key)
+  if perm is None:
+    idx = torch.arange(c * h * w, device=device).reshape(c, h, w)   # value = k_cm
+    perm = _flat_perm_cache[key] = idx.permute(1, 2, 0).reshape(-1).contiguous()   # position = k_nhwc
+  return perm
 
 
 class SpikingBlock(nn.Module):
