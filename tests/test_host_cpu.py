@@ -427,3 +427,31 @@ def test_workload_tables_reproduce_the_reference_geometry_columns(tmp_path):
   m3, _ = sparsity.workload_tables(ls, acc, frames=20, channels=128, full=False)
   assert [l.split(",")[0] for l in m3[1:]] == ["Conv1", "Conv2", "Conv3", "Dense1"]
   assert m3[4].rstrip("\n").split(",", 4)[4] == "20,32768,110,1,1,1,1,1,1"
+
+
+def test_bench_roofline_block_from_recorded_launch_times():
+  """bench.py's roofline arithmetic on fixed per-kernel times (no GPU): achieved = algorithmic
+  ops / average launch duration of the dominant device function, frac against the peak of the
+  instruction it issues, the read-out's HBM ceiling, conv0's stated VALU-issue ceiling."""
+  sys.path.insert(0, ROOT)
+  import bench
+  args = bench.parse([])
+  prof = {"conv3x3[128x128x2->128]": (5, 5 * 6.0), "conv3x3[64x64x128->128]": (5, 5 * 5.5),
+          "conv3x3[32x32x128->128]": (5, 5 * 1.4), "dense[32768->110]": (5, 5 * 0.13)}
+  out = bench.rooflines_of(args, prof, 1024, 20, [4, 4, 4, 4])
+  r = out["roofline"]
+  assert r["kernel"] == "conv3x3_bits_kernel" and r["launches_per_step"] == 2 and r["bound"] == "mfma"
+  ops = (2 * 1024 * 20 * 64 * 64 * 128 * 1152 + 2 * 1024 * 20 * 32 * 32 * 128 * 1152) / 2
+  assert abs(r["achieved"] - ops / (3.45e-3) / 1e12) < 1e-6 * r["achieved"]
+  assert abs(r["frac"] - r["achieved"] / 10000.0) < 1e-12 and r["unit"] == "TFLOP/s"
+  assert r["algorithmic_bytes"] == (1024 * 20 * (65536 + 16384) + 1024 * 20 * (16384 + 4096)) / 2
+  d = out["roofline_dense"]
+  assert d["bound"] == "hbm" and 0.3 < d["ceiling_hbm_frac"] < 0.4 and d["frac"] < d["ceiling_hbm_frac"]
+  c0 = [x for x in out["rooflines"] if x["kernel"].startswith("conv3x3[128x128x2")][0]
+  assert 0.5 < c0["valu_issue"]["frac"] < 0.8 and "note" in c0
+  # 8-bit codes run on the int8 instruction: its peak, not the fp6 one
+  out8 = bench.rooflines_of(bench.parse(["--bits", "8"]), prof, 1024, 20, [8, 8, 8, 8])
+  assert out8["roofline"]["peak"] == 5000.0
+  # mixed precision: the peak is the time-weighted one of the launches
+  outm = bench.rooflines_of(bench.parse(["--layer-bits", "2,4,8,4"]), prof, 1024, 20, [2, 4, 8, 4])
+  assert 5000.0 < outm["roofline"]["peak"] < 10000.0
