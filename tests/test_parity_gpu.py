@@ -1473,6 +1473,96 @@ def test_event_layer_checks_its_input_instead_of_trusting_the_hint(dev, oracle):
   assert hint.current() == 1
 
 
+def test_random_blocks_against_the_oracle(dev, oracle):
+  """Randomised geometries against the ORACLE (tests/stress.py compares kernels with each
+  other; this one compares them with the restatement of the reference): 28 fused conv blocks
+  -- image sizes that clip patches, any Cin / Cout, event counts or spikes, 2..8-bit codes,
+  random BatchNorm (incl. zero mean and bias: the multiply-only form), every neuron form,
+  carried-in potentials, with and without the fused pool -- and 16 dense blocks; potentials
+  and rasters bit-exact."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(20261004))
+  kinds = ("ms2", "ms4", "ms3", "plif", "lif", "vr")
+
+  def neuron(kind, n):
+    if kind == "plif":
+      tp = F32(-0.35)
+      return (ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, float(oracle.sigmoid_f32(tp)), 1.0, 0.0),
+              {"kind": "parametric_leaky_IF", "tau_param": tp})
+    if kind == "lif":
+      tv = rng.uniform(-1, 2, n).astype(F32)
+      return (ops.Neuron(L.NEURON_LIF, 1.0, 1.0, 0.0, decay=_t(oracle.sigmoid_f32(tv), dev)),
+              {"kind": "LIF", "tau_vec": tv})
+    tau = {"ms2": 2.0, "ms4": 4.0, "ms3": 3.0, "vr": 2.0}[kind]
+    vr = 0.1 if kind == "vr" else 0.0
+    return (ops.Neuron(L.NEURON_MULTI_STEP_LIF, tau, 1.0, vr),
+            {"kind": "multi_step_LIF", "tau": tau, "v_reset": vr})
+
+  for it in range(28):
+    first = it % 3 == 0
+    cin = 2 if first else int(rng.integers(3, 129))
+    cout = int(rng.choice([32, 64, 100, 128, 160]))
+    H, W = int(rng.integers(3, 22)), int(rng.integers(3, 22))
+    T, B = int(rng.integers(1, 8)), int(rng.integers(1, 4))
+    bits = int(rng.choice([2, 3, 4, 8]))
+    pool = int(rng.choice([1, 2]))
+    if pool == 2:
+      H, W = H + (H & 1), W + (W & 1)
+    leaf = syn_leaf = None
+    from snnquantprune_amd import synthetic as syn
+    leaf = syn.quant_leaf((3, 3, cin, cout), float(rng.uniform(3, 7)), int(rng.integers(1 << 30)), True,
+                          float(rng.choice([0.0, 0.5, 0.9])))
+    zero_bn = rng.random() < 0.3
+    bn = dict(mean=np.zeros(cout, F32) if zero_bn else rng.normal(0, 0.2, cout).astype(F32),
+              var=rng.uniform(0.5, 1.5, cout).astype(F32), scale=rng.uniform(0.5, 1.5, cout).astype(F32),
+              bias=np.zeros(cout, F32) if zero_bn else rng.normal(0, 0.2, cout).astype(F32))
+    if first:
+      x = np.minimum(rng.poisson(float(rng.choice([0.15, 0.6])), (T, B, H, W, 2)), 255).astype(np.uint8)
+    else:
+      x = (rng.random((T, B, H, W, cin)) < 0.2).astype(np.uint8)
+    kind = kinds[it % len(kinds)]
+    nrn, ncfg = neuron(kind, cout)
+    u0 = (rng.normal(0, 0.3, (B, H, W, cout)).astype(F32)) if rng.random() < 0.3 else None
+    qw = qweight_of(oracle, leaf, bits)
+    ue, se = oracle.conv_block(x, qw, bn, ncfg, "int", u0=u0)
+    if pool == 2:
+      se = oracle.max_pool_2x2(se)
+    w = _weight(leaf, bits, dev, transposed=True)
+    mean, mul, bias = oracle.bn_coeffs(bn["mean"], bn["var"], bn["scale"], bn["bias"])
+    flags = (L.BN_MEAN_ZERO | L.BN_BIAS_ZERO) if zero_bn else 0
+    bnc = ops.BnCoeffs(_t(mean, dev), _t(mul, dev), _t(bias, dev), flags)
+    g = ops.ConvGeom(H, W, cin, cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+    xin = _t(x, dev) if first else ops.pack_bits(_t(x, dev))
+    tag = "it %d cin %d cout %d %dx%d T %d B %d bits %d pool %d %s bn0 %s u0 %s" % (
+        it, cin, cout, H, W, T, B, bits, pool, kind, zero_bn, u0 is not None)
+    u, s = ops.conv_lif_forward(xin, g, w, nrn, bn=bnc, u0=None if u0 is None else _t(u0, dev),
+                                packed_out=True, pool=pool, impl=L.IMPL_MFMA,
+                                x_max=int(x.max()) if first else 1)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(se), err_msg=tag)
+    np.testing.assert_array_equal(_np(u), ue, err_msg=tag)
+  for it in range(16):
+    K = int(rng.choice([rng.integers(1, 200), rng.integers(200, 3000), 512, 784]))
+    N = int(rng.choice([rng.integers(1, 40), 110, 100, rng.integers(100, 300)]))
+    T, B = int(rng.integers(1, 30)), int(rng.integers(1, 9))
+    bits = int(rng.choice([2, 3, 4, 8]))
+    from snnquantprune_amd import synthetic as syn
+    leaf = syn.quant_leaf((K, N), float(rng.uniform(2, 8)), int(rng.integers(1 << 30)), True,
+                          float(rng.choice([0.0, 0.5, 0.9])))
+    x = (rng.random((T, B, K)) < rng.uniform(0.02, 0.4)).astype(np.uint8)
+    kind = kinds[it % len(kinds)]
+    nrn, ncfg = neuron(kind, N)
+    u0 = (rng.normal(0, 0.3, (B, N)).astype(F32)) if rng.random() < 0.3 else None
+    ue, se = oracle.dense_block(x, qweight_of(oracle, leaf, bits), ncfg, "int", u0=u0)
+    w = _weight(leaf, bits, dev, transposed=True)
+    u, s = ops.dense_lif_forward(ops.pack_bits(_t(x, dev)), w, K, N, nrn,
+                                 u0=None if u0 is None else _t(u0, dev), packed_out=True,
+                                 impl=L.IMPL_MFMA)
+    tag = "dense it %d K %d N %d T %d B %d bits %d %s" % (it, K, N, T, B, bits, kind)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(se), err_msg=tag)
+    np.testing.assert_array_equal(_np(u), ue, err_msg=tag)
+
+
 def test_eval_step_metrics(dev, oracle):
   from snnquantprune_amd import linen as nn
   from snnquantprune_amd import models, synthetic as syn, train_utils
