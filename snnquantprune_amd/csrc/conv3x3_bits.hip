@@ -198,10 +198,11 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   lds_barrier();                                 // tables are visible
 
   PatchWalk pw(a);
-  int r = (int)pw.first;                 // patch indices fit 31 bits (launch check)
+  // patch indices fit 31 bits (launch check) and are workgroup-uniform: scalar registers
+  int r = __builtin_amdgcn_readfirstlane((int)pw.first);
   while (r < (int)pw.count) {
-    int r_next = r + (int)pw.stride;
-    if (pw.queue && tid == 0) r_next = (int)pw.claim(); // next patch, a patch ahead
+    int claimed = 0;
+    if (pw.queue && tid == 0) claimed = (int)pw.claim();   // next patch, a patch ahead
     int b, y0, x0;
     pw.decode(a, r, b, y0, x0);
 
@@ -442,6 +443,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       stage_write((uint32_t)HALO_B);
     }
     lds_barrier();
+    // (every wave has read the previous patch's claim: behind the barrier above)
+    if (pw.queue && tid == 0) nxt[0] = (uint32_t)claimed;
     {
       const uint32_t e0 = img_e(0), o0 = img_o(0), e1 = img_e(1), o1 = img_o(1);
 #pragma unroll
@@ -482,11 +485,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, done, a.T - done, b, y0, x0, tid);
     }
     if (a.u_out && wave_on) u_io_tile<false>(u, a, b, y0, x0, cout, h, 0);
-    if (pw.queue) {                      // the claimed patch, to the whole workgroup
-      if (tid == 0) nxt[0] = (uint32_t)r_next;
-      lds_barrier();
-      r_next = __builtin_amdgcn_readfirstlane((int)nxt[0]);
-    }
+    // the claimed patch: published behind this patch's barriers, and not overwritten before
+    // every wave has passed the next patch's first barrier
+    int r_next = r + (int)pw.stride;
+    if (pw.queue) r_next = __builtin_amdgcn_readfirstlane((int)nxt[0]);
     r = r_next;
   }
   if (pw.queue && tid == 0) pw.finish();

@@ -174,15 +174,20 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
   const bool store_lane = POOL ? lane < 8 : lane < 32;
   uint32_t seen = 0;                       // largest input value this thread's waves met
-  const bool s_task = tid < 2 * HALO * HALO;
-  const int s_half = tid >= HALO * HALO ? 1 : 0, s_pix = tid - s_half * HALO * HALO;
+  // staging tasks: waves 0-1 take the even timesteps of a chunk, waves 2-3 the odd ones; the
+  // first 100 threads of each pair take one halo pixel each.  The timestep is uniform over a
+  // wave, so a load is a scalar frame address plus this thread's 32-bit pixel offset.
+  const int s_pix = tid & 127;
+  const bool s_task = s_pix < HALO * HALO;
+  const int s_half = __builtin_amdgcn_readfirstlane(tid >> 7);
   const int s_dst = (s_pix / HALO) * HROW2 + (s_pix % HALO) * 2;
 
   PatchWalk pw(a);
-  int r = (int)pw.first;                 // patch indices fit 31 bits (launch check)
+  // patch indices fit 31 bits (launch check) and are workgroup-uniform: scalar registers
+  int r = __builtin_amdgcn_readfirstlane((int)pw.first);
   while (r < (int)pw.count) {
-    int r_next = r + (int)pw.stride;
-    if (pw.queue && tid == 0) r_next = (int)pw.claim(); // next patch, a patch ahead
+    int claimed = 0;
+    if (pw.queue && tid == 0) claimed = (int)pw.claim();   // next patch, a patch ahead
     int b, y0, x0;
     pw.decode(a, r, b, y0, x0);
 
@@ -190,10 +195,12 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
     else zero_u(u);
     uint32_t pseen = 0;                  // largest input value of this patch so far
-    // staging task: halo pixel tid % 100 of the timesteps of parity tid / 100
     const int s_gy = y0 + s_pix / HALO - 1, s_gx = x0 + s_pix % HALO - 1;
     const bool s_valid = s_task && s_gy >= 0 && s_gy < a.H && s_gx >= 0 && s_gx < a.W;
-    const uint8_t *s_src = xb + (int64_t)b * a.xs_b + ((int64_t)s_gy * a.W + s_gx) * 2;
+    // byte offset of the pixel within a frame (frames are below 2 GiB: launch check); threads
+    // without a pixel read the frame's first one and drop it
+    const uint32_t s_off = s_valid ? (uint32_t)(s_gy * a.W + s_gx) * 2u : 0u;
+    const uint8_t *s_frames = xb + (int64_t)b * a.xs_b;
 
     for (int t0 = 0; t0 < a.T; t0 += tc) {
       const int nt = min(tc, a.T - t0);
@@ -201,23 +208,25 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       // Thread = one halo pixel (both polarities: 2 bytes) of every other timestep: its only
       // per-patch state is one source pointer, so nothing else is live while the byte pairs
       // wait in registers for the workgroup to agree on the path.
-      uint16_t v[STG_N];
+      uint32_t v[STG_N];
       uint32_t mx = 0;
 #pragma unroll
-      for (int i = 0; i < STG_N; ++i) {    // all loads first
+      for (int i = 0; i < STG_N; ++i) {    // all loads first; the skip is a scalar branch
         const int tt = 2 * i + s_half;
         v[i] = 0;
-        if (s_valid && tt < nt) v[i] = *(const uint16_t *)(s_src + (int64_t)(t0 + tt) * a.xs_t);
+        if (tt < nt) v[i] = *(const uint16_t *)(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
       }
 #pragma unroll
-      for (int i = 0; i < STG_N; ++i)
-        mx = max(mx, max((uint32_t)(v[i] & 0xFFu), (uint32_t)(v[i] >> 8)));
+      for (int i = 0; i < STG_N; ++i) {
+        v[i] = s_valid ? v[i] : 0u;
+        mx = max(mx, max(v[i] & 0xFFu, v[i] >> 8));
+      }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
       lds_barrier();                       // previous readers of the LDS images are done
       if (lane == 0 && mx != 0) atomicMax(&wgw[1], mx);
       lds_barrier();
-      const uint32_t cmax = wgw[1];        // uniform: every wave reads the same word
+      const uint32_t cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wgw[1]);   // one word
       seen = max(seen, cmax);
       pseen = max(pseen, cmax);
       const bool general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
@@ -226,9 +235,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         for (int i = 0; i < STG_N; ++i) {
           const int tt = 2 * i + s_half;
           if (tt < nt) {    // table modes: both bytes scale without a carry (counts <= 31 / 7)
-            const uint16_t val = general               ? (uint16_t)(v[i] ^ 0x8080u)    // x - 128
-                                 : LUTM == LUT_CHANNEL ? (uint16_t)(v[i] << 4)
-                                                       : (uint16_t)(v[i] << 2);
+            const uint16_t val = (uint16_t)(general               ? v[i] ^ 0x8080u    // x - 128
+                                            : LUTM == LUT_CHANNEL ? v[i] << 4
+                                                                  : v[i] << 2);
             uint8_t *p = lds + tt * HIMG2 + s_dst;
             *(uint16_t *)p = val;
             *(uint16_t *)(p + HCOPY2 + 2) = val;
@@ -284,8 +293,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       }
     }
     if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
+    int r_next = r + (int)pw.stride;
     if (pw.queue) {                      // the claimed patch, to the whole workgroup
-      if (tid == 0) wgw[2] = (uint32_t)r_next;
+      if (tid == 0) wgw[2] = (uint32_t)claimed;
       lds_barrier();
       r_next = __builtin_amdgcn_readfirstlane((int)wgw[2]);
     }
@@ -416,6 +426,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
     if (g->Cin < 1 || g->Cin > 128) return "bit input needs Cin <= 128";
   } else if (in_type == SNNQP_U8) {     // any count 0..255 (taken as x - 128 without a table)
     if (g->Cin != 2) return "u8 input needs Cin == 2";
+    if ((int64_t)g->H * g->W * 2 >= (int64_t)1 << 31) return "u8 frame of 2 GiB or more";
   } else {
     return "input must be BITS or U8";
   }
