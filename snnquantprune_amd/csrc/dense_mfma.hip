@@ -93,76 +93,152 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   for (int r = 0; r < RT; ++r)
     acc[r] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  uint32_t stg[TPT];
-  auto stage_load = [&](int chunk) {
+  // Global loads run D - 1 chunks ahead of their use, in rings of D register sets (spike
+  // words and B fragments): a chunk of MFMAs is about 0.3 us of a wave, a loaded global round
+  // trip several times that -- with one chunk of lookahead the K loop ran at the pace of the
+  // memory latency, not of the matrix pipe or of LDS.
+  constexpr int D = 4;
+  constexpr int U = D % 2 ? 2 * D : D;             // unroll: ring slot i % D, LDS buffer i & 1
+  uint32_t stgr[D][TPT];
+  // staging tasks: word wi of row `row`, the same (row, wi) for every chunk.  The loads of the
+  // K loop are unconditional (clamped addresses, the value dropped afterwards): with loads
+  // under lane masks the compiler falls back to s_waitcnt vmcnt(0), which drains the ring.
+  int64_t roff[TPT];
+  uint32_t rmask[TPT];
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) {
-      const int task = tid + k * 256;
-      const int row = task / WPR, wi = task % WPR;
-      uint32_t wv = 0;
-      const int kw = (chunk * KGROUPS + grp) * WPR + wi;
-      if (task < NTASK && row < rows && kw < a.KS) {
-        const int bl = row / a.T, t = row - bl * a.T;
-        wv = a.x[(int64_t)t * a.xs_t + (int64_t)(b0 + bl) * a.xs_b + kw];
-      }
-      stg[k] = wv;
+  for (int k = 0; k < TPT; ++k) {
+    const int task = tid + k * 256;
+    const int row = task / WPR;
+    const bool live = task < NTASK && row < rows;
+    rmask[k] = live ? 0xFFFFFFFFu : 0u;
+    roff[k] = 0;
+    if (live) {
+      const int bl = row / a.T, t = row - bl * a.T;
+      roff[k] = (int64_t)t * a.xs_t + (int64_t)(b0 + bl) * a.xs_b;
     }
+  }
+  auto chunk_word = [&](int chunk, int k) { return (chunk * KGROUPS + grp) * WPR + (tid + k * 256) % WPR; };
+  auto stage_load = [&](uint32_t (&stg)[TPT], int chunk) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) stg[k] = a.x[roff[k] + min(chunk_word(chunk, k), a.KS - 1)];
   };
-  auto stage_store = [&](int buf) {
+  // the words of dead rows and of k beyond K are zeroed here, by masks (a select next to the
+  // load would put its wait there)
+  auto stage_store = [&](const uint32_t (&stg)[TPT], int chunk, int buf) {
     uint8_t *base = abuf + buf * ABYTES;
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
       const int task = tid + k * 256;
       if (task < NTASK) {
         const int row = task / WPR, wi = task % WPR;
-        *(v4i *)(base + a_addr(row, wi * 2)) = expand16b(stg[k] & 0xFFFFu);
-        *(v4i *)(base + a_addr(row, wi * 2 + 1)) = expand16b(stg[k] >> 16);
+        const uint32_t wv = stg[k] & rmask[k] & (uint32_t)((chunk_word(chunk, k) - a.KS) >> 31);
+        *(v4i *)(base + a_addr(row, wi * 2)) = expand16b(wv & 0xFFFFu);
+        *(v4i *)(base + a_addr(row, wi * 2 + 1)) = expand16b(wv >> 16);
       }
     }
   };
 
-  // B fragments of a whole chunk (KSC k-steps) are prefetched into registers one
-  // chunk ahead, next to the A words of that chunk: every global access of the K
-  // loop is issued a full chunk of MFMAs before its first use.
+  // B fragments of a whole chunk (KSC k-steps) are prefetched into registers next to the A
+  // words of that chunk
   const v4i *wtile = (const v4i *)a.wt + ((int64_t)(wave_on ? nb : 0) * a.KS) * 64 + lane;
-  v4i bfA[KSC], bfB[KSC];
+  v4i bfr[D][KSC];
   auto load_b = [&](v4i (&bf)[KSC], int chunk) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
-      const int kg = (chunk * KGROUPS + grp) * KSC + ks;
-      bf[ks] = kg < a.KS ? wtile[(int64_t)kg * 64] : v4i{0, 0, 0, 0};
+      // (k-steps beyond K meet zero A bytes: any codes do)
+      const int kg = min((chunk * KGROUPS + grp) * KSC + ks, a.KS - 1);
+      bf[ks] = wtile[(int64_t)kg * 64];
     }
   };
-  auto compute = [&](const uint8_t *base, const v4i (&bf)[KSC]) {
-    if (!wave_on) return;
+  // One chunk of the K loop, as NSLOT = KSC * RT slots: slot s issues MFMA s of chunk c, the
+  // A-fragment read of slot s + PF, and an even share of everything else the iteration has to
+  // do -- the global loads of chunk c + D - 1 and the expansion of the spike words of chunk
+  // c + 1 into the other LDS buffer (one dword of 4 bytes per piece: bit field, multiply, mask).
+  // Vector instructions only overlap the matrix pipe when the SAME wave issues them between
+  // its MFMAs: with the chunk as "all MFMAs, then all staging" the two never co-executed
+  // (SQ_VALU_MFMA_COEXEC_CYCLES 2 % of the MFMA-busy cycles, each of MFMA / VALU / LDS busy a
+  // third of the time), whichever way the two waves of a SIMD were phased.
+  constexpr int NSLOT = KSC * RT;
+  constexpr int PF = 3;                               // A fragments in flight
+  constexpr int NPIECE = TPT * 8;                     // dwords the thread expands per chunk
+  // loop-invariant LDS offsets: fragment reads (per k-step; row tile and buffer are immediates)
+  // and the two 16-byte stores of each staging task
+  int rd_off[KSC];
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks) {
+  for (int ks = 0; ks < KSC; ++ks) rd_off[ks] = a_addr(n, ks * 2 + h);
+  int wr_off[TPT][2];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const v4i av = *(const v4i *)(base + a_addr(r * 32 + n, ks * 2 + h));
-        acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bf[ks], acc[r], 0, 0, 0);
+  for (int k = 0; k < TPT; ++k) {
+    const int task = tid + k * 256;
+    const int row = task < NTASK ? task / WPR : 0, wi = task % WPR;
+    wr_off[k][0] = a_addr(row, wi * 2);
+    wr_off[k][1] = a_addr(row, wi * 2 + 1);
+  }
+  auto frag = [&](int rbuf, int s) -> v4i {
+    return *(const v4i *)(abuf + rbuf * ABYTES + (s % RT) * 32 * BK + rd_off[s / RT]);
+  };
+  auto fused_chunk = [&](int rbuf, const v4i (&bf)[KSC], uint32_t (&ld_stg)[TPT], v4i (&ld_bf)[KSC],
+                         int ld_chunk, const uint32_t (&st_stg)[TPT], int st_chunk) {
+    v4i av[PF + 1];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) av[s] = frag(rbuf, s);
+    uint32_t wv[TPT];
+#pragma unroll
+    for (int k = 0; k < TPT; ++k)
+      wv[k] = st_stg[k] & rmask[k] & (uint32_t)((chunk_word(st_chunk, k) - a.KS) >> 31);
+    v4i ex = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      // (a wave beyond N multiplies block 0's codes into accumulators nobody reads)
+      acc[s % RT] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s % (PF + 1)], bf[s / RT], acc[s % RT], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PF < NSLOT) av[(s + PF) % (PF + 1)] = frag(rbuf, s + PF);
+      // global loads of the chunk D - 1 ahead: one B fragment per row-tile round, the spike
+      // words in the first slots
+      if (s % RT == 0) {
+        const int ks = s / RT;
+        const int kg = min((ld_chunk * KGROUPS + grp) * KSC + ks, a.KS - 1);
+        ld_bf[ks] = wtile[(int64_t)kg * 64];
       }
+      if (s % KSC == 1 && s / KSC < TPT) {
+        const int k = s / KSC;
+        ld_stg[k] = a.x[roff[k] + min(chunk_word(ld_chunk, k), a.KS - 1)];
+      }
+      // expansion pieces p with p * NSLOT / NPIECE == s
+#pragma unroll
+      for (int p = 0; p < NPIECE; ++p) {
+        if (p * NSLOT / NPIECE == s) {
+          const int k = p / 8, hf = (p / 4) & 1, d = p & 3;
+          // the word passes through an empty volatile asm in every slot that expands a piece
+          // of it: the piece cannot be computed before its slot (sched_barrier alone orders
+          // instructions, not the values they were selected from)
+          asm volatile("" : "+v"(wv[k]));
+          ex[d] = (int)((((wv[k] >> (16 * hf + 4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u);
+          if (d == 3 && tid + k * 256 < NTASK)
+            *(v4i *)(abuf + (rbuf ^ 1) * ABYTES + wr_off[k][hf]) = ex;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  stage_load(0);
-  load_b(bfA, 0);
-  stage_store(0);
+  // chunks beyond K contribute zero A bytes (any codes do), so the loop runs over groups of U
+  // chunks without a tail case
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+    stage_load(stgr[d], d);
+    load_b(bfr[d], d);
+  }
+  stage_store(stgr[0], 0, 0);
   lds_barrier();
-  // chunks beyond K contribute zero B fragments and zero A bytes, so the loop
-  // runs over pairs of chunks without a tail case
   const int ngc = (nchunks + KGROUPS - 1) / KGROUPS;     // chunks per group
-  for (int c = 0; c < ngc; c += 2) {
-    stage_load(c + 1);
-    load_b(bfB, c + 1);
-    compute(abuf, bfA);
-    stage_store(1);
-    lds_barrier();
-    stage_load(c + 2);
-    load_b(bfA, c + 2);
-    compute(abuf + ABYTES, bfB);
-    stage_store(0);
-    lds_barrier();
+  for (int c = 0; c < ngc; c += U) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {                        // chunk c + i: ring slot i % D, LDS buffer i & 1
+      fused_chunk(i & 1, bfr[i % D], stgr[(i + D - 1) % D], bfr[(i + D - 1) % D], c + i + D - 1,
+                  stgr[(i + 1) % D], c + i + 1);
+      lds_barrier();
+    }
   }
 
   // int32 tile -> LDS [row][128]; C/D layout: col = lane & 31,
@@ -244,7 +320,7 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
                         "batch-norm descriptor with null arrays");
   if (T == 0 || B == 0) return SNNQP_OK;
-  SNNQP_REQUIRE(T <= 160, SNNQP_EUNSUPPORTED, "dense mfma: T > 160");
+  SNNQP_REQUIRE(T <= 96, SNNQP_EUNSUPPORTED, "dense mfma: T > 96");
   DenseMfmaArgs a;
   a.x = (const uint32_t *)x; a.xs_t = xs_t; a.xs_b = xs_b;
   a.T = T; a.B = B; a.K = K; a.N = N; a.KS = (K + 31) / 32;
@@ -255,9 +331,9 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   const unsigned gy = (unsigned)((N + 127) / 128);
   // largest row tile that still gives the chip enough workgroups, else the
   // smallest one that holds a whole sample (most workgroups)
-  static const int rts[4] = {5, 3, 2, 1};
+  static const int rts[3] = {3, 2, 1};
   int rt = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 3; ++i) {
     const int sb = rts[i] * 32 / T;
     if (sb < 1) continue;
     rt = rts[i];
@@ -267,7 +343,6 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   a.SB = rt * 32 / T;
   const unsigned gx = (unsigned)((B + a.SB - 1) / a.SB);
   switch (rt) {
-    case 5: launch_dense<5>(a, gx, gy, st); break;
     case 3: launch_dense<3>(a, gx, gy, st); break;
     case 2: launch_dense<2>(a, gx, gy, st); break;
     default: launch_dense<1>(a, gx, gy, st); break;

@@ -336,8 +336,79 @@ def test_dense_block_mfma(dev, oracle, shape):
     np.testing.assert_array_equal(_np(ua), _np(ub))
 
 
+@pytest.mark.parametrize("shape", [(20, 40, 4100, 110, False), (7, 100, 8192, 200, True),
+                                   (170, 4, 4096, 33, False), (20, 64, 32768, 110, True)],
+                         ids=["odd_k_odd_chunks", "ragged_rows_two_col_blocks_bn", "long_t",
+                              "readout_shape_bn"])
+def test_dense_block_split_k(dev, oracle, shape):
+  """Long contractions: the split-K GEMM + neuron kernels over the caller's workspace
+  (dense_splitk.hip) against the oracle, the fused MFMA kernel and the direct-form kernel --
+  rasters and final potentials bit-exact; rows that do not fill a 160-row tile, K that is
+  neither a multiple of 32 nor of the chunk pairs, N beyond one 128-feature block, T > 96
+  (which the fused kernel cannot hold), BatchNorm, a carry, batch-major input, every neuron."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, K, N, with_bn = shape
+  assert L.lib().snnqp_dense_workspace_bytes(T, B, K, N) > 0
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N, bits=4, p=0.8)
+  qw = qweight_of(oracle, c["leaf"], 4)
+  rng = np.random.Generator(np.random.PCG64(4100 + T))
+  bn = None
+  if with_bn:
+    bn = {"scale": (1 + 0.2 * rng.standard_normal(N)).astype(F32), "bias": (0.1 * rng.standard_normal(N)).astype(F32),
+          "mean": (0.1 * rng.standard_normal(N)).astype(F32), "var": (1 + 0.3 * rng.random(N)).astype(F32)}
+  if bn:      # the oracle's dense block has no norm: the same layer as a 1x1 convolution block
+    leaf4 = {"kernel": c["leaf"]["kernel"].reshape(1, 1, K, N), "DuQ_0": c["leaf"]["DuQ_0"],
+             "prune_0": {"mask": c["leaf"]["prune_0"]["mask"].reshape(1, 1, K, N)}}
+    eu, es = oracle.conv_block(c["x"].reshape(T, B, 1, 1, K), qweight_of(oracle, leaf4, 4), bn, None,
+                               "int", padding=((0, 0), (0, 0)), u0=c["u0"].reshape(B, 1, 1, N))
+    eu, es = eu.reshape(B, N), es.reshape(T, B, N)
+  else:
+    eu, es = oracle.dense_block(c["x"], qw, None, "int", u0=c["u0"])
+  assert 0.01 < es.mean() < 0.6
+  w = _weight(c["leaf"], 4, dev, transposed=True)
+  x = ops.pack_bits(_t(c["x"], dev))
+  u0 = _t(c["u0"], dev)
+  bnc = _bn(bn, dev) if bn else None
+  u, s = ops.dense_lif_forward(x, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+  # the other kernels of the library on the same block
+  ug, sg = ops.dense_lif_forward(x, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True, impl=L.IMPL_GENERIC)
+  np.testing.assert_array_equal(_np(s), _np(sg))
+  np.testing.assert_array_equal(_np(u), _np(ug))
+  if T <= 96:
+    uf, sf = ops.dense_lif_forward(x, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True,
+                                   impl=L.IMPL_MFMA, workspace=False)
+    np.testing.assert_array_equal(_np(s), _np(sf))
+    np.testing.assert_array_equal(_np(u), _np(uf))
+  xb = ops.pack_bits(_t(np.ascontiguousarray(np.swapaxes(c["x"], 0, 1)), dev))
+  ub, sb = ops.dense_lif_forward(xb, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True,
+                                 impl=L.IMPL_MFMA, time_major=False)
+  np.testing.assert_array_equal(_np(sb), _np(s))
+  np.testing.assert_array_equal(_np(ub), _np(u))
+  for nrn in (ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, 0.8, 0.1),
+              ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, 0.3, 1.0, 0.0),
+              ops.Neuron(L.NEURON_LIF, 0.0, 1.0, 0.0,
+                         decay=_t(np.linspace(0.2, 0.9, N).astype(F32), dev))):
+    ua, sa = ops.dense_lif_forward(x, w, K, N, nrn, packed_out=True, impl=L.IMPL_MFMA)
+    ub, sb = ops.dense_lif_forward(x, w, K, N, nrn, packed_out=True, impl=L.IMPL_GENERIC)
+    np.testing.assert_array_equal(_np(sa), _np(sb))
+    np.testing.assert_array_equal(_np(ua), _np(ub))
+  # a workspace that is too small is refused, not overrun
+  small = torch.empty(1024, dtype=torch.uint8, device=dev)
+  n_, w_ = _mslif().struct(), w.struct()
+  import ctypes
+  rc = L.lib().snnqp_dense_lif_forward_ws(
+      ctypes.c_void_p(x.bits.data_ptr()), L.BITS, x.bits.stride(0), x.bits.stride(1), T, B, K, N,
+      ctypes.byref(w_), ctypes.c_void_p(w.wt.data_ptr()), None, ctypes.byref(n_), None, None,
+      ctypes.c_void_p(s.bits.data_ptr()), L.BITS, L.IMPL_MFMA, ctypes.c_void_p(small.data_ptr()), 1024,
+      None)
+  assert rc == L.EINVAL and "workspace" in L.lib().snnqp_last_error().decode()
+
+
 def test_dense_block_long_T_falls_back(dev, oracle):
-  """More timesteps than the MFMA dense kernel's row tile holds (T > 160): the block
+  """More timesteps than the MFMA dense kernel's row tile holds (T > 96): the block
   runs on the direct-form kernel instead of failing."""
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
