@@ -247,8 +247,7 @@ int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bou
  * IMPL_MFMA additionally needs `wt`: the int8 codes tiled by
  * snnqp_pack_codes_mfma (Npad = N rounded up to 32; K rows zero-padded to a multiple
  * of 32 when K is not one), BITS input (zero bits beyond K),
- * T <= 96 (longer runs: the workspace form below when K is long, else the direct-form
- * kernel), s_type BITS. */
+ * T <= 96 (longer runs: the direct-form kernel), s_type BITS. */
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,
@@ -256,23 +255,6 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             const snnqp_neuron_t *nrn, const float *u0,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream);
-
-/* The same block with a caller-owned scratch buffer (the library allocates nothing).  A long
- * contraction over many rows (the read-out of the conv nets: K = 32768, T * B = 20480) runs
- * as a split-K int8-MFMA GEMM over all (sample, t) rows into `ws`, then one neuron kernel
- * (dense_splitk.hip); results are bit-identical to snnqp_dense_lif_forward, which is this
- * call with ws = NULL.  snnqp_dense_workspace_bytes gives the size `ws` must have for a
- * shape (device memory, 16-byte aligned, contents irrelevant before and after the call; 0 =
- * the shape does not use one and ws may be NULL).  A workspace must not be shared by calls
- * that can run concurrently on different streams. */
-int64_t snnqp_dense_workspace_bytes(int32_t T, int32_t B, int32_t K, int32_t N);
-int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
-                               int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
-                               int32_t N, const snnqp_weight_t *w,
-                               const int8_t *wt, const snnqp_bn_t *bn,
-                               const snnqp_neuron_t *nrn, const float *u0,
-                               float *u_out, void *s_out, int s_type, int impl,
-                               void *ws, int64_t ws_bytes, snnqp_stream_t stream);
 
 /* ---- element-wise pieces ----------------------------------------------------
  * replaces: neural_dynamics(u, x) scanned over T, spiking_learning.py:460

@@ -42,10 +42,6 @@ int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bou
   return run_current_min(w, bn, bound, Cout, out_bits, (hipStream_t)stream);
 }
 
-int64_t snnqp_dense_workspace_bytes(int32_t T, int32_t B, int32_t K, int32_t N) {
-  return dense_splitk_workspace_bytes(T, B, K, N);
-}
-
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,
@@ -53,17 +49,6 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             const snnqp_neuron_t *nrn, const float *u0,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream) {
-  return snnqp_dense_lif_forward_ws(x, in_type, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn,
-                                    nrn, u0, u_out, s_out, s_type, impl, nullptr, 0, stream);
-}
-
-int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
-                               int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
-                               int32_t N, const snnqp_weight_t *w,
-                               const int8_t *wt, const snnqp_bn_t *bn,
-                               const snnqp_neuron_t *nrn, const float *u0,
-                               float *u_out, void *s_out, int s_type, int impl,
-                               void *ws, int64_t ws_bytes, snnqp_stream_t stream) {
   SNNQP_REQUIRE(w && nrn, SNNQP_EINVAL, "dense_lif_forward: null descriptor");
   SNNQP_REQUIRE(K > 0 && N > 0, SNNQP_EINVAL, "dense_lif_forward: bad K/N");
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
@@ -71,21 +56,13 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
                 SNNQP_EINVAL, "dense_lif_forward: unknown neuron kind %d", nrn->kind);
   SNNQP_REQUIRE(impl >= SNNQP_IMPL_AUTO && impl <= SNNQP_IMPL_MFMA, SNNQP_EINVAL,
                 "dense_lif_forward: unknown impl %d", impl);
-  SNNQP_REQUIRE(ws_bytes >= 0 && (ws || ws_bytes == 0), SNNQP_EINVAL,
-                "dense_lif_forward: workspace size without a workspace");
   const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
-  // long contractions over many rows: split-K GEMM + neuron kernel through the workspace
-  if (!why && impl != SNNQP_IMPL_GENERIC && ws && T > 0 && B > 0) {
-    const int64_t need = dense_splitk_workspace_bytes(T, B, K, N);
-    if (need > 0) {
-      SNNQP_REQUIRE(ws_bytes >= need, SNNQP_EINVAL,
-                    "dense_lif_forward: workspace of %lld bytes, snnqp_dense_workspace_bytes says %lld",
-                    (long long)ws_bytes, (long long)need);
-      return run_dense_splitk(x, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn, u0, u_out,
-                              (uint32_t *)s_out, ws, ws_bytes, (hipStream_t)stream);
-    }
-  }
   if (!why && T > 96) why = "more than 96 timesteps (one sample must fit a row tile)";
+  // the fused kernel addresses the rows of one workgroup (at most 96 samples) with 32-bit
+  // word offsets from the workgroup's first sample
+  if (!why && ((int64_t)(T > 0 ? T - 1 : 0) * x_stride_t + 96 * x_stride_b + (K + 31) / 32 >= ((int64_t)1 << 31) ||
+               x_stride_t < 0 || x_stride_b < 0))
+    why = "input strides beyond 32-bit word offsets within a workgroup";
   if (impl == SNNQP_IMPL_MFMA)
     SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "dense_lif_forward: MFMA kernel: %s", why);
   if (!why && impl != SNNQP_IMPL_GENERIC)

@@ -77,8 +77,10 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   constexpr int LDSB = (2 * KGROUPS * ABYTES > EBYTES) ? 2 * KGROUPS * ABYTES : EBYTES;
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDSB];
 
-  const int grp = threadIdx.x >> 8;              // K group of this wave
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  // (group and wave indices in scalar registers: so are the addresses of the B fragments)
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // K group of this wave
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint8_t *abuf = lds + grp * 2 * ABYTES;
   const int n = lane & 31, h = lane >> 5;
   const int b0 = blockIdx.x * a.SB;
@@ -103,8 +105,9 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   // staging tasks: word wi of row `row`, the same (row, wi) for every chunk.  The loads of the
   // K loop are unconditional (clamped addresses, the value dropped afterwards): with loads
   // under lane masks the compiler falls back to s_waitcnt vmcnt(0), which drains the ring.
-  int64_t roff[TPT];
+  uint32_t roff[TPT];                              // word offset within this workgroup's samples
   uint32_t rmask[TPT];
+  const uint32_t *xw = a.x + (int64_t)b0 * a.xs_b;
 #pragma unroll
   for (int k = 0; k < TPT; ++k) {
     const int task = tid + k * 256;
@@ -114,13 +117,13 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     roff[k] = 0;
     if (live) {
       const int bl = row / a.T, t = row - bl * a.T;
-      roff[k] = (int64_t)t * a.xs_t + (int64_t)(b0 + bl) * a.xs_b;
+      roff[k] = (uint32_t)((int64_t)t * a.xs_t + (int64_t)bl * a.xs_b);   // < 2^31: launch check
     }
   }
   auto chunk_word = [&](int chunk, int k) { return (chunk * KGROUPS + grp) * WPR + (tid + k * 256) % WPR; };
   auto stage_load = [&](uint32_t (&stg)[TPT], int chunk) {
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) stg[k] = a.x[roff[k] + min(chunk_word(chunk, k), a.KS - 1)];
+    for (int k = 0; k < TPT; ++k) stg[k] = xw[roff[k] + (uint32_t)min(chunk_word(chunk, k), a.KS - 1)];
   };
   // the words of dead rows and of k beyond K are zeroed here, by masks (a select next to the
   // load would put its wait there)
@@ -140,14 +143,14 @@ dense_mfma_kernel(DenseMfmaArgs a) {
 
   // B fragments of a whole chunk (KSC k-steps) are prefetched into registers next to the A
   // words of that chunk
-  const v4i *wtile = (const v4i *)a.wt + ((int64_t)(wave_on ? nb : 0) * a.KS) * 64 + lane;
+  const v4i *wtile = (const v4i *)a.wt + ((int64_t)(wave_on ? nb : 0) * a.KS) * 64;   // wave-uniform
   v4i bfr[D][KSC];
   auto load_b = [&](v4i (&bf)[KSC], int chunk) {
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
       // (k-steps beyond K meet zero A bytes: any codes do)
       const int kg = min((chunk * KGROUPS + grp) * KSC + ks, a.KS - 1);
-      bf[ks] = wtile[(int64_t)kg * 64];
+      bf[ks] = (wtile + (int64_t)kg * 64)[lane];
     }
   };
   // One chunk of the K loop, as NSLOT = KSC * RT slots: slot s issues MFMA s of chunk c, the
@@ -198,11 +201,11 @@ dense_mfma_kernel(DenseMfmaArgs a) {
       if (s % RT == 0) {
         const int ks = s / RT;
         const int kg = min((ld_chunk * KGROUPS + grp) * KSC + ks, a.KS - 1);
-        ld_bf[ks] = wtile[(int64_t)kg * 64];
+        ld_bf[ks] = (wtile + (int64_t)kg * 64)[lane];
       }
       if (s % KSC == 1 && s / KSC < TPT) {
         const int k = s / KSC;
-        ld_stg[k] = a.x[roff[k] + min(chunk_word(ld_chunk, k), a.KS - 1)];
+        ld_stg[k] = xw[roff[k] + (uint32_t)min(chunk_word(ld_chunk, k), a.KS - 1)];
       }
       // expansion pieces p with p * NSLOT / NPIECE == s
 #pragma unroll

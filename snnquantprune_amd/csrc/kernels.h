@@ -37,13 +37,4 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, hipStream_t st);
 
-// long contractions: split-K GEMM + neuron kernel over a caller-owned workspace
-// (dense_splitk.hip); 0 bytes = this shape is served by the fused kernel
-int64_t dense_splitk_workspace_bytes(int32_t T, int32_t B, int32_t K, int32_t N);
-int run_dense_splitk(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
-                     int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
-                     const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
-                     float *u_out, uint32_t *s_out, void *ws, int64_t ws_bytes,
-                     hipStream_t st);
-
 }  // namespace snnqp

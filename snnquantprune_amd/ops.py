@@ -564,30 +564,11 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
   return u_out, (PackedSpikes(s, geom.Cout) if packed_out else s)
 
 
-_dense_ws = {}     # (device index, stream) -> scratch tensor of the split-K read-out
-
-
-def _dense_workspace(dev, nbytes: int):
-  """Scratch for snnqp_dense_lif_forward_ws: one buffer per (device, stream), grown on demand;
-  calls on one stream are ordered, so they may share it."""
-  if nbytes <= 0:
-    return None
-  key = (dev.index if dev.index is not None else torch.cuda.current_device(),
-         int(torch.cuda.current_stream().cuda_stream))
-  ws = _dense_ws.get(key)
-  if ws is None or ws.numel() < nbytes:
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _dense_ws[key] = ws
-  return ws
-
-
 def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
                       bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
                       want_u: bool = True, packed_out: bool = False,
-                      impl: int = L.IMPL_AUTO, time_major: bool = True,
-                      workspace: bool = True):
-  """x [T, B, K] -> (u_T [B, N] | None, spikes [T, B, N]).  `workspace`: give the library the
-  scratch buffer it asks for (long contractions then run as split-K GEMM + neuron kernel)."""
+                      impl: int = L.IMPL_AUTO, time_major: bool = True):
+  """x [T, B, K] -> (u_T [B, N] | None, spikes [T, B, N])."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
@@ -604,16 +585,11 @@ def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
     s = torch.empty((T, B, N), dtype=torch.float32, device=dev)
   w, n = weight.struct(), neuron.struct()
   b = bn.struct() if bn is not None else None
-  ws = None
-  if (workspace and in_type == L.BITS and packed_out and weight.wt is not None
-      and impl != L.IMPL_GENERIC):
-    ws = _dense_workspace(dev, int(L.lib().snnqp_dense_workspace_bytes(T, B, K, N)))
   with _timed("dense[%d->%d]" % (K, N)):
-    L.check(L.lib().snnqp_dense_lif_forward_ws(
+    L.check(L.lib().snnqp_dense_lif_forward(
         _ptr(xt), in_type, xs_t, xs_b, T, B, K, N, ctypes.byref(w), _ptr(weight.wt),
         ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0),
-        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl,
-        _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl, _stream()))
   return u_out, (PackedSpikes(s, N) if packed_out else s)
 
 

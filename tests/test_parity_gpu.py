@@ -337,19 +337,18 @@ def test_dense_block_mfma(dev, oracle, shape):
 
 
 @pytest.mark.parametrize("shape", [(20, 40, 4100, 110, False), (7, 100, 8192, 200, True),
-                                   (170, 4, 4096, 33, False), (20, 64, 32768, 110, True)],
+                                   (90, 4, 4096, 33, False), (20, 64, 32768, 110, True)],
                          ids=["odd_k_odd_chunks", "ragged_rows_two_col_blocks_bn", "long_t",
                               "readout_shape_bn"])
-def test_dense_block_split_k(dev, oracle, shape):
-  """Long contractions: the split-K GEMM + neuron kernels over the caller's workspace
-  (dense_splitk.hip) against the oracle, the fused MFMA kernel and the direct-form kernel --
-  rasters and final potentials bit-exact; rows that do not fill a 160-row tile, K that is
-  neither a multiple of 32 nor of the chunk pairs, N beyond one 128-feature block, T > 96
-  (which the fused kernel cannot hold), BatchNorm, a carry, batch-major input, every neuron."""
+def test_dense_block_long_contractions(dev, oracle, shape):
+  """Long contractions on the fused MFMA dense kernel (register rings several chunks deep,
+  staging interleaved with the MFMAs) against the oracle and the direct-form kernel --
+  rasters and final potentials bit-exact; K that is neither a multiple of 32 nor of the
+  chunk groups, rows that do not fill the row tile, N beyond one 128-feature block, a sample
+  that nearly fills the tile (T = 90), BatchNorm, a carry, batch-major input, every neuron."""
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
   T, B, K, N, with_bn = shape
-  assert L.lib().snnqp_dense_workspace_bytes(T, B, K, N) > 0
   c = cases.dense_block_case(T=T, B=B, K=K, N=N, bits=4, p=0.8)
   qw = qweight_of(oracle, c["leaf"], 4)
   rng = np.random.Generator(np.random.PCG64(4100 + T))
@@ -373,15 +372,9 @@ def test_dense_block_split_k(dev, oracle, shape):
   u, s = ops.dense_lif_forward(x, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True, impl=L.IMPL_MFMA)
   np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
   np.testing.assert_array_equal(_np(u), eu)
-  # the other kernels of the library on the same block
   ug, sg = ops.dense_lif_forward(x, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True, impl=L.IMPL_GENERIC)
   np.testing.assert_array_equal(_np(s), _np(sg))
   np.testing.assert_array_equal(_np(u), _np(ug))
-  if T <= 96:
-    uf, sf = ops.dense_lif_forward(x, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True,
-                                   impl=L.IMPL_MFMA, workspace=False)
-    np.testing.assert_array_equal(_np(s), _np(sf))
-    np.testing.assert_array_equal(_np(u), _np(uf))
   xb = ops.pack_bits(_t(np.ascontiguousarray(np.swapaxes(c["x"], 0, 1)), dev))
   ub, sb = ops.dense_lif_forward(xb, w, K, N, _mslif(), bn=bnc, u0=u0, packed_out=True,
                                  impl=L.IMPL_MFMA, time_major=False)
@@ -395,16 +388,6 @@ def test_dense_block_split_k(dev, oracle, shape):
     ub, sb = ops.dense_lif_forward(x, w, K, N, nrn, packed_out=True, impl=L.IMPL_GENERIC)
     np.testing.assert_array_equal(_np(sa), _np(sb))
     np.testing.assert_array_equal(_np(ua), _np(ub))
-  # a workspace that is too small is refused, not overrun
-  small = torch.empty(1024, dtype=torch.uint8, device=dev)
-  n_, w_ = _mslif().struct(), w.struct()
-  import ctypes
-  rc = L.lib().snnqp_dense_lif_forward_ws(
-      ctypes.c_void_p(x.bits.data_ptr()), L.BITS, x.bits.stride(0), x.bits.stride(1), T, B, K, N,
-      ctypes.byref(w_), ctypes.c_void_p(w.wt.data_ptr()), None, ctypes.byref(n_), None, None,
-      ctypes.c_void_p(s.bits.data_ptr()), L.BITS, L.IMPL_MFMA, ctypes.c_void_p(small.data_ptr()), 1024,
-      None)
-  assert rc == L.EINVAL and "workspace" in L.lib().snnqp_last_error().decode()
 
 
 def test_dense_block_long_T_falls_back(dev, oracle):
