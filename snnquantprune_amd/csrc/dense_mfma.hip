@@ -6,15 +6,17 @@
 // rows m = (sample, t); only the neuron is sequential:
 //  * a workgroup owns SB samples x all T steps (<= RT*32 rows) and a block of 128
 //    output features; it is 8 waves = two groups of 4 (32 features per wave) that
-//    split K: group g walks the chunks c = g (mod 2) with its own LDS buffers, so
-//    twice the global loads are in flight (the K loop is latency-bound: one chunk
-//    of prefetch per wave) and the int32 partial tiles are added once at the end;
+//    split K: group g walks the chunks c = g (mod 2) with its own LDS buffers, and the
+//    int32 partial tiles are added once at the end;
 //  * K is walked in chunks of 256: the rows' spike bits are expanded to {0,1}
 //    bytes in LDS (row stride 256 B, 16-byte chunks XOR-swizzled by row so the
 //    ds_read_b128 of an A fragment is conflict-free); the B fragments stream
 //    from the MFMA-tiled codes (snnqp_pack_codes_mfma: one contiguous 1 KiB
 //    read per wave and k-step) straight into registers and are reused by the
-//    RT row tiles;
+//    RT row tiles; spike words and B fragments are requested three chunks ahead of
+//    their use (register rings, counted s_waitcnt), and inside a chunk every wave
+//    interleaves its MFMAs with its share of the loads and of the next chunk's
+//    expansion, slot by slot (fused_chunk);
 //  * after the K loop the int32 tile goes through LDS once so that each thread
 //    gets the T currents of one (sample, feature) pair in order, runs the
 //    neuron with u in a register and ballots the spikes into 32-bit words.
