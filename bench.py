@@ -64,7 +64,7 @@ def parse(argv=None):
   ap.add_argument("--counts", action="store_true",
                   help="event COUNT frames, Poisson(lam) per pixel and polarity as the reference's "
                        "preprocessing produces them (input_pipeline.py:195-218), instead of binary")
-  ap.add_argument("--model", choices=("c3", "cextnet"), default="c3",
+  ap.add_argument("--model", choices=("c3", "cextnet", "dense"), default="c3",
                   help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
                        "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
   ap.add_argument("--input", choices=("u8", "f32"), default="u8",
@@ -78,6 +78,10 @@ def parse(argv=None):
                        "BatchNorm instructions instead of the multiply alone")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--graph", action="store_true",
+                  help="capture model.apply into a hipGraph after the warm-up and replay it in the "
+                       "timed steps (for launch-bound configurations such as --model dense; the "
+                       "per-kernel times then come from the eager warm-up steps)")
   ap.add_argument("--allow-diag", action="store_true",
                   help="accept a diagnostic libsnnqp (SNNQP_DIAG_LIB); the line is marked")
   # test plumbing: the same step / fence / all-reduce code on CPU tensors over gloo with a
@@ -97,6 +101,9 @@ def layer_bits(args):
 
 
 def metric_name(args):
+  if args.model == "dense":
+    return "samples/sec/node (2-layer qdense 2048-512-%d, T=%d, %d-bit/%.4g%%-pruned)" % (
+        args.classes * 10, args.frames, args.bits, args.prune * 100)
   lb = layer_bits(args)
   bits = "%d-bit" % lb[0] if len(set(lb)) == 1 else "mixed %s-bit" % "/".join(
       str(b) for b in sorted(set(lb)))
@@ -301,6 +308,10 @@ def main(argv=None):
       model = models.CextNet(num_classes=args.classes, config=cfg)
       variables_np = syn.cextnet_variables(prune_p=args.prune, out=args.classes * 10,
                                            random_bn=args.random_bn)
+    elif args.model == "dense":     # BASELINE config C2: the head of CextNet on its own
+      cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune, hidden=512)
+      model = models.DenseSNN(num_classes=args.classes, config=cfg)
+      variables_np = syn.dense_net_variables(2048, 512, args.classes * 10, True, args.prune)
     else:
       model = models.ConvDenseSNN(num_classes=args.classes, config=cfg)
       variables_np = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10,
@@ -316,7 +327,9 @@ def main(argv=None):
   gen = torch.Generator(device=dev)
   gen.manual_seed(8627169 + rank)
   p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
-  if args.counts:
+  if args.model == "dense":                      # [B, T, 2048] binary spikes
+    x = (torch.rand((B, T, 2048), device=dev, generator=gen) < p_spike).to(torch.uint8)
+  elif args.counts:
     x = torch.poisson(torch.full((B, T, hw, hw, 2), float(args.lam), device=dev),
                       generator=gen).clamp_(max=255).to(torch.uint8)
   else:
@@ -350,12 +363,28 @@ def main(argv=None):
   if ops is not None:
     ops.profile_start()
   out = None
-  for _ in range(args.warmup):
+  for i in range(args.warmup):
+    if args.graph and ops is not None and i > 0 and i == (args.warmup + 1) // 2:
+      ops.profile_stop()          # --graph: kernel times from the second half of the warm-up
+      ops.profile_start()
     out = step()
   fence()
+  prof_warm = None
   if ops is not None:
-    ops.profile_stop()
-    ops.profile_start()
+    prof_warm = ops.profile_stop()
+    if not args.graph:
+      ops.profile_start()
+  if args.graph:
+    assert gpu and ops is not None and args.warmup > 0, "--graph needs a GPU and a warm-up step"
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):        # every launch of model.apply, on the capture stream
+      static_logits = apply_fn(x)
+
+    def step():                          # noqa: F811  (the timed steps replay the graph)
+      graph.replay()
+      return parallel.all_gather_rows(static_logits)
+    out = step()
+    fence()
   t0 = time.perf_counter()
   trace = os.environ.get("SNNQP_BENCH_TRACE")      # diagnostic: host time of every step's enqueue
   marks = []
@@ -368,7 +397,8 @@ def main(argv=None):
   if trace and rank == 0:
     print("enqueue done at (ms):", [round(m * 1e3, 2) for m in marks], "all done", round(dt * 1e3, 2),
           file=sys.stderr)
-  prof = ops.profile_stop() if ops is not None else {}    # {tag: (launches, total ms)}
+  # {tag: (launches, total ms)}: from the timed steps, or from the eager warm-up under --graph
+  prof = (prof_warm if args.graph else ops.profile_stop()) if ops is not None else {}
   assert out.shape == (world * B, args.classes), out.shape
   if args.stand_in:
     # every rank's rows arrived, in rank order: row r*B of the gathered logits is rank r's first
@@ -402,7 +432,11 @@ def main(argv=None):
               % args.lam + ", N(0,1/fan_in) weights, " +
               ("random BatchNorm statistics" if args.random_bn else "BatchNorm as initialised") +
               ", random seeds fixed",
-      "config": {"workload": ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
+      "config": {"workload": ("C2: qdense(2048->512)+LIF -> qdense(512->%d)+LIF + vote, [B, T, 2048] "
+                              "binary spikes, T=%d, %d-bit, %.4g%% pruned"
+                              % (args.classes * 10, T, args.bits, args.prune * 100))
+                             if args.model == "dense" else
+                             ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
                               "qdense(2048->512->%d) + vote, " % (args.classes * 10)
                               if args.model == "cextnet" else
                               "C3 topology: 3x(qconv3x3+BN+LIF+pool2) + qdense(32768->%d)+LIF + vote, "
@@ -412,6 +446,8 @@ def main(argv=None):
                  "batch_per_gpu": B, "global_batch": world * B, "frames": T,
                  "parallelism": "dp%d (batch-sharded, all-gather logits)" % world},
   }
+  if args.graph:
+    line["config"]["launch"] = "hipGraph replay of model.apply (kernel times from the eager warm-up)"
   if build_flags or os.environ.get("SNNQP_DIAG_LIB"):
     line["DIAGNOSTIC_BUILD"] = build_flags or os.environ.get("SNNQP_DIAG_LIB")
   if args.stand_in:
@@ -449,6 +485,9 @@ def rooflines_of(args, prof, B, T, lb):
                                   B * T * (32 * 32 * 16 + 16 * 16 * 16), conv_peak(lb[2])),
       "dense[32768->%d]" % nout: (B * T * 32768 * nout, B * T * (4096 + 16) + 32768 * 128,
                                   INT8_MFMA_PEAK_TOPS),
+      # config C2 (bit-packed spikes in and out, int8 codes once per launch)
+      "dense[2048->512]": (B * T * 2048 * 512, B * T * (256 + 64) + 2048 * 512, INT8_MFMA_PEAK_TOPS),
+      "dense[512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 16) + 512 * 128, INT8_MFMA_PEAK_TOPS),
   }
   traffic = {}
   if B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3":
@@ -480,10 +519,10 @@ def rooflines_of(args, prof, B, T, lb):
   # rocprofv3 --stats groups it (conv1 and conv2 are two launches of one kernel):
   # achieved = algorithmic ops (bytes) per launch / average launch duration
   conv_kernel = "conv3x3_bits_kernel"   # one device function, fp6 or int8 instruction inside
-  dense_tag = "dense[32768->%d]" % nout
+  dense_tag = "dense[2048->512]" if args.model == "dense" else "dense[32768->%d]" % nout
   groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
             "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
-            "dense_mfma_kernel": [dense_tag]}
+            "dense_mfma_kernel": [dense_tag] + (["dense[512->%d]" % nout] if args.model == "dense" else [])}
   gtime = {g: sum(kern[t]["avg_ms"] * kern[t]["launches"] for t in tags if t in kern)
            for g, tags in groups.items()}
   out = {"kernels": kern}

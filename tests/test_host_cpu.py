@@ -345,6 +345,14 @@ def test_bench_metric_label_follows_the_arguments():
   assert bench.metric_name(bench.parse(["--frames", "50", "--layer-bits", "2,4,2,4", "--prune",
                                         "0.95"])) == \
       "samples/sec/node (DVS128 T=50, mixed 2/4-bit/95%-pruned)"
+  c2 = bench.parse(["--model", "dense", "--batch", "256", "--bits", "8", "--prune", "0.5", "--graph"])
+  assert c2.graph and bench.metric_name(c2) == \
+      "samples/sec/node (2-layer qdense 2048-512-110, T=20, 8-bit/50%-pruned)"
+  # the roofline block of the C2 line: the first dense block is the dense layer the metric names
+  r = bench.rooflines_of(c2, {"dense[2048->512]": (10, 0.2), "dense[512->110]": (10, 0.2)}, 256, 20, [8] * 4)
+  assert r["roofline_dense"]["kernel"] == "dense[2048->512]" and r["roofline"]["kernel"] == "dense_mfma_kernel"
+  nbytes = 256 * 20 * (256 + 64) + 2048 * 512
+  assert abs(r["roofline_dense"]["achieved"] - nbytes / 0.02e-3 / 1e9) < 1e-6
 
 
 def _flax_blob_module():

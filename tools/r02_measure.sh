@@ -19,6 +19,8 @@ run 8bit_counts --bits 8 --prune 0.3 --counts
 run counts --counts
 run cextnet --model cextnet
 run f32 --input f32
+run c2 --model dense --batch 256 --bits 8 --prune 0.5 --steps 50 --warmup 10
+run c2_graph --model dense --batch 256 --bits 8 --prune 0.5 --steps 200 --warmup 10 --graph
 python - $O <<'PY' | tee $O/configs.txt
 import json, glob, os, sys
 for f in sorted(glob.glob(sys.argv[1] + "/bench*.json")):
