@@ -557,9 +557,18 @@ def rooflines_of(args, prof, B, T, lb):
     updates = B * T * 128 * 128 * 128
     instr_per_update = 3.5
     ceiling_ms = updates * instr_per_update / 64.0 / (VALU_PEAK_GINSTR * 1e9) * 1e3
+    # the same ceiling from a measurement instead of a count: the tile's vector instructions
+    # alone (8 x {v_pk_add, v_pk_fma, 2 v_cmp, 2 v_cndmask, v_writelane}, 4 waves per SIMD, no
+    # LDS, no MFMA: tools/ubench/u8c2_epilogue_rate.hip) take 245 SIMD cycles per 32-pixel x
+    # 32-channel tile-step at 2.4 GHz -- compare / select / min / max issue every 4.2 cycles,
+    # add / mul / fma / and every 2.3 (tools/ubench/pk_f32_rate.hip)
+    tiles_per_simd = updates / 1024.0 / 1024.0           # 1024 updates per tile-step, 1024 SIMDs
+    mix_ms = tiles_per_simd * 245.0 / 2.4e9 * 1e3
     c0["valu_issue"] = {"updates": updates, "instr_per_update": instr_per_update,
                         "peak_ginstr_per_s": VALU_PEAK_GINSTR, "ceiling_ms": ceiling_ms,
-                        "frac": ceiling_ms / c0["avg_launch_ms"]}
+                        "frac": ceiling_ms / c0["avg_launch_ms"],
+                        "measured_mix_cycles_per_tile": 245.0, "measured_mix_ms": mix_ms,
+                        "measured_mix_frac": mix_ms / c0["avg_launch_ms"]}
     c0["note"] = ("conv0 does 18 MACs and 0.3 HBM bytes per neuron update; it is bound by VALU "
                   "issue of the neuron epilogue (valu_issue.frac of that ceiling), neither roofline")
   dn = rooflines.get(dense_tag)
