@@ -1105,6 +1105,34 @@ def test_full_cextnet_with_tcja(dev, oracle, golden_dir):
   assert 0.02 < g["dense1_s"].mean() < 0.5 and 0.02 < g["dense2_s"].mean() < 0.5
 
 
+def test_full_size_cextnet_against_oracle(dev, oracle):
+  """The reference's full DVS128 model at ITS geometry -- 128x128x2 events, T = 20 (the TCJA
+  convolutions over T are 20 -> 20), 4-bit / 90 % pruned, random BatchNorm statistics -- against
+  the oracle computed here: every raster, both gates and the logits bit-exact."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.cextnet_case(T=20, B=2, hw=128)
+  g = cases.cextnet_expected(oracle, c)
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  model = models.CextNet(num_classes=11, config=cfg)
+  (logits, _), mut = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None,
+                                 train=False, rng=None, mutable=["intermediates"])
+  im = mut["intermediates"]
+  for i in range(3):
+    np.testing.assert_array_equal(_np(im["pool%d" % i][0]), g["pool%d_bits" % i])
+  for i in range(2):
+    np.testing.assert_array_equal(_np(im["tcja_gate_%d" % i][0]), g["gate%d" % i])
+    s = im["conv_t_%d" % i][0]
+    s = _np(s) if hasattr(s, "bits") else packbits_lastaxis(_np(s))
+    np.testing.assert_array_equal(s, g["conv_t_%d_bits" % i])
+  for name in ("dense1", "dense2"):
+    d = im[name + "_out"][0]
+    d = d.to_dense() if hasattr(d, "to_dense") else d
+    np.testing.assert_array_equal(_np(d).astype(np.uint8), g[name + "_s"])
+  np.testing.assert_array_equal(_np(logits), g["logits"])
+  assert 0.02 < g["dense1_s"].mean() < 0.5 and 0.02 < g["dense2_s"].mean() < 0.5
+
+
 def test_mixed_precision_c5_like_model(dev, oracle):
   """BASELINE config C5 composed from the same blocks: per-layer 2/4-bit weights,
   95 % unstructured prune, 10 classes (read-out 100), odd T."""
