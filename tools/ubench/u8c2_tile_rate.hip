@@ -29,8 +29,31 @@ __device__ __forceinline__ void update_pair(v2f &u, v2f x, v2f kv, float th, uns
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(w), "n"(0));
 }
 
+// two pairs at once, instruction by instruction: two independent dependency chains per wave
+__device__ __forceinline__ void update_two(v2f &ua, v2f &ub, v2f xa, v2f xb, v2f kv, float th,
+                                           unsigned &word) {
+  v2f ta, tb;
+  unsigned long long a0, a1, b0, b1;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ta) : "v"(xa), "v"(ua));
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(tb) : "v"(xb), "v"(ub));
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(ta), "v"(kv), "v"(ua));
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tb) : "v"(tb), "v"(kv), "v"(ub));
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(a0) : "v"(th), "v"(ta.x));
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(a1) : "v"(th), "v"(ta.y));
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(b0) : "v"(th), "v"(tb.x));
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(b1) : "v"(th), "v"(tb.y));
+  asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(ua.x) : "v"(ta.x), "s"(a0));
+  asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(ua.y) : "v"(ta.y), "s"(a1));
+  asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(ub.x) : "v"(tb.x), "s"(b0));
+  asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(ub.y) : "v"(tb.y), "s"(b1));
+  const unsigned long long ma = a0 | a1, mb = b0 | b1;
+  const unsigned wa = (unsigned)ma | (unsigned)(ma >> 32), wb = (unsigned)mb | (unsigned)(mb >> 32);
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(wa), "n"(0));
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(wb), "n"(1));
+}
+
 template <int VARIANT>
-__global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, float th, int spread) {
+__global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float th, int spread) {
   // one array: the table at LDS offset 0 (an accumulator IS a table address, as in the kernel,
   // where constant k rows add the table base inside the MFMA), the A image behind it
   __shared__ __attribute__((aligned(16))) float smem[4096 + 2048];
@@ -57,7 +80,7 @@ __global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, flo
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
       v2f x[8];
-      if (VARIANT == 0) {
+      if (VARIANT == 0 || VARIANT == 5) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = v2f{0.3f + j, 0.7f};
       } else {
@@ -85,8 +108,13 @@ __global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, flo
           asm volatile("" : "+v"(x[j]));
         }
       }
+      if (VARIANT == 5) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) update_pair(u[tl][j], x[j], kv, th, word, j);
+        for (int j = 0; j < 8; j += 2) update_two(u[tl][j], u[tl][j + 1], x[j], x[j + 1], kv, th, word);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) update_pair(u[tl][j], x[j], kv, th, word, j);
+      }
     }
   }
   float s = (float)word;
@@ -94,23 +122,27 @@ __global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, flo
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <int V>
-void run(const char *name, float *out, int spread) {
+void run(const char *name, float *out, int spread, int wps = 4) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 10000; float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<V>), dim3(256 * 4), dim3(256), 0, 0, out, iters, 0.5f, 1.0f, spread);
+    hipLaunchKernelGGL((k<V>), dim3(256 * wps), dim3(256), 0, 0, out, iters, 0.5f, 1.0f, spread);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
   }
-  const double tiles = (double)iters * 2 * 4;      // tile-steps per SIMD (2 tiles per step, 4 waves)
-  printf("%-46s spread %4d: %.1f SIMD cycles per tile (2.4 GHz)\n", name, spread, ms * 1e6 / tiles * 2.4);
+  const double tiles = (double)iters * 2 * wps;    // tile-steps per SIMD (2 tiles per step, wps waves)
+  printf("%-46s spread %4d, %d waves/SIMD: %.1f SIMD cycles per tile (2.4 GHz)\n", name, spread, wps,
+         ms * 1e6 / tiles * 2.4);
 }
 int main() {
-  float *out; (void)hipMalloc(&out, 256 * 4 * 256 * 4);
+  float *out; (void)hipMalloc(&out, 256 * 8 * 256 * 4);
   run<0>("vector instructions alone", out, 1);
   run<1>("+ 16 table reads, one entry (broadcast)", out, 1);
   run<1>("+ 16 table reads, 253 entries", out, 253);
   run<2>("+ A reads + MFMA -> table addresses", out, 1);
   run<2>("+ A reads + MFMA -> table addresses", out, 253);
+  for (int w = 2; w <= 8; ++w) run<2>("whole tile-step (conflict-free table)", out, 1, w);
+  for (int w = 2; w <= 8; w += 2) run<0>("vector instructions alone", out, 1, w);
+  for (int w = 2; w <= 8; w += 2) run<5>("vector instructions, two pairs interleaved", out, 1, w);
   return 0;
 }
