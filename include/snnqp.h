@@ -105,8 +105,11 @@ typedef struct {
  * spiking_learning.py:457-458).  All three device arrays have Cout entries.
  * `flags`: facts the caller knows about the arrays (it folded them on the host):
  * SNNQP_BN_MEAN_ZERO / SNNQP_BN_BIAS_ZERO = every mean / bias entry is +-0.0, so that
- * fl(x - 0) and fl(x + 0) are x itself and a kernel may skip the instruction (a freshly
- * initialised BatchNorm has both).  0 = nothing known. */
+ * fl(x - 0) and fl(x + 0) equal x and a kernel may skip the instruction (a freshly
+ * initialised BatchNorm has both).  Equal as numbers: for x = -0.0 the skipped form keeps
+ * -0.0 where fl(-0.0 + 0.0) is +0.0.  The sign of a zero current never changes a spike or a
+ * non-zero potential; it can show in the sign bit of a membrane potential that is exactly
+ * zero (u_out), which compares equal.  0 = nothing known; other bits are refused. */
 #define SNNQP_BN_MEAN_ZERO 1
 #define SNNQP_BN_BIAS_ZERO 2
 typedef struct {
@@ -138,6 +141,12 @@ typedef struct {
   int32_t groups;               /* feature_group_count   */
 } snnqp_conv_geom_t;
 
+/* ABI version of this header: bumped whenever a struct or a signature below changes
+ * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
+ * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
+ * snnqp_fallback_counts).  A binding compares snnqp_version() with the SNNQP_VERSION it was
+ * written against and refuses a library of another version (_lib.py does). */
+#define SNNQP_VERSION 300
 int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build

@@ -15,6 +15,9 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int8,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
 
+# include/snnqp.h SNNQP_VERSION the prototypes below were written against
+ABI_VERSION = 300
+
 # enums of include/snnqp.h
 F32, U8, BITS = 0, 1, 2
 W_F32, W_I8 = 0, 1
@@ -131,6 +134,11 @@ def lib():
       fn = getattr(handle, name)
       fn.restype = res
       fn.argtypes = args
+    if handle.snnqp_version() != ABI_VERSION:
+      raise ImportError(
+          "%s has ABI version %d, this binding was written against %d (include/snnqp.h "
+          "SNNQP_VERSION): rebuild it with `python __graft_entry__.py`"
+          % (path, handle.snnqp_version(), ABI_VERSION))
     _lib = handle
   return _lib
 

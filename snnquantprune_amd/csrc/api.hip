@@ -18,7 +18,7 @@ void set_error(const char *fmt, ...) {
 
 extern "C" {
 
-int snnqp_version(void) { return 100; }  // 0.1.0
+int snnqp_version(void) { return SNNQP_VERSION; }
 
 const char *snnqp_last_error(void) { return snnqp::g_last_error.c_str(); }
 

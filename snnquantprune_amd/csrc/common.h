@@ -131,6 +131,20 @@ struct BnP {
   int flags;            // SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO (caller-asserted)
 };
 
+// a BatchNorm descriptor is either absent or complete, and carries no flag bits this build
+// does not know (an uninitialised `flags` of a caller built against an older header must
+// not silently select the mean / bias shortcuts)
+#define SNNQP_CHECK_BN(bn)                                                              \
+  do {                                                                                  \
+    if (bn) {                                                                           \
+      SNNQP_REQUIRE((bn)->mean && (bn)->mul && (bn)->bias, SNNQP_EINVAL,                \
+                    "batch-norm descriptor with null arrays");                          \
+      SNNQP_REQUIRE(((bn)->flags & ~(SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO)) == 0,    \
+                    SNNQP_EINVAL, "batch-norm descriptor with unknown flag bits 0x%x "  \
+                    "(built against another snnqp.h?)", (unsigned)(bn)->flags);         \
+    }                                                                                   \
+  } while (0)
+
 inline BnP make_bn(const snnqp_bn_t *b) {
   BnP p;
   p.mean = b ? b->mean : nullptr;

@@ -198,7 +198,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   lds_barrier();                                 // tables are visible
 
   PatchWalk pw(a);
-  // patch indices fit 31 bits (launch check) and are workgroup-uniform: scalar registers
+  // patch indices (+ one grid stride) stay below 2^31 (run_conv3x3_mfma refuses launches of
+  // 2^30 patches or more) and are workgroup-uniform: scalar registers
   int r = __builtin_amdgcn_readfirstlane((int)pw.first);
   while (r < (int)pw.count) {
     int claimed = 0;

@@ -10,8 +10,11 @@
 // dequant / BatchNorm constants are per-lane registers, the membrane potentials of a
 // tile stay in 16 VGPRs for all T, and the v_cmp that thresholds a register *is* the
 // packed spike word of two pixels (64-bit lane mask); pooling is an OR of those masks.
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <utility>
 
 #include "conv_tile.h"
 
@@ -183,7 +186,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int s_dst = (s_pix / HALO) * HROW2 + (s_pix % HALO) * 2;
 
   PatchWalk pw(a);
-  // patch indices fit 31 bits (launch check) and are workgroup-uniform: scalar registers
+  // patch indices (+ one grid stride) stay below 2^31 (run_conv3x3_mfma refuses launches of
+  // 2^30 patches or more) and are workgroup-uniform: scalar registers
   int r = __builtin_amdgcn_readfirstlane((int)pw.first);
   while (r < (int)pw.count) {
     int claimed = 0;
@@ -337,10 +341,28 @@ struct SchedPool {
   uint32_t *words = nullptr;
   hipEvent_t busy[SCHED_SLOTS] = {};
   bool has_event[SCHED_SLOTS] = {};
+  bool retired[SCHED_SLOTS] = {};      // no event could be made: never handed out again
   unsigned next = 0;
 };
 std::mutex g_sched_mu;
 SchedPool g_sched[64];
+
+// The pool's words and events belong to the device of the launch stream, which need not be
+// the calling thread's current device: allocate and create them with that device current.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+    if (cur == dev) return;
+    if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+    prev = cur;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && hipSetDevice(prev) != hipSuccess) (void)hipGetLastError();
+  }
+};
 }  // namespace
 
 uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
@@ -354,6 +376,8 @@ uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
   std::lock_guard<std::mutex> lock(g_sched_mu);
   SchedPool &p = g_sched[dev];
   if (!p.words) {
+    DeviceGuard on(dev);
+    if (!on.ok) return nullptr;
     uint32_t *w = nullptr;
     if (hipMalloc((void **)&w, (size_t)SCHED_SLOTS * SCHED_WORDS * sizeof(uint32_t)) != hipSuccess) {
       (void)hipGetLastError();
@@ -362,7 +386,18 @@ uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
     p.words = w;
   }
   const int slot = (int)(p.next++ % SCHED_SLOTS);
-  if (p.has_event[slot] && hipEventQuery(p.busy[slot]) != hipSuccess) {
+  if (p.retired[slot]) return nullptr;
+  if (!p.has_event[slot]) {
+    // the event that will guard the slot exists BEFORE the slot is handed out: a slot whose
+    // launches could not be tracked would look free while one is still walking it
+    DeviceGuard on(dev);
+    if (!on.ok || hipEventCreateWithFlags(&p.busy[slot], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      p.retired[slot] = true;
+      return nullptr;
+    }
+    p.has_event[slot] = true;
+  } else if (hipEventQuery(p.busy[slot]) != hipSuccess) {
     (void)hipGetLastError();            // hipErrorNotReady: the slot's last launch is in flight
     return nullptr;
   }
@@ -379,25 +414,56 @@ uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
 void sched_release(int dev, int slot, hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_sched_mu);
   SchedPool &p = g_sched[dev];
-  if (!p.has_event[slot]) {
-    if (hipEventCreateWithFlags(&p.busy[slot], hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      // no event: the slot cannot be proven free again, so retire it from the rotation by
-      // leaving has_event false and never reusing it while anything may be in flight
-      p.has_event[slot] = false;
-      return;
-    }
-    p.has_event[slot] = true;
+  // (the event was created in sched_acquire).  A failed record leaves the event at its
+  // previous state -- "complete" -- while the launch runs: the slot can no longer be
+  // proven free, so it leaves the rotation.
+  if (hipEventRecord(p.busy[slot], st) != hipSuccess) {
+    (void)hipGetLastError();
+    p.retired[slot] = true;
   }
-  if (hipEventRecord(p.busy[slot], st) != hipSuccess) (void)hipGetLastError();
+}
+
+int stream_device(hipStream_t st) {
+  int dev = 0;
+  hipDevice_t sdev;
+  if (hipStreamGetDevice(st, &sdev) == hipSuccess) return (int)sdev;
+  (void)hipGetLastError();
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return dev;
+}
+
+void persistent_limits(const void *kernel, int threads, size_t dyn_lds, int dev, int *cus_out,
+                       int *occ_out) {
+  typedef std::tuple<const void *, int, size_t, int> Key;
+  static std::mutex mu;
+  static std::map<Key, std::pair<int, int>> cache;
+  const Key key(kernel, threads, dyn_lds, dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    int cus = 256, occ = 1;
+    DeviceGuard on(dev);               // the occupancy query answers for the current device
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, dyn_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      occ = 1;
+    }
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+    it = cache.emplace(key, std::make_pair(cus, occ)).first;
+  }
+  *cus_out = it->second.first;
+  *occ_out = it->second.second;
 }
 
 int run_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound, int32_t Cout,
                     uint32_t *out_bits, hipStream_t st) {
   SNNQP_REQUIRE(w && out_bits && Cout > 0 && bound >= 0, SNNQP_EINVAL, "current_min: bad argument");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
-  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
-                        "batch-norm descriptor with null arrays");
+  SNNQP_CHECK_BN(bn);
   const int slices = bound >= 256 ? 16 : 1;
   hipLaunchKernelGGL(current_min_kernel, dim3((Cout + 63) / 64, slices), dim3(256), 0, st,
                      make_dequant(w->L, w->m), make_bn(bn), bound, Cout, out_bits);
@@ -445,9 +511,12 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                 "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "conv3x3 mfma: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
-  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
-                        "batch-norm descriptor with null arrays");
+  SNNQP_CHECK_BN(bn);
   if (T == 0 || B == 0) return SNNQP_OK;
+  // the kernels keep a patch index (+ one grid stride) in a 32-bit scalar register; the
+  // smallest patch is the bits kernel's 4 x 8 pixels
+  SNNQP_REQUIRE((int64_t)B * ((g->H + 3) / 4) * ((g->W + 7) / 8) < ((int64_t)1 << 30),
+                SNNQP_EUNSUPPORTED, "conv3x3 mfma: more than 2^30 patches in one launch");
   ConvMfmaArgs a;
   a.x = x; a.xs_t = xs_t; a.xs_b = xs_b; a.T = T; a.B = B;
   a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.Cout = g->Cout;

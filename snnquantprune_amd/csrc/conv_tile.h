@@ -530,17 +530,19 @@ __device__ __forceinline__ v16i splat16(int v) {
 uint32_t *sched_acquire(hipStream_t st, int *dev, int *slot);
 void sched_release(int dev, int slot, hipStream_t st);
 
+// CUs of device `dev` and the workgroups of `kernel` one CU holds (threads, dynamic LDS):
+// asked from the runtime once per (kernel, threads, LDS bytes, device) and remembered -- the
+// two queries cost tens of microseconds, as much as a small layer's kernel.
+void persistent_limits(const void *kernel, int threads, size_t dyn_lds, int dev, int *cus, int *occ);
+int stream_device(hipStream_t st);
+
 template <typename K>
 static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipStream_t st,
                                      size_t dyn_lds = 0, int threads = 256) {
   int dev = 0, cus = 256, occ = 2, slot = -1;
-  a.sched = gy <= (unsigned)SCHED_Y && a.npatch < (1ll << 30) ? sched_acquire(st, &dev, &slot) : nullptr;
-  if (!a.sched && hipGetDevice(&dev) != hipSuccess) dev = 0;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, dyn_lds) != hipSuccess ||
-      occ < 1)
-    occ = 1;
-  if (occ > 8) occ = 8;
+  a.sched = gy <= (unsigned)SCHED_Y ? sched_acquire(st, &dev, &slot) : nullptr;   // npatch < 2^30: run_conv3x3_mfma
+  if (!a.sched) dev = stream_device(st);
+  persistent_limits((const void *)kernel, threads, dyn_lds, dev, &cus, &occ);
   const int64_t gmax = (int64_t)cus * occ;
   unsigned gx = (unsigned)(a.npatch < gmax ? a.npatch : gmax);
   a.xcd_split = 0;

@@ -322,8 +322,7 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   SNNQP_REQUIRE(x && s_out, SNNQP_EINVAL, "dense mfma: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense mfma: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
-  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
-                        "batch-norm descriptor with null arrays");
+  SNNQP_CHECK_BN(bn);
   if (T == 0 || B == 0) return SNNQP_OK;
   SNNQP_REQUIRE(T <= 96, SNNQP_EUNSUPPORTED, "dense mfma: T > 96");
   DenseMfmaArgs a;

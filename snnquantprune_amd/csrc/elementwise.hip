@@ -74,8 +74,7 @@ int snnqp_lif_forward(const float *x, int32_t T, int64_t R, int32_t C,
                 "lif_forward: LIF neuron needs a decay vector");
   SNNQP_REQUIRE(s_type == SNNQP_F32 || s_type == SNNQP_BITS, SNNQP_EINVAL,
                 "lif_forward: spike output type must be F32 or BITS");
-  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
-                        "lif_forward: batch-norm descriptor with null arrays");
+  SNNQP_CHECK_BN(bn);
   const int64_t n = R * C;
   if (n == 0 || T == 0) return SNNQP_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -93,8 +92,8 @@ int snnqp_lif_forward(const float *x, int32_t T, int64_t R, int32_t C,
 int snnqp_batchnorm_forward(const float *x, int64_t rows, int32_t C,
                             const snnqp_bn_t *bn, float *y,
                             snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && y && bn && bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
-                "batchnorm_forward: null argument");
+  SNNQP_REQUIRE(x && y && bn, SNNQP_EINVAL, "batchnorm_forward: null argument");
+  SNNQP_CHECK_BN(bn);
   SNNQP_REQUIRE(rows >= 0 && C > 0, SNNQP_EINVAL, "batchnorm_forward: bad shape");
   const int64_t n = rows * C;
   if (n == 0) return SNNQP_OK;

@@ -176,8 +176,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
   if (a.total == 0 || T == 0) return SNNQP_OK;
   if (a.nrn.kind == SNNQP_NEURON_LIF)
     SNNQP_REQUIRE(a.nrn.decay, SNNQP_EINVAL, "LIF neuron needs a decay vector");
-  if (bn) SNNQP_REQUIRE(bn->mean && bn->mul && bn->bias, SNNQP_EINVAL,
-                        "batch-norm descriptor with null arrays");
+  SNNQP_CHECK_BN(bn);
   if (a.nrn.kind != SNNQP_NEURON_NONE) {
     SNNQP_REQUIRE(s_type == SNNQP_F32 || s_type == SNNQP_BITS, SNNQP_EINVAL,
                   "spike output type must be F32 or BITS");

@@ -343,14 +343,30 @@ class CountHint:
     self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
     self._event = None
 
+  @staticmethod
+  def capturing() -> bool:
+    """True while the current stream is being captured into a hipGraph: the read-back
+    (a copy, a memset and an event) must stay out of the graph -- an event recorded on a
+    capturing stream cannot be queried afterwards, and every replay would re-zero the
+    shared word -- so a captured launch gets no `x_seen` word and the last known hint."""
+    return torch.cuda.is_current_stream_capturing()
+
   def current(self) -> int:
+    if self.capturing():
+      return self.value
     if self._event is not None and self._event.query():
       self._event = None
       self.value = max(1, int(self._host[0]))
     return self.value
 
+  def seen_word(self):
+    """The device word a launch reports into, or None under graph capture."""
+    return None if self.capturing() else self.word
+
   def launched(self):
     """After a launch that was given `word`: start its read-back (at most one in flight)."""
+    if self.capturing():
+      return
     if self._event is None:
       self._host.copy_(self.word, non_blocking=True)
       self.word.zero_()

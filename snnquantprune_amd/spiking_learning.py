@@ -339,7 +339,7 @@ class SpikingBlock(nn.Module):
       import dataclasses
       w = dataclasses.replace(w, min_current_bits=ops.current_min_bits(
           w, bn, int(w.abs_sum_max), geom.Cout))
-    x_seen = hint.word if hint is not None else None
+    x_seen = hint.seen_word() if hint is not None else None
     try:
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,

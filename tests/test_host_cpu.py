@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), "libsnnqp.so does not export %s" % name
   assert declared == set(L.EXPORTED_SYMBOLS)
-  assert lib.snnqp_version() >= 100
+  assert lib.snnqp_version() == L.ABI_VERSION
   # the in-tree library is the product build: no diagnostic switch compiled in
   assert L.build_flags() == ""
   L.require_product_build()
@@ -57,6 +57,16 @@ def test_argument_errors_are_reported_without_a_gpu():
   assert rc == L.EINVAL and b"feature_group_count" in lib.snnqp_last_error()  # flax_qconv.py:117
   rc = lib.snnqp_vote(ctypes.c_void_p(8), L.F32, 4, 2, 110, 7, ctypes.c_void_p(8), None)
   assert rc == L.EINVAL
+  # a BatchNorm descriptor with flag bits this build does not know (a caller built against
+  # an older snnqp.h leaves `flags` uninitialised) is refused, not read as "mean and bias zero"
+  g3 = L.ConvGeomT(8, 8, 2, 128, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1)
+  wi = L.WeightT(L.W_I8, 8, 7.0, 1.0, 10, 7, 0)
+  nrn = L.NeuronT(L.NEURON_MULTI_STEP_LIF, 2.0, 1.0, 0.0, None)
+  bad = L.BnT(8, 8, 8, 0x7F3)
+  rc = lib.snnqp_conv_lif_forward(ctypes.c_void_p(8), L.U8, 128, 128 * 4, 4, 1, ctypes.byref(g3),
+                                  ctypes.byref(wi), None, ctypes.byref(bad), ctypes.byref(nrn),
+                                  None, None, ctypes.c_void_p(8), L.BITS, 2, L.IMPL_MFMA, 1, None, None)
+  assert rc == L.EINVAL and b"unknown flag bits" in lib.snnqp_last_error()
 
 
 def test_conv_out_shape_matches_reference_table():

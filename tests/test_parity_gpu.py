@@ -1763,3 +1763,79 @@ def test_conv_work_queues_on_concurrent_streams(dev, oracle):
   for u, s in outs:
     np.testing.assert_array_equal(_np(s), e["pooled_bits"])
     np.testing.assert_array_equal(_np(u), e["u"])
+
+
+def test_event_layer_fallback_in_a_later_chunk(dev, oracle):
+  """conv0 stages its halo in chunks of at most 32 timesteps and decides the path (tables /
+  fused membrane update / general) per chunk.  T = 40 is two chunks; the hot pixel (count
+  200) sits in the SECOND chunk of one patch only, so that patch runs a table + fused
+  chunk and then a general chunk, carrying its potentials across (and, with u0, starts from
+  a carried-in state, where the fused form is never taken).  Rasters and the final membrane
+  potentials against the oracle, hints 1 and 4, with and without u0."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, hw = 40, 3, 16
+  c = cases.conv_block_case(T=T, B=B, hw=hw, cin=2, seed=961, gain=4.0)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  bn, nrn = _bn(c["bn"], dev), _mslif()
+  g = ops.ConvGeom(hw, hw, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  rng = np.random.Generator(np.random.PCG64(77))
+  x = (rng.random((T, B, hw, hw, 2)) < 0.1).astype(np.uint8)
+  x[35, 1, 9, 4, 0] = 200                               # second chunk of sample 1, patch (1, 0)
+  x[36, 1, 9, 4, 1] = 3
+  u0 = (rng.random((B, hw, hw, 128)) * 0.6).astype(F32)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  for carry in (None, u0):
+    eu, es = oracle.conv_block(x, qw, c["bn"], None, "int", u0=carry)
+    for hint in (1, 4):
+      seen = torch.zeros(1, dtype=torch.int32, device=dev)
+      for pool in (1, 2):
+        u, s = ops.conv_lif_forward(_t(x, dev), g, w, nrn, bn=bn,
+                                    u0=None if carry is None else _t(carry, dev), want_u=True,
+                                    packed_out=True, pool=pool, impl=L.IMPL_MFMA, x_max=hint,
+                                    x_seen=seen)
+        exp = oracle.max_pool_2x2(es) if pool == 2 else es
+        tag = "hint %d pool %d carry %s" % (hint, pool, carry is not None)
+        np.testing.assert_array_equal(_np(s), packbits_lastaxis(exp), err_msg=tag)
+        np.testing.assert_array_equal(_np(u), eu, err_msg=tag)
+      assert int(seen.item()) == 200
+
+
+def test_model_captured_into_a_graph_then_called_eagerly(dev, oracle):
+  """ConvDenseSNN.apply captured into a hipGraph (the uint8 event layer's count hint keeps
+  its read-back -- copy, memset, event -- out of the capture: ops.CountHint), replayed, and
+  then called eagerly on the same device: all three give the oracle's logits, and the eager
+  call after the capture neither raises on a captured event nor finds the hint's word
+  re-zeroed by a replay."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.conv_net_case()
+  e = cases.conv_net_expected(oracle, c)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+
+  def apply():
+    return model.apply(variables, x, trgt=None, train=False, rng=None)[0]
+  np.testing.assert_array_equal(_np(apply()), e["logits"])       # warm: packs, allocations
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  cap = torch.cuda.Stream(device=dev)
+  with torch.cuda.stream(cap):
+    apply()
+    cap.synchronize()
+    with torch.cuda.graph(graph, stream=cap):
+      static = apply()
+  for _ in range(3):
+    static.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(static), e["logits"])
+  hint = ops.count_hint(dev)
+  for _ in range(3):                                             # eager again, hint alive
+    np.testing.assert_array_equal(_np(apply()), e["logits"])
+    torch.cuda.synchronize()
+    assert hint.current() == 1
+  graph.replay()
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(_np(static), e["logits"])
