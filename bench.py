@@ -67,10 +67,21 @@ def parse(argv=None):
   ap.add_argument("--model", choices=("c3", "cextnet", "dense"), default="c3",
                   help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
                        "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
-  ap.add_argument("--input", choices=("u8", "f32"), default="u8",
-                  help="resident input dtype: uint8 event frames (default) or the float32 "
-                       "frames the reference's pipeline hands over (inspected and narrowed "
-                       "on device inside the step)")
+  ap.add_argument("--input", choices=("u8", "f32", "ev1", "ev4"), default="u8",
+                  help="input format: uint8 event frames (default), the float32 frames the "
+                       "reference's pipeline hands over (inspected and narrowed on device inside "
+                       "the step), or the packed wire formats of include/snnqp.h -- ev1: bit-packed "
+                       "binary frames (81 920 B per sample instead of 655 360), ev4: nibble-packed "
+                       "counts <= 15 (327 680 B)")
+  ap.add_argument("--feed", choices=("resident", "host"), default="resident",
+                  help="resident: the batch is in HBM before the timed region (the contract's "
+                       "`value`).  host: every step's batch comes from page-locked host memory "
+                       "through feed.DeviceFeeder (two batches prefetched on a copy stream, as "
+                       "examples/input_pipeline.py:17-27): the PCIe-inclusive rate; the line is "
+                       "marked `pcie_inclusive`")
+  ap.add_argument("--no-fed-leg", action="store_true",
+                  help="skip the short host-fed leg (ev1 frames through the feeder) that the "
+                       "default run appends to the line as `fed`")
   ap.add_argument("--random-bn", action="store_true",
                   help="BatchNorm with random running statistics / scale / bias (a trained "
                        "model) instead of the freshly initialised one (mean 0, var 1, scale 1, "
@@ -161,6 +172,51 @@ def launch_ranks(args, argv):
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
   return 0
+
+
+def make_feeder(x_dev, dev, nbatches=4):
+  """Host side of `--feed host`: `nbatches` distinct batches in page-locked host memory (the
+  resident batch and rolled copies of it: same statistics, different bytes), cycled through
+  feed.DeviceFeeder -- what a loader that decodes into pinned buffers would hand over."""
+  import itertools
+  import torch
+  from snnquantprune_amd import feed, ops
+  host = []
+  for k in range(nbatches):
+    if isinstance(x_dev, ops.PackedFrames):
+      d = torch.roll(x_dev.data, k, 0).cpu().pin_memory()
+      host.append({"dvs_matrix": ops.PackedFrames(d, x_dev.H, x_dev.W, x_dev.fmt)})
+    else:
+      host.append({"dvs_matrix": torch.roll(x_dev, k, 0).cpu().pin_memory()})
+  return feed.DeviceFeeder(itertools.cycle(host), dev, 2)
+
+
+def fed_leg(args, frames_u8, apply_fn, parallel, fence, dev, steps, warmup):
+  """The PCIe-inclusive figure next to the resident one: the same model on bit-packed (EV1)
+  frames that arrive from page-locked host memory, two batches prefetched (feed.py), timed
+  the same way.  Binary workloads only (EV1 holds no counts)."""
+  import torch
+  from snnquantprune_amd import _lib as L_, ops
+  pf = ops.pack_frames(frames_u8, L_.EV1)
+  feeder = make_feeder(pf, dev)
+
+  def step():
+    return parallel.all_gather_rows(apply_fn(next(feeder)["dvs_matrix"]))
+  for _ in range(max(1, warmup)):
+    step()
+  fence()
+  b0 = feeder.bytes_copied
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  fence()
+  dt = time.perf_counter() - t0
+  nbytes = feeder.bytes_copied - b0
+  B = frames_u8.shape[0]
+  return {"format": "ev1 (bit-packed binary frames, include/snnqp.h)", "steps": steps,
+          "samples_per_s_per_gpu": B * steps / dt, "ms_per_step": dt / steps * 1e3,
+          "bytes_per_sample": pf.data[0].numel() * 4, "h2d_GBps": nbytes / dt / 1e9,
+          "prefetch_depth": 2, "source": "page-locked host memory, hipMemcpyAsync on a copy stream"}
 
 
 def cpu_baseline(args, variables_np):
@@ -334,13 +390,24 @@ def main(argv=None):
                       generator=gen).clamp_(max=255).to(torch.uint8)
   else:
     x = (torch.rand((B, T, hw, hw, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
+  frames_u8 = x if (args.model != "dense" and not args.stand_in) else None
   if args.input == "f32":
     x = x.to(torch.float32)
+  elif args.input in ("ev1", "ev4") and ops is not None and args.model != "dense":
+    from snnquantprune_amd import _lib as L_
+    x = ops.pack_frames(x, L_.EV1 if args.input == "ev1" else L_.EV4)
+    torch.cuda.synchronize()
+
+  feeder = None
+  if args.feed == "host":
+    assert gpu and ops is not None and args.model != "dense", "--feed host needs a GPU and event frames"
+    feeder = make_feeder(x, dev)
 
   def step():
     if ops is not None:
       ops.forget_inputs()     # a new batch: whatever is cached about the last one is dropped
-    return parallel.all_gather_rows(apply_fn(x))
+    xb = next(feeder)["dvs_matrix"] if feeder is not None else x
+    return parallel.all_gather_rows(apply_fn(xb))
 
   def fence():
     if world > 1:
@@ -385,6 +452,7 @@ def main(argv=None):
       return parallel.all_gather_rows(static_logits)
     out = step()
     fence()
+  fed_b0 = feeder.bytes_copied if feeder is not None else 0
   t0 = time.perf_counter()
   trace = os.environ.get("SNNQP_BENCH_TRACE")      # diagnostic: host time of every step's enqueue
   marks = []
@@ -394,6 +462,9 @@ def main(argv=None):
       marks.append(time.perf_counter() - t0)
   fence()
   dt = time.perf_counter() - t0
+  fed_bytes = 0
+  if feeder is not None:
+    fed_bytes = feeder.bytes_copied - fed_b0
   if trace and rank == 0:
     print("enqueue done at (ms):", [round(m * 1e3, 2) for m in marks], "all done", round(dt * 1e3, 2),
           file=sys.stderr)
@@ -413,6 +484,17 @@ def main(argv=None):
   if world > 1:
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
   dt = float(tmax.item())
+
+  # the host-fed leg (every rank runs it: the step holds a collective); binary frames only
+  fed = None
+  if (gpu and ops is not None and frames_u8 is not None and args.feed == "resident"
+      and not args.no_fed_leg and not args.counts and not args.graph):
+    fed = fed_leg(args, frames_u8, apply_fn, parallel, fence, dev, args.steps, min(args.warmup, 2))
+    tf = torch.tensor([fed["ms_per_step"]], device=dev, dtype=torch.float64)
+    if world > 1:
+      torch.distributed.all_reduce(tf, op=torch.distributed.ReduceOp.MAX)
+    fed["ms_per_step"] = float(tf.item())
+    fed["samples_per_s_per_gpu"] = B / (fed["ms_per_step"] * 1e-3)
 
   if rank != 0:
     return
@@ -454,6 +536,15 @@ def main(argv=None):
     line["stand_in"] = True
     print(json.dumps(line))
     return
+  if args.feed == "host":
+    line["pcie_inclusive"] = True
+    line["feed"] = {"mode": "host", "format": args.input, "prefetch_depth": 2,
+                    "h2d_GBps": fed_bytes / dt / 1e9, "bytes_per_sample": fed_bytes / (B * args.steps)}
+  else:
+    line["feed"] = {"mode": "resident", "format": args.input}
+  if fed is not None:
+    fed["vs_resident"] = fed["samples_per_s_per_gpu"] / (value / world)
+    line["fed"] = fed
   line.update(rooflines_of(args, prof, B, T, lb))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:
@@ -475,7 +566,9 @@ def rooflines_of(args, prof, B, T, lb):
     return FP6_MFMA_PEAK_TOPS if bits <= 4 else INT8_MFMA_PEAK_TOPS
   # tag: (MACs per launch, algorithmic HBM bytes per launch in the formats the kernels
   #       really read / write, matrix peak of the instruction the kernel issues)
-  in_bytes = 128 * 128 * 2 * (4 if args.input == "f32" else 1)
+  # bytes of one input frame as conv0 reads it (ev4 frames are unpacked to uint8 first)
+  in_bytes = {"f32": 128 * 128 * 2 * 4, "u8": 128 * 128 * 2, "ev4": 128 * 128 * 2,
+              "ev1": 128 * 128 * 2 // 8}[args.input]
   spec = {
       "conv3x3[128x128x2->128]": (B * T * 128 * 128 * 128 * 18,
                                   B * T * (in_bytes + 64 * 64 * 16), INT8_MFMA_PEAK_TOPS),
@@ -490,7 +583,8 @@ def rooflines_of(args, prof, B, T, lb):
       "dense[512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 16) + 512 * 128, INT8_MFMA_PEAK_TOPS),
   }
   traffic = {}
-  if B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3":
+  if (B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3"
+      and args.input == "u8"):
     for path in PMC_TRAFFIC:
       if os.path.exists(path):
         with open(path) as f:

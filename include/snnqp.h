@@ -44,8 +44,18 @@ enum {
   SNNQP_EHIP = -3          /* HIP runtime error */
 };
 
-/* element type of an activation tensor */
-enum { SNNQP_F32 = 0, SNNQP_U8 = 1, SNNQP_BITS = 2 };
+/* element type of an activation tensor.
+ * SNNQP_EV1 / SNNQP_EV4 are wire formats of the model INPUT, the 2-channel event frames
+ * [H][W][2] of examples/input_pipeline.py:195-218 (what the host feeds, examples/
+ * input_pipeline.py:17-27, 655 360 B per DVS128 sample as uint8):
+ *   SNNQP_EV1  binary frames, one bit per element in index order: element
+ *              i = (y * W + x) * 2 + polarity is bit (i & 31) of 32-bit word (i >> 5); a
+ *              frame takes ceil(H * W * 2 / 32) words (frames are word-aligned) =
+ *              numpy.packbits(frame.ravel(), bitorder="little") -- 81 920 B per sample;
+ *   SNNQP_EV4  count frames with counts <= 15, one byte per pixel: polarity 0 in bits
+ *              0..3, polarity 1 in bits 4..7; a frame takes H * W bytes -- 327 680 B.
+ * Strides of such tensors are in words (EV1) / bytes (EV4). */
+enum { SNNQP_F32 = 0, SNNQP_U8 = 1, SNNQP_BITS = 2, SNNQP_EV1 = 3, SNNQP_EV4 = 4 };
 /* element type of a weight tensor */
 enum { SNNQP_W_F32 = 0, SNNQP_W_I8 = 1 };
 /* neuron models, spiking_learning.py:357-438 */
@@ -71,7 +81,8 @@ enum {
   SNNQP_FLAG_MASK_NOT_BINARY = 2,
   SNNQP_FLAG_NOT_INTEGER = 4,   /* activation not an integer in [0, 255]    */
   SNNQP_FLAG_GT_ONE = 8,        /* activation > 1 (not a binary spike)      */
-  SNNQP_FLAG_GT_127 = 16        /* activation > 127 (not an int8 MFMA operand) */
+  SNNQP_FLAG_GT_127 = 16,       /* activation > 127 (not an int8 MFMA operand) */
+  SNNQP_FLAG_GT_15 = 32         /* activation > 15 (does not fit an EV4 nibble)      */
 };
 
 /* Weights after the transforms of flax_qdense.py:74-85 / flax_qconv.py:147-156.
@@ -194,6 +205,15 @@ int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
  * or 0; y is the uint8 copy, meaningful when flags[1] == 0. */
 int snnqp_narrow_f32(const float *x, uint8_t *y, int64_t n, int32_t *flags,
                      snnqp_stream_t stream);
+/* Event frames between uint8 [frames][H][W][2] and the wire formats SNNQP_EV1 /
+ * SNNQP_EV4 (device side of the host feed; the host packs with the same layout).
+ * pack: a value the format cannot hold is saturated (EV1: > 1 -> 1, EV4: > 15 -> 15) and
+ * flagged (SNNQP_FLAG_GT_ONE / SNNQP_FLAG_GT_15 OR-ed into the nullable device word
+ * `flags`).  unpack: exact inverse on every tensor that packed without a flag. */
+int snnqp_pack_frames(const uint8_t *x, int64_t frames, int32_t H, int32_t W, int fmt,
+                      void *y, int32_t *flags, snnqp_stream_t stream);
+int snnqp_unpack_frames(const void *x, int fmt, int64_t frames, int32_t H, int32_t W,
+                        uint8_t *y, snnqp_stream_t stream);
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
                     uint32_t *bits, snnqp_stream_t stream);
 int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
@@ -227,7 +247,8 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       of the kernel zero-padded along Cin to Cpad = 64 (Cin <= 64) or 128,
  *       tiled by snnqp_pack_codes_mfma with K = 9 * Cpad (row = tap * Cpad + cin);
  *       a pixel keeps its ceil(Cin / 32) spike words, zero bits beyond Cin --
- *       or U8 input with Cin == 2, any count 0..255), s_type BITS;
+ *       or U8 input with Cin == 2, any count 0..255; or EV1 input, Cin == 2: the bit-packed
+ *       frames are staged directly, 1/8 of the uint8 bytes), s_type BITS;
  *       any H, W, Cout and neuron kind.  SNNQP_IMPL_AUTO picks MFMA when it can.
  * x_max the largest input value the caller EXPECTS (1 for spikes and binary event frames;
  *       0 = unknown, taken as 1): with the weights' abs_sum_max it sizes the LDS tables the

@@ -19,13 +19,13 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
 ABI_VERSION = 300
 
 # enums of include/snnqp.h
-F32, U8, BITS = 0, 1, 2
+F32, U8, BITS, EV1, EV4 = 0, 1, 2, 3, 4
 W_F32, W_I8 = 0, 1
 NEURON_NONE, NEURON_MULTI_STEP_LIF, NEURON_PARAMETRIC_LEAKY_IF, NEURON_LIF = 0, 1, 2, 3
 Q_DUQ, Q_UNIFORM_STATIC, Q_PARAMETRIC_D, Q_PARAMETRIC_D_XMAX = 0, 1, 2, 3
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA = 0, 1, 2
 FLAG_CODE_OVERFLOW, FLAG_MASK_NOT_BINARY = 1, 2
-FLAG_NOT_INTEGER, FLAG_GT_ONE, FLAG_GT_127 = 4, 8, 16
+FLAG_NOT_INTEGER, FLAG_GT_ONE, FLAG_GT_127, FLAG_GT_15 = 4, 8, 16, 32
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 
 
@@ -67,6 +67,10 @@ _PROTOTYPES = {
     "snnqp_inspect_u8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_f32_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "snnqp_narrow_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "snnqp_pack_frames": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    "snnqp_unpack_frames": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_void_p,
+                                    c_void_p]),
     "snnqp_pack_bits": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p,
                                 c_void_p]),
     "snnqp_unpack_bits": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -63,10 +63,16 @@ __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
   return (b + 15) & ~15;
 }
 
-template <int NF, bool POOL, int LUTM>
+// IN: SNNQP_U8 (one byte per count) or SNNQP_EV1 (bit-packed binary frames, snnqp.h): the
+// same kernel behind another staging loop.  EV1 frames cannot hold a value above 1, so the
+// table modes need no check of the chunk (and the chunk no reduction, no atomic and one
+// barrier less); a thread stages one halo ROW of one timestep -- 20 bits out of two words,
+// expanded through a 256-entry byte -> 8-byte LDS table -- instead of one pixel.
+template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8>
 __global__ void __launch_bounds__(256, U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
+  constexpr bool EV1 = IN == SNNQP_EV1;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tc = a.tchunk;                       // multiple of 8, <= TCHUNK
@@ -85,6 +91,18 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   //   [1] largest input value of the chunk being staged   [2] the claimed next patch
   uint32_t *wgw = obuf + OutStage<POOL>::BYTES / 4;
   if (tid == 0) { wgw[0] = 0x7F800000u; wgw[1] = 0u; }
+  // EV1: byte of 8 input bits -> 8 operand bytes, in the scale of the kernel's path: 16 x
+  // (per-channel tables), 4 x (shared table), or x - 128 (no table: general path)
+  typedef int v2i_a8 __attribute__((ext_vector_type(2)));
+  v2i_a8 *xtab = (v2i_a8 *)(wgw + 4);
+  if (EV1) {
+    const uint32_t one = LUTM == LUT_CHANNEL ? 16u : LUTM == LUT_SHARED ? 4u : 0x81u;
+    const uint32_t zero = LUTM == LUT_NONE ? 0x80u : 0u;
+    uint32_t e[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j >> 2] |= (((uint32_t)tid >> j) & 1u ? one : zero) << (8 * (j & 3));
+    xtab[tid] = v2i_a8{(int)e[0], (int)e[1]};       // 256 threads, 256 entries
+  }
   if (LUTM != LUT_NONE) lds_barrier();
   // tables and constants become visible with the first staging barrier
   if (LUTM == LUT_SHARED) {
@@ -205,9 +223,50 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     // without a pixel read the frame's first one and drop it
     const uint32_t s_off = s_valid ? (uint32_t)(s_gy * a.W + s_gx) * 2u : 0u;
     const uint8_t *s_frames = xb + (int64_t)b * a.xs_b;
+    // EV1: the 20 bits of a halo row start `lead` bits before pixel x0 of the row (none when
+    // x0 = 0: the pixel left of the image does not exist); pixels outside the image are
+    // cleared by a mask of two bits per halo column (workgroup-uniform: scalars)
+    const uint32_t e_lead = x0 > 0 ? 2u : 0u;
+    const int e_hi = min(HALO - 1, a.W - x0);                  // last halo column inside the image
+    const uint32_t e_colmask = ((1u << (2 * (e_hi + 1))) - 1u) & ~((1u << (2 - (int)e_lead)) - 1u);
+    const uint32_t e_fwords = (uint32_t)(((int64_t)a.H * a.W * 2 + 31) >> 5);
+    const uint32_t *e_frames = (const uint32_t *)a.x + (int64_t)b * a.xs_b;
 
     for (int t0 = 0; t0 < a.T; t0 += tc) {
       const int nt = min(tc, a.T - t0);
+      bool general = LUTM == LUT_NONE;
+      if constexpr (EV1) {
+        // ---- stage the chunk from bit-packed frames: one (timestep, halo row) per thread ----
+        lds_barrier();                     // previous readers of the LDS images are done
+        for (int task = tid; task < nt * HALO; task += 256) {
+          const int tt = task / HALO, hy = task - tt * HALO;
+          const int gy = y0 + hy - 1;
+          const bool rv = gy >= 0 && gy < a.H;
+          const uint32_t start = (uint32_t)((rv ? gy : 0) * a.W + x0) * 2u - e_lead;
+          const uint32_t wi = start >> 5;
+          const uint32_t *f = e_frames + (int64_t)(t0 + tt) * a.xs_t;
+          // (the word behind the frame's last one is never needed: its bits would be pixels
+          // beyond the image, which the mask clears)
+          const uint32_t lo = f[wi], hi = f[min(wi + 1u, e_fwords - 1u)];
+          uint32_t v = __builtin_amdgcn_alignbit(hi, lo, start & 31u);
+          v = (v << (2u - e_lead)) & (rv ? e_colmask : 0u);
+          const v2i_a8 d0 = xtab[v & 0xFFu], d1 = xtab[(v >> 8) & 0xFFu], d2 = xtab[(v >> 16) & 0xFu];
+          uint8_t *row = lds + tt * HIMG2 + hy * HROW2;
+          *(v2i_a8 *)row = d0;
+          *(v2i_a8 *)(row + 8) = d1;
+          *(v2i_a8 *)(row + 16) = d2;
+          // copy 1: the same bytes two to the right (pixel hx at byte 2 hx + 2)
+          const uint32_t q0 = (uint32_t)d0.x, q1 = (uint32_t)d0.y, q2 = (uint32_t)d1.x,
+                         q3 = (uint32_t)d1.y, q4 = (uint32_t)d2.x, q5 = (uint32_t)d2.y;
+          uint8_t *row1 = row + HCOPY2;
+          *(v2i_a8 *)row1 = v2i_a8{(int)(q0 << 16), (int)__builtin_amdgcn_alignbit(q1, q0, 16)};
+          *(v2i_a8 *)(row1 + 8) = v2i_a8{(int)__builtin_amdgcn_alignbit(q2, q1, 16),
+                                         (int)__builtin_amdgcn_alignbit(q3, q2, 16)};
+          *(v2i_a8 *)(row1 + 16) = v2i_a8{(int)__builtin_amdgcn_alignbit(q4, q3, 16),
+                                          (int)__builtin_amdgcn_alignbit(q5, q4, 16)};
+        }
+        lds_barrier();
+      } else {
       // ---- stage the chunk: load, take the maximum, choose the path, write ----
       // Thread = one halo pixel (both polarities: 2 bytes) of every other timestep: its only
       // per-patch state is one source pointer, so nothing else is live while the byte pairs
@@ -233,7 +292,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       const uint32_t cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wgw[1]);   // one word
       seen = max(seen, cmax);
       pseen = max(pseen, cmax);
-      const bool general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
+      general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
       if (s_task) {
 #pragma unroll
         for (int i = 0; i < STG_N; ++i) {
@@ -250,6 +309,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       }
       lds_barrier();
       if (tid == 0) wgw[1] = 0u;           // for the next chunk (read above, behind a barrier)
+      }
       // the FL-step blocks of the chunk: table path (with the membrane update as a fused
       // multiply-add where that is proven bit-identical for this launch) or general path
       auto run_chunk = [&](auto mode_tag, auto fma_tag) {
@@ -493,8 +553,11 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   } else if (in_type == SNNQP_U8) {     // any count 0..255 (taken as x - 128 without a table)
     if (g->Cin != 2) return "u8 input needs Cin == 2";
     if ((int64_t)g->H * g->W * 2 >= (int64_t)1 << 31) return "u8 frame of 2 GiB or more";
+  } else if (in_type == SNNQP_EV1) {    // bit-packed binary event frames, staged directly
+    if (g->Cin != 2) return "EV1 frames have Cin == 2";
+    if ((int64_t)g->H * g->W * 2 >= (int64_t)1 << 31) return "EV1 frame of 2^31 bits or more";
   } else {
-    return "input must be BITS or U8";
+    return "input must be BITS, U8 or EV1 (unpack EV4 frames first: snnqp_unpack_frames)";
   }
   if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
   return nullptr;
@@ -537,23 +600,30 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   // (the A operand then carries 4 * x, which must stay an int8).  For U8 input x_max is the
   // value the caller EXPECTS not to be exceeded (0 / unknown: binary events); the kernel
   // checks every chunk it stages and runs the general path where the hint does not hold
-  const int64_t xm = in_type == SNNQP_BITS ? 1 : (x_max > 0 ? x_max : 1);
+  const bool ev1 = in_type == SNNQP_EV1;
+  const int64_t xm = (in_type == SNNQP_BITS || ev1) ? 1 : (x_max > 0 ? x_max : 1);
   a.x_limit = (int32_t)(xm > 255 ? 255 : xm);
   const int64_t bound = (int64_t)w->abs_sum_max * xm;
   const bool lut = w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
   a.lut_bound = lut ? (int32_t)bound : 0;
   a.tchunk = T >= TCHUNK ? TCHUNK : (T + 7) & ~7;
-  const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 +
+  // images | table | spike-word ring | 4 workgroup words | EV1: byte -> 8-byte table
+  const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 + (ev1 ? 2048 : 0) +
                            (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
   // per-channel tables (BatchNorm folded in) while the workgroup stays within 64 KiB of LDS
   // (there the accumulator counts table rows of 128 B: A = 16 x input, B = 8 x code)
-  const bool lutc = lut && in_type == SNNQP_U8 && bound <= LUT2_CAP && xm <= 7 &&
+  const bool lutc = lut && in_type != SNNQP_BITS && bound <= LUT2_CAP && xm <= 7 &&
                     w->code_max > 0 && w->code_max <= 15 &&
                     lds_fixed + u8c2_table_bytes(LUT_CHANNEL, (int)bound) <= 65536;
+#define SNNQP_CONV_LAUNCH_IN(KERN, NFV, PL, LM, LDS)                               \
+  do {                                                                             \
+    if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
+    else launch_persistent(KERN<NFV, PL, LM, SNNQP_U8>, a, gy, st, LDS);            \
+  } while (0)
 #define SNNQP_CONV_LAUNCH_NF(KERN, NFV, LM, LDS)                                   \
   do {                                                                             \
-    if (pl) launch_persistent(KERN<NFV, true, LM>, a, gy, st, LDS);                 \
-    else launch_persistent(KERN<NFV, false, LM>, a, gy, st, LDS);                   \
+    if (pl) SNNQP_CONV_LAUNCH_IN(KERN, NFV, true, LM, LDS);                         \
+    else SNNQP_CONV_LAUNCH_IN(KERN, NFV, false, LM, LDS);                           \
   } while (0)
 #define SNNQP_CONV_LAUNCH(KERN, LM, LDS)                                           \
   do {                                                                             \
@@ -597,6 +667,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   }
 #undef SNNQP_CONV_LAUNCH
 #undef SNNQP_CONV_LAUNCH_NF
+#undef SNNQP_CONV_LAUNCH_IN
   SNNQP_CHECK_LAUNCH("conv3x3 mfma kernel");
   return SNNQP_OK;
 }

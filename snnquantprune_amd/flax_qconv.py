@@ -106,6 +106,8 @@ class QuantConv(nn.Module):
 
   def __call__(self, inputs, rng: Any = None):
     x, integer = packing.prepare_input(inputs)
+    if isinstance(x, ops.PackedFrames):                   # packed model input: the connection
+      x = x.to_u8()                                       # alone reads plain uint8 frames
     nsp = len(self._ksize())
     is_single = False
     if x.ndim == nsp + 1:                                 # flax_qconv.py:109-112

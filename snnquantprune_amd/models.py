@@ -83,7 +83,7 @@ def _sow_density(mod, name, x, lead_dims=2):
 
 
 def _as_input(inputs):
-  if isinstance(inputs, ops.PackedSpikes):
+  if isinstance(inputs, (ops.PackedSpikes, ops.PackedFrames)):
     return inputs
   x = torch.as_tensor(inputs)
   if x.dtype not in (torch.uint8, torch.float32):

@@ -65,6 +65,124 @@ class PackedSpikes:
     return "PackedSpikes(shape=%s, device=%s)" % (self.shape, self.device)
 
 
+class PackedFrames:
+  """The model input -- 2-channel event frames [..., H, W, 2], leading axes [B, T] as the
+  reference hands them over (examples/tcja/models.py:38, :109) -- in one of the wire
+  formats of include/snnqp.h: `data` is int32 [..., ceil(H*W*2/32)] for _lib.EV1 (binary
+  frames, 1 bit per element) or uint8 [..., H*W] for _lib.EV4 (counts <= 15, one byte per
+  pixel).  What the host feed ships (feed.py): 1/8 resp. 1/2 of the uint8 bytes.  The
+  first conv block stages EV1 frames directly; every other consumer unpacks."""
+
+  def __init__(self, data: torch.Tensor, H: int, W: int, fmt: int):
+    assert fmt in (L.EV1, L.EV4), fmt
+    unit = frame_units(H, W, fmt)
+    assert data.dtype == (torch.int32 if fmt == L.EV1 else torch.uint8), data.dtype
+    assert data.shape[-1] == unit and data.is_contiguous(), (tuple(data.shape), unit)
+    self.data, self.H, self.W, self.fmt = data, int(H), int(W), int(fmt)
+
+  @property
+  def shape(self):
+    return tuple(self.data.shape[:-1]) + (self.H, self.W, 2)
+
+  @property
+  def device(self):
+    return self.data.device
+
+  @property
+  def ndim(self):
+    return self.data.ndim + 2
+
+  @property
+  def dtype(self):
+    return torch.uint8
+
+  @property
+  def is_cuda(self):
+    return self.data.is_cuda
+
+  def __getitem__(self, idx):
+    """Indexing over the leading (batch / time) axes only."""
+    if not isinstance(idx, tuple):
+      idx = (idx,)
+    assert len(idx) < self.data.ndim, "cannot index inside a packed frame"
+    return PackedFrames(self.data[idx].contiguous(), self.H, self.W, self.fmt)
+
+  def narrow(self, dim, start, length):
+    assert dim < self.data.ndim - 1
+    return PackedFrames(self.data.narrow(dim, start, length).contiguous(), self.H, self.W, self.fmt)
+
+  def to(self, device, non_blocking=False):
+    return PackedFrames(self.data.to(device, non_blocking=non_blocking), self.H, self.W, self.fmt)
+
+  def to_u8(self) -> torch.Tensor:
+    return unpack_frames(self)
+
+  def __repr__(self):
+    return "PackedFrames(%s, shape=%s, device=%s)" % (
+        "EV1" if self.fmt == L.EV1 else "EV4", self.shape, self.device)
+
+
+def frame_units(H: int, W: int, fmt: int) -> int:
+  """Words (EV1) / bytes (EV4) of one packed frame."""
+  return (H * W * 2 + 31) // 32 if fmt == L.EV1 else H * W
+
+
+def pack_frames_host(x, fmt: int) -> PackedFrames:
+  """uint8 frames [..., H, W, 2] in host memory (numpy array or CPU tensor) -> PackedFrames
+  in host memory, with numpy -- what a data pipeline does once per sample before the feed.
+  Raises if a value does not fit the format (EV1: > 1, EV4: > 15)."""
+  import numpy as np
+  a = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+  if a.dtype != np.uint8 or a.ndim < 3 or a.shape[-1] != 2:
+    raise ValueError("event frames must be uint8 [..., H, W, 2], got %s %s" % (a.dtype, a.shape))
+  H, W = a.shape[-3], a.shape[-2]
+  lead = a.shape[:-3]
+  limit = 1 if fmt == L.EV1 else 15
+  if a.size and int(a.max()) > limit:
+    raise ValueError("event count %d does not fit the %s frame format (max %d)"
+                     % (int(a.max()), "EV1" if fmt == L.EV1 else "EV4", limit))
+  if fmt == L.EV1:
+    flat = np.ascontiguousarray(a).reshape(lead + (H * W * 2,))
+    b = np.packbits(flat, axis=-1, bitorder="little")
+    nbytes = frame_units(H, W, fmt) * 4
+    if b.shape[-1] != nbytes:
+      b = np.concatenate([b, np.zeros(lead + (nbytes - b.shape[-1],), np.uint8)], -1)
+    data = torch.from_numpy(np.ascontiguousarray(b).view(np.int32))
+  else:
+    data = torch.from_numpy(np.ascontiguousarray(a[..., 0] | (a[..., 1] << 4)).reshape(lead + (H * W,)))
+  return PackedFrames(data, H, W, fmt)
+
+
+def pack_frames(x: torch.Tensor, fmt: int, flags: Optional[torch.Tensor] = None) -> PackedFrames:
+  """uint8 frames [..., H, W, 2] on the GPU -> PackedFrames (snnqp_pack_frames).  Values the
+  format cannot hold are saturated and flagged into the int32 device word `flags`
+  (_lib.FLAG_GT_ONE / FLAG_GT_15) when one is given; nothing is read back here."""
+  _require_gpu(x, flags)
+  assert x.dtype == torch.uint8 and x.shape[-1] == 2 and x.ndim >= 3, (x.dtype, tuple(x.shape))
+  x = x.contiguous()
+  H, W = x.shape[-3], x.shape[-2]
+  lead = tuple(x.shape[:-3])
+  frames = 1
+  for d in lead:
+    frames *= d
+  data = torch.empty(lead + (frame_units(H, W, fmt),),
+                     dtype=torch.int32 if fmt == L.EV1 else torch.uint8, device=x.device)
+  L.check(L.lib().snnqp_pack_frames(_ptr(x), frames, H, W, fmt, _ptr(data), _ptr(flags), _stream()))
+  return PackedFrames(data, H, W, fmt)
+
+
+def unpack_frames(p: PackedFrames) -> torch.Tensor:
+  """PackedFrames -> uint8 [..., H, W, 2] (snnqp_unpack_frames)."""
+  _require_gpu(p.data)
+  lead = tuple(p.data.shape[:-1])
+  frames = 1
+  for d in lead:
+    frames *= d
+  y = torch.empty(lead + (p.H, p.W, 2), dtype=torch.uint8, device=p.device)
+  L.check(L.lib().snnqp_unpack_frames(_ptr(p.data), p.fmt, frames, p.H, p.W, _ptr(y), _stream()))
+  return y
+
+
 # ---------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------
@@ -188,6 +306,8 @@ def _in_desc(x):
   """(pointer tensor, in_type, words/elements per pixel-row unit)."""
   if isinstance(x, PackedSpikes):
     return x.bits, L.BITS
+  if isinstance(x, PackedFrames):
+    return x.data, x.fmt
   if x.dtype == torch.uint8:
     return x, L.U8
   if x.dtype == torch.float32:
@@ -554,7 +674,11 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
   T, B = (xt.shape[0], xt.shape[1]) if time_major else (xt.shape[1], xt.shape[0])
-  unit = geom.H * geom.W * (xt.shape[-1])
+  if isinstance(x, PackedFrames):        # [T, B, words / bytes of a frame]
+    assert (x.H, x.W, 2) == (geom.H, geom.W, geom.Cin) and xt.ndim == 3, (x.shape, geom)
+    unit = xt.shape[-1]
+  else:
+    unit = geom.H * geom.W * (xt.shape[-1])
   xs_t, xs_b = _tb_strides(xt, T, B, time_major, unit)
   OH, OW = geom.out_hw()
   dev = xt.device
@@ -739,6 +863,8 @@ def density(x, lead_dims: int = 2, counts: bool = False) -> torch.Tensor:
   """Fraction of non-zero activations of each leading slice (default per [T, B]),
   the probe of examples/tcja/models.py:128-142; float32 of shape x.shape[:lead_dims]
   (or the exact int32 non-zero counts with counts=True)."""
+  if isinstance(x, PackedFrames):
+    x = unpack_frames(x)
   if isinstance(x, PackedSpikes):
     t, typ, C, shape = x.bits, L.BITS, x.channels, x.shape
   elif x.dtype == torch.uint8:

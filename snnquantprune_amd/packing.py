@@ -147,7 +147,7 @@ def prepare_input(x, prefer_bits: Optional[bool] = None):
 
   PackedSpikes and uint8 / bool / integer tensors are integer-typed as they are;
   float32 tensors are inspected when AUTO_INTEGER_INPUTS is set."""
-  if isinstance(x, ops.PackedSpikes):
+  if isinstance(x, (ops.PackedSpikes, ops.PackedFrames)):
     return x, True
   if not isinstance(x, torch.Tensor):
     x = torch.as_tensor(x)

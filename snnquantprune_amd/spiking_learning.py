@@ -231,6 +231,13 @@ class SpikingBlock(nn.Module):
         return False
     return True
 
+  @staticmethod
+  def _event_layer_geometry(g: ops.ConvGeom) -> bool:
+    """What conv3x3_u8c2_kernel serves (snnqp.h, IMPL_MFMA): 3x3, stride 1, pad 1, Cin = 2."""
+    return (g.Cin == 2 and (g.KH, g.KW) == (3, 3) and tuple(g.stride) == (1, 1)
+            and tuple(map(tuple, g.pad)) == ((1, 1), (1, 1)) and tuple(g.in_dil) == (1, 1)
+            and tuple(g.k_dil) == (1, 1) and g.groups == 1)
+
   def __call__(self, u, inputs):
     if self.pool not in (1, 2):
       raise ValueError("pool must be 1 or 2")
@@ -272,6 +279,17 @@ class SpikingBlock(nn.Module):
       x = d.reshape(d.shape[0], d.shape[1], -1).contiguous()
     nrn = self.neural_dynamics.neuron(conn.features)
     bn = norm.coeffs(conn.features) if norm is not None else None
+
+    # Packed event frames (the host feed's wire formats): the fused 3x3 event layer stages
+    # bit-packed binary frames (EV1) directly; every other consumer -- nibble-packed count
+    # frames, other geometries, the float32 and direct-form kernels -- gets the uint8 frames
+    # back with one device pass.
+    if isinstance(x, ops.PackedFrames):
+      direct = (x.fmt == L.EV1 and not is_dense and w.wtype == L.W_I8
+                and self.impl != L.IMPL_GENERIC and x.ndim == 5
+                and self._event_layer_geometry(conn.geometry(tuple(x.shape[2:-1]), cin)))
+      if not direct:
+        x = ops.unpack_frames(x)
 
     # binary uint8 activations into a dense block (config C2's first layer): pack the bits
     # once so the int8-MFMA dense kernel serves it (it reads bit-packed rows)
@@ -317,6 +335,8 @@ class SpikingBlock(nn.Module):
       # what to expect -- no inspection pass, no read-back in front of the launch
       hint = ops.count_hint(x.device)
       x_max = hint.current()
+    elif isinstance(x, ops.PackedFrames):
+      x_max = 1                          # EV1: binary by construction
     else:
       x_max = ops.input_max_bound(x) if integer else 0
     impl = self.impl
@@ -412,6 +432,8 @@ class SpikingBlock(nn.Module):
   # -- arbitrary connection / norm / neuron: compose the stand-alone ops -----------
   def _composed(self, u, inputs):
     conn, norm, nrn_mod = self.connection_fn, self.norm_fn, self.neural_dynamics
+    if isinstance(inputs, ops.PackedFrames):
+      inputs = inputs.to_u8()
     if self.batch_major_input:
       inputs = inputs.transpose(0, 1)
     T = inputs.shape[0]

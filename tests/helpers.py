@@ -33,3 +33,22 @@ def packbits_lastaxis(s):
 
 def rate(s):
   return float(np.mean(np.asarray(s, dtype=np.float64)))
+
+
+def pack_ev1(x):
+  """uint8 0/1 frames [..., H, W, 2] -> uint32 words [..., ceil(H*W*2/32)]: the SNNQP_EV1
+  wire format of include/snnqp.h restated with a plain loop-free numpy expression (element
+  i = (y*W + x)*2 + p in bit i & 31 of word i >> 5)."""
+  x = np.asarray(x)
+  lead, n = x.shape[:-3], int(np.prod(x.shape[-3:]))
+  nw = (n + 31) // 32
+  flat = np.zeros(lead + (nw * 32,), np.uint64)
+  flat[..., :n] = x.reshape(lead + (n,))
+  w = (flat.reshape(lead + (nw, 32)) << np.arange(32, dtype=np.uint64)).sum(-1)
+  return w.astype(np.uint32)
+
+
+def pack_ev4(x):
+  """uint8 counts <= 15 [..., H, W, 2] -> uint8 [..., H*W] (SNNQP_EV4: polarity 0 low nibble)."""
+  x = np.asarray(x).astype(np.uint8)
+  return (x[..., 0] + 16 * x[..., 1]).astype(np.uint8).reshape(x.shape[:-3] + (-1,))

@@ -473,3 +473,173 @@ def test_bench_roofline_block_from_recorded_launch_times():
   # mixed precision: the peak is the time-weighted one of the launches
   outm = bench.rooflines_of(bench.parse(["--layer-bits", "2,4,8,4"]), prof, 1024, 20, [2, 4, 8, 4])
   assert 5000.0 < outm["roofline"]["peak"] < 10000.0
+
+
+# ---------------------------------------------------------------------------
+# eval harness (examples/eval.py:53-139): sharding, feed, metric reduction
+# ---------------------------------------------------------------------------
+
+_EVAL_WORKER = r"""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from snnquantprune_amd import eval as ev, linen as nn, parallel
+from snnquantprune_amd.train_utils import mse_loss
+
+class StandIn:      # stand-in for CextNet: logits a per-sample function of the frames
+  dtype = torch.float32
+  def init(self, rngs, x, **kw):
+    return {"params": {"scale": torch.tensor(1.0)}, "batch_stats": {}}
+  def apply(self, variables, x, trgt=None, train=False, online=False, rng=None, mutable=False,
+            rngs=None):
+    assert not train and mutable == ["batch_stats"]
+    if hasattr(x, "to_u8"):
+      raise AssertionError("CPU test feeds plain frames")
+    f = x.reshape(x.shape[0], -1).to(torch.float32)
+    logits = torch.stack([(f[:, k::11].sum(1) * variables["params"]["scale"]) for k in range(11)], 1)
+    return (logits / logits.sum(1, keepdim=True).clamp(min=1), None), {}
+
+cfg = nn.ConfigDict()
+cfg.seed, cfg.num_frames, cfg.num_classes = 1, 3, 11
+cfg.eval_batch_size, cfg.batch_size, cfg.steps_per_eval = %(bs)d, %(bs)d, %(steps)d
+cfg.smoothing, cfg.loss_fn, cfg.backend = 0.0, mse_loss, "gloo"
+cfg.dataset = %(data)r
+state, summary, per_step = ev.evaluate_metrics(cfg, %(workdir)r, model=StandIn(), device="cpu")
+rank = int(os.environ.get("RANK", "0"))
+if rank == 0:
+  print("SUMMARY " + json.dumps({"summary": summary,
+                                 "loss": per_step["loss"].tolist(),
+                                 "acc": per_step["accuracy"].tolist()}))
+if torch.distributed.is_initialized():
+  torch.distributed.barrier()
+  torch.distributed.destroy_process_group()
+"""
+
+
+def _eval_dataset(path, n=24, T=3, hw=6):
+  rng = np.random.Generator(np.random.PCG64(31))
+  x = (rng.random((n, T, hw, hw, 2)) < 0.3).astype(np.uint8)
+  y = rng.integers(0, 11, n).astype(np.int8)
+  np.savez(path, dvs_matrix=x, label=y)
+  return x, y
+
+
+def _eval_reference(x, y, world, bs, steps):
+  """What evaluate() must report, restated: process r owns samples [r * n // world, ...)
+  (input_pipeline.py:245-254), batches of bs // world, repeated; per-step per-rank mse loss
+  and per-sample accuracy, then the mean of each."""
+  from oracle import snn_oracle as o
+  n = len(y)
+  split, per = n // world, bs // world
+  nb = split // per
+  loss = np.zeros((steps, world)); acc = np.zeros((steps, world, per))
+  for r in range(world):
+    xs, ys = x[r * split:(r + 1) * split], y[r * split:(r + 1) * split]
+    for s in range(steps):
+      i = s % nb
+      xb, yb = xs[i * per:(i + 1) * per], ys[i * per:(i + 1) * per]
+      f = xb.reshape(per, -1).astype(np.float32)
+      logits = np.stack([f[:, k::11].sum(1) for k in range(11)], 1)
+      logits = logits / np.maximum(logits.sum(1, keepdims=True), 1)
+      m = o.compute_metrics(logits.astype(np.float32), yb)
+      loss[s, r], acc[s, r] = m["loss"], m["accuracy"]
+  return loss, acc
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_evaluate_shards_feeds_and_reduces_like_eval_py(tmp_path, world):
+  """evaluate() under 1 and 2 gloo processes on CPU: every rank restores / initialises, takes
+  its contiguous slice of the split, runs eval_step per batch through the (degenerate, CPU)
+  feeder, and the all-gathered per-step losses and per-sample accuracies equal the restated
+  reference loop; steps_per_eval = -1 covers the split once, a larger count wraps around."""
+  data = str(tmp_path / "frames.npz")
+  x, y = _eval_dataset(data)
+  for bs, steps in ((8, -1), (4, 7)):
+    script = tmp_path / ("worker_%d_%d.py" % (world, bs))
+    script.write_text(_EVAL_WORKER % dict(root=ROOT, bs=bs, steps=steps, data=data,
+                                          workdir=str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29640 + world * 4 + (bs == 4)),
+               WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o_ in zip(procs, outs):
+      assert p.returncode == 0, o_
+    line = [l for l in outs[0].splitlines() if l.startswith("SUMMARY ")][0]
+    got = json.loads(line[len("SUMMARY "):])
+    nsteps = len(y) // bs if steps == -1 else steps
+    eloss, eacc = _eval_reference(x, y, world, bs, nsteps)
+    np.testing.assert_allclose(np.asarray(got["loss"]), eloss, rtol=1e-6, atol=1e-7)   # float32 means
+    np.testing.assert_array_equal(np.asarray(got["acc"]), eacc)
+    assert got["summary"]["steps"] == nsteps and got["summary"]["world"] == world
+    assert got["summary"]["samples"] == nsteps * bs
+    assert abs(got["summary"]["accuracy"] - eacc.mean()) < 1e-6
+    assert abs(got["summary"]["loss"] - eloss.mean()) < 1e-6
+
+
+def test_evaluate_refuses_an_indivisible_batch(tmp_path):
+  from snnquantprune_amd import eval as ev, linen as nn
+  cfg = nn.ConfigDict()
+  cfg.eval_batch_size = 7
+  env_world = os.environ.get("WORLD_SIZE")
+  os.environ["WORLD_SIZE"] = "1"
+  try:
+    cfg.eval_batch_size = 0
+    data = str(tmp_path / "d.npz")
+    _eval_dataset(data, n=4)
+    cfg.dataset, cfg.steps_per_eval, cfg.seed, cfg.num_frames = data, 1, 0, 3
+    with pytest.raises(ValueError):
+      ev.evaluate_metrics(cfg, str(tmp_path), model=object(), device="cpu")
+  finally:
+    if env_world is None:
+      del os.environ["WORLD_SIZE"]
+    else:
+      os.environ["WORLD_SIZE"] = env_world
+  from snnquantprune_amd import parallel
+  with pytest.raises(ValueError, match="divisible"):
+    parallel.shard_bounds(10, 0, 4)
+
+
+def test_latest_checkpoint_picks_the_largest_step(tmp_path):
+  from snnquantprune_amd import eval as ev
+  assert ev.latest_checkpoint(str(tmp_path)) is None
+  for s in (2, 10, 9):
+    (tmp_path / ("checkpoint_%d" % s)).write_bytes(b"x")
+  (tmp_path / "checkpoint_11.tmp").write_bytes(b"x")
+  assert os.path.basename(ev.latest_checkpoint(str(tmp_path))) == "checkpoint_10"
+
+
+def test_packed_frame_formats_on_the_host():
+  """The host packers against the formats restated in tests/helpers.py, shapes, slicing and
+  the refusal of values a format cannot hold (no GPU involved)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  from tests.helpers import pack_ev1, pack_ev4
+  rng = np.random.Generator(np.random.PCG64(3))
+  for H, W in ((128, 128), (13, 17), (5, 3)):
+    x = (rng.random((2, 3, H, W, 2)) < 0.2).astype(np.uint8)
+    p = ops.pack_frames_host(x, L.EV1)
+    assert p.shape == x.shape and p.data.shape == (2, 3, (H * W * 2 + 31) // 32)
+    np.testing.assert_array_equal(p.data.numpy().view(np.uint32), pack_ev1(x))
+    np.testing.assert_array_equal(p[1].data.numpy().view(np.uint32), pack_ev1(x[1]))
+    np.testing.assert_array_equal(p.narrow(0, 1, 1).data.numpy().view(np.uint32), pack_ev1(x[1:2]))
+    c = np.minimum(rng.poisson(2.0, (2, 3, H, W, 2)), 15).astype(np.uint8)
+    q = ops.pack_frames_host(c, L.EV4)
+    assert q.data.shape == (2, 3, H * W)
+    np.testing.assert_array_equal(q.data.numpy(), pack_ev4(c))
+    with pytest.raises(ValueError):
+      ops.pack_frames_host(c + 1 if c.max() == 15 else np.full_like(c, 16), L.EV4)
+    with pytest.raises(ValueError):
+      ops.pack_frames_host(np.full_like(x, 2), L.EV1)
+  assert ops.frame_units(128, 128, L.EV1) * 4 == 4096 and ops.frame_units(128, 128, L.EV4) == 16384
+
+
+def test_feeder_on_cpu_is_the_plain_iterator():
+  from snnquantprune_amd import feed
+  batches = [{"dvs_matrix": np.full((2, 3), i, np.uint8), "label": torch.tensor([i, i])} for i in range(5)]
+  f = feed.DeviceFeeder(iter(batches), "cpu", 2)
+  got = list(f)
+  assert len(got) == 5 and f.batches == 5
+  for i, b in enumerate(got):
+    assert int(np.asarray(b["dvs_matrix"]).max()) == i

@@ -1839,3 +1839,198 @@ def test_model_captured_into_a_graph_then_called_eagerly(dev, oracle):
   graph.replay()
   torch.cuda.synchronize()
   np.testing.assert_array_equal(_np(static), e["logits"])
+
+
+# ---------------------------------------------------------------------------
+# packed event frames (the host feed's wire formats, snnqp.h SNNQP_EV1 / SNNQP_EV4)
+# ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (13, 17), (34, 34), (5, 3)])
+def test_packed_frames_round_trip(dev, hw):
+  """EV1 / EV4: the host packer (numpy), the device packer and the format restated in
+  tests/helpers.py agree word for word; unpack inverts pack; values a format cannot hold
+  are saturated and flagged on the device, refused on the host.  Frame sizes whose bit
+  count is not a multiple of 32 included."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  from tests.helpers import pack_ev1, pack_ev4
+  H, W = hw
+  rng = np.random.Generator(np.random.PCG64(H * 100 + W))
+  binary = (rng.random((3, 4, H, W, 2)) < 0.3).astype(np.uint8)
+  counts = np.minimum(rng.poisson(1.5, (3, 4, H, W, 2)), 15).astype(np.uint8)
+  for fmt, x, ref in ((L.EV1, binary, pack_ev1(binary)), (L.EV4, counts, pack_ev4(counts)),
+                      (L.EV4, binary, pack_ev4(binary))):
+    host = ops.pack_frames_host(x, fmt)
+    devp = ops.pack_frames(_t(x, dev), fmt)
+    view = (lambda t: t.cpu().numpy().view(np.uint32)) if fmt == L.EV1 else (lambda t: t.cpu().numpy())
+    np.testing.assert_array_equal(view(host.data), ref)
+    np.testing.assert_array_equal(view(devp.data), ref)
+    assert host.shape == devp.shape == x.shape
+    np.testing.assert_array_equal(_np(ops.unpack_frames(devp)), x)
+    np.testing.assert_array_equal(_np(ops.unpack_frames(host.to(dev))), x)
+    np.testing.assert_array_equal(_np(devp[1].to_u8()), x[1])          # leading-axis indexing
+  # overflow: saturate + flag on the device, raise on the host
+  big = counts.copy()
+  big[1, 2, H // 2, W // 2, 1] = 77
+  for fmt, flag, sat in ((L.EV1, L.FLAG_GT_ONE, 1), (L.EV4, L.FLAG_GT_15, 15)):
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    p = ops.pack_frames(_t(big, dev), fmt, flags)
+    assert int(flags.item()) == flag
+    np.testing.assert_array_equal(_np(ops.unpack_frames(p)), np.minimum(big, sat))
+    with pytest.raises(ValueError):
+      ops.pack_frames_host(big, fmt)
+  flags = torch.zeros(1, dtype=torch.int32, device=dev)
+  ops.pack_frames(_t(binary, dev), L.EV1, flags)
+  assert int(flags.item()) == 0
+
+
+@pytest.mark.parametrize("hw,T", [((16, 16), 9), ((24, 24), 40), ((13, 17), 5), ((34, 34), 20)])
+def test_event_layer_stages_bit_packed_frames(dev, oracle, hw, T):
+  """conv0 on EV1 frames (1 bit per element, staged directly: one halo row = 20 bits out of
+  two words) against the oracle and against the same launch on uint8 frames: rasters and
+  final potentials bit-equal, with and without the 2x2 pool, with a carried-in state, with
+  4-bit codes (per-channel tables), 8-bit codes (shared table) and with no table at all
+  (unknown accumulator bound: the general x - 128 path); image sizes that are not multiples
+  of 8 or whose rows do not start on a word boundary; batch-major and time-major."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  H, W = hw
+  B = 3
+  rng = np.random.Generator(np.random.PCG64(T * 1000 + H))
+  x = (rng.random((T, B, H, W, 2)) < 0.12).astype(np.uint8)
+  x[:, :, 0, 0, :] = 1                         # image corners: the masks of edge patches
+  x[:, :, H - 1, W - 1, :] = 1
+  x[:, :, 0, W - 1, 0] = 1
+  u0 = (rng.random((B, H, W, 128)) * 0.6).astype(F32)
+  g = ops.ConvGeom(H, W, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  nrn = _mslif()
+  for bits, notable in ((4, False), (8, False), (8, True)):
+    c = cases.conv_block_case(T=2, B=1, hw=8, cin=2, bits=bits, seed=961 + bits, gain=4.0)
+    qw = qweight_of(oracle, c["leaf"], bits)
+    w = _weight(c["leaf"], bits, dev, transposed=True)
+    if notable:
+      w = dataclasses.replace(w, abs_sum_max=0, min_current_bits=0)
+    bn = _bn(c["bn"], dev)
+    for carry in (None, u0):
+      eu, es = oracle.conv_block(x, qw, c["bn"], None, "int", u0=carry)
+      assert 0.01 < es.mean() < 0.6
+      for pool in (1, 2) if H % 2 == 0 and W % 2 == 0 else (1,):
+        exp = packbits_lastaxis(oracle.max_pool_2x2(es) if pool == 2 else es)
+        kw = dict(bn=bn, u0=None if carry is None else _t(carry, dev), want_u=True,
+                  packed_out=True, pool=pool, impl=L.IMPL_MFMA, x_max=1)
+        tag = "bits %d notable %s carry %s pool %d" % (bits, notable, carry is not None, pool)
+        u8_u, u8_s = ops.conv_lif_forward(_t(x, dev), g, w, nrn, **kw)
+        pf = ops.pack_frames(_t(x, dev), L.EV1)
+        ev_u, ev_s = ops.conv_lif_forward(pf, g, w, nrn, **kw)
+        np.testing.assert_array_equal(_np(ev_s), exp, err_msg=tag)
+        np.testing.assert_array_equal(_np(ev_u), eu, err_msg=tag)
+        np.testing.assert_array_equal(_np(u8_s), exp, err_msg=tag)
+        # batch-major frames [B, T, words], as the model's input arrives
+        pfb = ops.pack_frames(_t(np.ascontiguousarray(np.swapaxes(x, 0, 1)), dev), L.EV1)
+        bm_u, bm_s = ops.conv_lif_forward(pfb, g, w, nrn, time_major=False, **kw)
+        np.testing.assert_array_equal(_np(bm_s), exp, err_msg=tag + " batch-major")
+        np.testing.assert_array_equal(_np(bm_u), eu, err_msg=tag + " batch-major")
+
+
+def test_models_take_packed_frames(dev, oracle):
+  """model.apply on PackedFrames -- EV1 (binary, staged directly by the event layer) and EV4
+  (counts, unpacked on the device first) -- gives the logits of the uint8 input and of the
+  oracle: the C3 topology and the full CextNet."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.conv_net_case()
+  e = cases.conv_net_expected(oracle, c)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  host = ops.pack_frames_host(c["x"], L.EV1)             # packed on the host, shipped as is
+  for inp in (host.to(dev), ops.pack_frames(_t(c["x"], dev), L.EV1),
+              ops.pack_frames(_t(c["x"], dev), L.EV4), _t(c["x"], dev)):
+    (logits, _), mut = model.apply(variables, inp, trgt=None, train=False, rng=None,
+                                   mutable=["intermediates"])
+    np.testing.assert_array_equal(_np(logits), e["logits"])
+    np.testing.assert_array_equal(_np(mut["intermediates"]["pool0"][0]), e["pool0_bits"])
+  cc = cases.conv_net_case(counts=True)
+  ec = cases.conv_net_expected(oracle, cc)
+  vc = nn.tree_from_numpy(cc["vars"], dev)
+  assert 1 < int(cc["x"].max()) <= 15
+  (logits, _) = model.apply(vc, ops.pack_frames_host(cc["x"], L.EV4).to(dev), trgt=None,
+                            train=False, rng=None)
+  np.testing.assert_array_equal(_np(logits), ec["logits"])
+  ct = cases.cextnet_case()
+  et = cases.cextnet_expected(oracle, ct)
+  net = models.CextNet(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  vt = nn.tree_from_numpy(ct["vars"], dev)
+  (logits, _) = net.apply(vt, ops.pack_frames_host(ct["x"], L.EV1).to(dev), trgt=None, train=False,
+                          rng=None)
+  np.testing.assert_array_equal(_np(logits), et["logits"])
+
+
+def test_feeder_hands_over_every_batch_in_order(dev):
+  """feed.DeviceFeeder on the GPU: 12 batches through a ring of 4 device buffers (depth 2),
+  pinned and unpinned sources, a consumer that keeps using batch k while k + 1 and k + 2
+  are copied: every batch arrives intact and in order, and a batch stays valid until the
+  next one has been asked for."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import feed, ops
+  rng = np.random.Generator(np.random.PCG64(9))
+  frames = [(rng.random((4, 3, 16, 16, 2)) < 0.3).astype(np.uint8) for _ in range(12)]
+
+  def source(pin, packed):
+    for i, f in enumerate(frames):
+      v = ops.pack_frames_host(f, L.EV1) if packed else f
+      yield {"dvs_matrix": feed.pinned_like(v) if pin else v, "label": np.full((4,), i, np.int8)}
+  for pin in (True, False):
+    for packed in (True, False):
+      f = feed.DeviceFeeder(source(pin, packed), dev, 2)
+      sums = []
+      for i, b in enumerate(f):
+        x = b["dvs_matrix"]
+        u8 = x.to_u8() if packed else x
+        # a long-running consumer of this batch: the copies of the next two overlap it
+        acc = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(20):
+          acc = acc + u8.to(torch.int64).sum()
+        sums.append((acc, int(b["label"][0].item())))
+        np.testing.assert_array_equal(_np(u8), frames[i])
+      assert [s[1] for s in sums] == list(range(12))
+      for i, (acc, _) in enumerate(sums):
+        assert int(acc.item()) == 20 * int(frames[i].sum())
+      assert f.batches == 12 and f.bytes_copied > 0
+
+
+def test_evaluate_restores_feeds_and_scores_like_the_oracle(dev, oracle, tmp_path, golden_dir):
+  """eval.evaluate_metrics (examples/eval.py:53-139) end to end on the GPU: a Flax checkpoint
+  file in the workdir -> restore -> the split through the feeder (uint8 and bit-packed
+  frames) -> eval_step per batch -> mean loss / accuracy, against the oracle's logits and
+  metrics on the same samples."""
+  from snnquantprune_amd import checkpoint, eval as ev, linen as nn
+  from snnquantprune_amd import synthetic as syn
+  from snnquantprune_amd.train_utils import mse_loss
+  c = cases.conv_net_case(B=8)
+  rng = np.random.Generator(np.random.PCG64(12))
+  labels = rng.integers(0, 11, 8).astype(np.int8)
+  state = {"step": np.int32(3), "params": {"params": c["vars"]["params"]},
+           "batch_stats": c["vars"]["batch_stats"]}
+  (tmp_path / "checkpoint_3").write_bytes(checkpoint.msgpack_serialize(state))
+  (tmp_path / "checkpoint_1").write_bytes(b"stale")
+  data = str(tmp_path / "frames.npz")
+  np.savez(data, dvs_matrix=c["x"], label=labels)
+  e = cases.conv_net_expected(oracle, c)
+  want = [oracle.compute_metrics(e["logits"][i * 4:(i + 1) * 4], labels[i * 4:(i + 1) * 4])
+          for i in range(2)]
+  for fmt in ("u8", "ev1"):
+    cfg = syn.make_config(bits=4, prune_percentage=0.9)
+    cfg.model, cfg.dataset, cfg.feed_format = "ConvDenseSNN", data, fmt
+    cfg.eval_batch_size, cfg.batch_size, cfg.steps_per_eval = 4, 4, -1
+    cfg.loss_fn, cfg.smoothing = mse_loss, 0.0
+    state, summary, per_step = ev.evaluate_metrics(cfg, str(tmp_path), device=dev)
+    assert summary["steps"] == 2 and summary["samples"] == 8
+    np.testing.assert_array_equal(per_step["accuracy"].numpy().reshape(2, 4),
+                                  np.stack([w["accuracy"] for w in want]).astype(np.float32))
+    np.testing.assert_allclose(per_step["loss"].numpy().reshape(2), [w["loss"] for w in want],
+                               rtol=1e-6)
+    assert abs(summary["accuracy"] - np.mean([w["accuracy"].mean() for w in want])) < 1e-6
+    assert "QuantConv_0" in state.params["params"]
