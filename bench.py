@@ -443,13 +443,11 @@ def main(argv=None):
       ops.profile_start()
   if args.graph:
     assert gpu and ops is not None and args.warmup > 0, "--graph needs a GPU and a warm-up step"
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):        # every launch of model.apply, on the capture stream
-      static_logits = apply_fn(x)
+    # the product API: nn.capture records model.apply once (linen.CapturedApply)
+    captured = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
 
     def step():                          # noqa: F811  (the timed steps replay the graph)
-      graph.replay()
-      return parallel.all_gather_rows(static_logits)
+      return parallel.all_gather_rows(captured()[0])
     out = step()
     fence()
   fed_b0 = feeder.bytes_copied if feeder is not None else 0

@@ -104,6 +104,9 @@ typedef struct {
                         * max of sum_k |code| is valid too.  0 = unknown */
   int32_t code_max;    /* W_I8: max |code|; 0 = unknown.  Codes of magnitude <= 7 are
                           exact in fp6 (e2m3) and may take the f8f6f4 MFMA */
+  const int32_t *col_sum; /* W_I8, dense layers, nullable: device int32 [N], sum over k of the
+                          codes of each output feature.  Lets the MFMA dense kernel read
+                          uint8 rows as x - 128 (any count 0..255) and add 128 * col_sum back */
   uint32_t min_current_bits; /* float32 bits of the smallest non-zero |input current| the block
                           can see with the BatchNorm it is used with -- snnqp_current_min()
                           with bound = abs_sum_max (bit-packed inputs);
@@ -266,6 +269,14 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            float *u_out, void *s_out, int s_type, int pool,
                            int impl, int x_max, int32_t *x_seen, snnqp_stream_t stream);
 
+/* Blocks that SNNQP_IMPL_AUTO handed to the direct-form kernel since the library was loaded
+ * (or the last reset): it serves every geometry and type, 20-25 x slower than the MFMA kernels.
+ * `reason` (nullable, reason_len bytes) receives why the last one fell back, e.g.
+ * "conv: bit input needs Cin <= 128".  With SNNQP_LOG_FALLBACKS set in the environment every
+ * new reason is also printed to stderr.  No reference counterpart (diagnostic). */
+int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *reason,
+                          int32_t reason_len, int reset);
+
 /* Smallest non-zero |BatchNorm_c(fl(fl(acc / L) * m))| over |acc| <= bound and the Cout
  * channels (bn nullable: identity), as float32 bits, atomically min-ed into *out_bits
  * (device word the caller initialises to 0x7F800000).  For snnqp_weight_t.min_current_bits:
@@ -276,8 +287,10 @@ int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bou
 /* Same for QuantDense: x [T][B][K], weights [K][N] (GENERIC) .
  * IMPL_MFMA additionally needs `wt`: the int8 codes tiled by
  * snnqp_pack_codes_mfma (Npad = N rounded up to 32; K rows zero-padded to a multiple
- * of 32 when K is not one), BITS input (zero bits beyond K),
- * T <= 96 (longer runs: the direct-form kernel), s_type BITS. */
+ * of 32 when K is not one), s_type BITS and either BITS input (zero bits beyond K),
+ * T <= 96, or U8 input (any count 0..255, read in place: no packing pass, no inspection)
+ * with w->col_sum, K % 16 == 0, K <= 65536, 16-byte aligned rows and T <= 64.  Longer runs
+ * and everything else: the direct-form kernel. */
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,

@@ -31,7 +31,8 @@ OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 
 class WeightT(Structure):
   _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
-              ("abs_sum_max", c_int32), ("code_max", c_int32), ("min_current_bits", c_uint32)]
+              ("abs_sum_max", c_int32), ("code_max", c_int32), ("col_sum", c_void_p),
+              ("min_current_bits", c_uint32)]
 
 
 BN_MEAN_ZERO, BN_BIAS_ZERO = 1, 2
@@ -84,6 +85,7 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
         c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "snnqp_fallback_counts": (c_int, [POINTER(c_int64), POINTER(c_int64), c_char_p, c_int32, c_int]),
     "snnqp_current_min": (c_int, [POINTER(WeightT), POINTER(BnT), c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_lif_forward": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(BnT),
                                   POINTER(NeuronT), c_void_p, c_void_p, c_void_p,

@@ -3,9 +3,52 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
 using namespace snnqp;
 
+// A block that IMPL_AUTO hands to the direct-form kernel runs 20-25 x slower than on the MFMA
+// kernels (one thread per output neuron): counted, with the reason, so that a caller (and
+// bench.py's JSON line) can see the cliff instead of guessing at it.
+namespace {
+std::atomic<int64_t> g_fallback_conv{0}, g_fallback_dense{0};
+std::mutex g_fallback_mu;
+char g_fallback_reason[256] = "";
+
+void note_fallback(bool dense, const char *why) {
+  (dense ? g_fallback_dense : g_fallback_conv).fetch_add(1, std::memory_order_relaxed);
+  static const bool log = std::getenv("SNNQP_LOG_FALLBACKS") != nullptr;
+  std::lock_guard<std::mutex> lock(g_fallback_mu);
+  const bool fresh = std::strncmp(g_fallback_reason + (dense ? 7 : 6), why ? why : "", 200) != 0;
+  std::snprintf(g_fallback_reason, sizeof(g_fallback_reason), "%s%s", dense ? "dense: " : "conv: ",
+                why ? why : "");
+  if (log && fresh)
+    std::fprintf(stderr, "libsnnqp: %s block on the direct-form kernel: %s\n",
+                 dense ? "dense" : "conv", why ? why : "");
+}
+}  // namespace
+
 extern "C" {
+
+int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *reason,
+                          int32_t reason_len, int reset) {
+  if (conv_blocks) *conv_blocks = g_fallback_conv.load(std::memory_order_relaxed);
+  if (dense_blocks) *dense_blocks = g_fallback_dense.load(std::memory_order_relaxed);
+  std::lock_guard<std::mutex> lock(g_fallback_mu);
+  if (reason && reason_len > 0) {
+    std::strncpy(reason, g_fallback_reason, (size_t)reason_len - 1);
+    reason[reason_len - 1] = 0;
+  }
+  if (reset) {
+    g_fallback_conv = 0;
+    g_fallback_dense = 0;
+    g_fallback_reason[0] = 0;
+  }
+  return SNNQP_OK;
+}
 
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
@@ -33,6 +76,7 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
   SNNQP_REQUIRE(pool == 1, SNNQP_EUNSUPPORTED,
                 "conv_lif_forward: the direct-form kernel does not fuse the "
                 "max-pool; call snnqp_maxpool2x2 after it");
+  if (impl == SNNQP_IMPL_AUTO) note_fallback(false, why);
   return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, g, w, bn, nrn, u0,
                      u_out, s_out, s_type, nullptr, (hipStream_t)stream);
 }
@@ -57,7 +101,11 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
   SNNQP_REQUIRE(impl >= SNNQP_IMPL_AUTO && impl <= SNNQP_IMPL_MFMA, SNNQP_EINVAL,
                 "dense_lif_forward: unknown impl %d", impl);
   const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
-  if (!why && T > 96) why = "more than 96 timesteps (one sample must fit a row tile)";
+  if (!why && T > (in_type == SNNQP_U8 ? 64 : 96))
+    why = "more than 96 (uint8 input: 64) timesteps (one sample must fit a row tile)";
+  if (!why && in_type == SNNQP_U8 &&
+      ((((uintptr_t)x) & 15) != 0 || x_stride_t % 16 != 0 || x_stride_b % 16 != 0))
+    why = "uint8 rows not 16-byte aligned";
   // the fused kernel addresses the rows of one workgroup (at most 96 samples) with 32-bit
   // word offsets from the workgroup's first sample
   if (!why && ((int64_t)(T > 0 ? T - 1 : 0) * x_stride_t + 96 * x_stride_b + (K + 31) / 32 >= ((int64_t)1 << 31) ||
@@ -66,8 +114,9 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
   if (impl == SNNQP_IMPL_MFMA)
     SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "dense_lif_forward: MFMA kernel: %s", why);
   if (!why && impl != SNNQP_IMPL_GENERIC)
-    return run_dense_mfma(x, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn,
+    return run_dense_mfma(x, in_type, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn,
                           u0, u_out, (uint32_t *)s_out, (hipStream_t)stream);
+  if (impl == SNNQP_IMPL_AUTO) note_fallback(true, why);
   snnqp_conv_geom_t g;
   g.H = 1; g.W = 1; g.Cin = K; g.Cout = N; g.KH = 1; g.KW = 1;
   g.stride_h = g.stride_w = 1;

@@ -1,6 +1,11 @@
 // Fused SpikingBlock(QuantDense, neuron) (spiking_learning.py:446-462 with
 // flax_qdense.py:87 as the connection) on int8 MFMA: bit-packed spikes x int8
 // codes -> int32 -> dequantise -> [BatchNorm] -> neuron over T -> packed spikes.
+// A second instantiation (IN = SNNQP_U8) reads uint8 rows as they are -- the [B, T, K]
+// event-count input of a dense-only model (config C2) -- with no packing pass and no
+// inspection of the values: a byte x enters the MFMA as the int8 x - 128 (x ^ 0x80, exact
+// for every count 0..255) and 128 * sum_k w[k][n] (snnqp_weight_t.col_sum) is added back to
+// the int32 accumulator.
 //
 // The connection is stateless across t, so the contraction is one GEMM over
 // rows m = (sample, t); only the neuron is sequential:
@@ -20,6 +25,8 @@
 //  * after the K loop the int32 tile goes through LDS once so that each thread
 //    gets the T currents of one (sample, feature) pair in order, runs the
 //    neuron with u in a register and ballots the spikes into 32-bit words.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace snnqp {
@@ -31,8 +38,9 @@ constexpr int BK = 256;          // k per chunk (bytes per LDS row)
 constexpr int KSC = BK / 32;     // MFMA k-steps per chunk
 
 struct DenseMfmaArgs {
-  const uint32_t *x;
-  int64_t xs_t, xs_b;            // word strides
+  const uint32_t *x;             // bit-packed rows (words) or uint8 rows (bytes)
+  const int32_t *col_sum;        // U8 input: sum over k of the codes of each feature
+  int64_t xs_t, xs_b;            // word (bits) / byte (u8) strides
   int32_t T, B, K, N, KS, SB;    // KS = ceil(K / 32), SB samples per workgroup
   const int8_t *wt;              // MFMA-tiled codes [Npad/32][KS][64][16]
   Dequant dq;
@@ -66,11 +74,15 @@ __device__ __forceinline__ int a_addr(int row, int c16) {
 
 constexpr int KGROUPS = 2;       // wave groups splitting K
 
-template <int RT>
+template <int RT, int IN>
 __global__ void __launch_bounds__(256 * KGROUPS)
 dense_mfma_kernel(DenseMfmaArgs a) {
+  constexpr bool U8 = IN == SNNQP_U8;
   constexpr int ROWS = RT * 32;
-  constexpr int WPR = BK / 32;                    // words per row per chunk
+  // staging tasks of a row and chunk: one 32-bit spike word -> 32 bytes, or one 16-byte piece
+  // of uint8 counts -> the same 16 bytes ^ 0x80
+  constexpr int WPR = U8 ? BK / 16 : BK / 32;
+  typedef typename std::conditional<U8, v4i, uint32_t>::type stg_t;
   constexpr int NTASK = ROWS * WPR;
   constexpr int TPT = (NTASK + 255) / 256;
   // two A buffers per group; the epilogue tile (ROWS x 128 int32) overlays them
@@ -100,16 +112,18 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   // Global loads run D - 1 chunks ahead of their use, in rings of D register sets (spike
   // words and B fragments): a chunk of MFMAs is about 0.3 us of a wave, a loaded global round
   // trip several times that -- with one chunk of lookahead the K loop ran at the pace of the
-  // memory latency, not of the matrix pipe or of LDS.
-  constexpr int D = 4;
+  // memory latency, not of the matrix pipe or of LDS.  (uint8 rows stage four times the
+  // registers per chunk: one chunk less of lookahead.)
+  constexpr int D = U8 ? 3 : 4;
   constexpr int U = D % 2 ? 2 * D : D;             // unroll: ring slot i % D, LDS buffer i & 1
-  uint32_t stgr[D][TPT];
+  stg_t stgr[D][TPT];
   // staging tasks: word wi of row `row`, the same (row, wi) for every chunk.  The loads of the
   // K loop are unconditional (clamped addresses, the value dropped afterwards): with loads
   // under lane masks the compiler falls back to s_waitcnt vmcnt(0), which drains the ring.
-  uint32_t roff[TPT];                              // word offset within this workgroup's samples
+  uint32_t roff[TPT];                              // word / byte offset within this workgroup's samples
   uint32_t rmask[TPT];
-  const uint32_t *xw = a.x + (int64_t)b0 * a.xs_b;
+  const uint32_t *xw = a.x + (U8 ? 0 : (int64_t)b0 * a.xs_b);
+  const uint8_t *xbytes = (const uint8_t *)a.x + (U8 ? (int64_t)b0 * a.xs_b : 0);
 #pragma unroll
   for (int k = 0; k < TPT; ++k) {
     const int task = tid + k * 256;
@@ -123,22 +137,39 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     }
   }
   auto chunk_word = [&](int chunk, int k) { return (chunk * KGROUPS + grp) * WPR + (tid + k * 256) % WPR; };
-  auto stage_load = [&](uint32_t (&stg)[TPT], int chunk) {
+  // uint8: 16-byte piece `chunk_word` of the row; K is a multiple of 16 (launch check), pieces
+  // beyond K re-read the row's first one (they meet the zero codes the tiles are padded with,
+  // and so do the rows beyond `rows`: nothing of a uint8 row needs masking)
+  auto stage_load1 = [&](int chunk, int k) -> stg_t {
+    if constexpr (U8) {
+      const int piece = chunk_word(chunk, k);
+      return *(const v4i *)(xbytes + roff[k] + (uint32_t)(piece * 16 < a.K ? piece * 16 : 0));
+    } else {
+      return xw[roff[k] + (uint32_t)min(chunk_word(chunk, k), a.KS - 1)];
+    }
+  };
+  auto stage_load = [&](stg_t (&stg)[TPT], int chunk) {
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) stg[k] = xw[roff[k] + (uint32_t)min(chunk_word(chunk, k), a.KS - 1)];
+    for (int k = 0; k < TPT; ++k) stg[k] = stage_load1(chunk, k);
   };
   // the words of dead rows and of k beyond K are zeroed here, by masks (a select next to the
   // load would put its wait there)
-  auto stage_store = [&](const uint32_t (&stg)[TPT], int chunk, int buf) {
+  auto stage_store = [&](const stg_t (&stg)[TPT], int chunk, int buf) {
     uint8_t *base = abuf + buf * ABYTES;
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
       const int task = tid + k * 256;
       if (task < NTASK) {
         const int row = task / WPR, wi = task % WPR;
-        const uint32_t wv = stg[k] & rmask[k] & (uint32_t)((chunk_word(chunk, k) - a.KS) >> 31);
-        *(v4i *)(base + a_addr(row, wi * 2)) = expand16b(wv & 0xFFFFu);
-        *(v4i *)(base + a_addr(row, wi * 2 + 1)) = expand16b(wv >> 16);
+        if constexpr (U8) {
+          const v4i v = stg[k];
+          *(v4i *)(base + a_addr(row, wi)) = v4i{v.x ^ (int)0x80808080, v.y ^ (int)0x80808080,
+                                                 v.z ^ (int)0x80808080, v.w ^ (int)0x80808080};
+        } else {
+          const uint32_t wv = stg[k] & rmask[k] & (uint32_t)((chunk_word(chunk, k) - a.KS) >> 31);
+          *(v4i *)(base + a_addr(row, wi * 2)) = expand16b(wv & 0xFFFFu);
+          *(v4i *)(base + a_addr(row, wi * 2 + 1)) = expand16b(wv >> 16);
+        }
       }
     }
   };
@@ -165,9 +196,12 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   // third of the time), whichever way the two waves of a SIMD were phased.
   constexpr int NSLOT = KSC * RT;
   constexpr int PF = 3;                               // A fragments in flight
-  constexpr int NPIECE = TPT * 8;                     // dwords the thread expands per chunk
+  constexpr int LSTEP = NSLOT / TPT;                  // slots between two staging loads
+  static_assert(NSLOT % TPT == 0 && LSTEP >= 2, "one staging load every LSTEP slots");
+  constexpr int PPT = U8 ? 4 : 8;                     // dwords a staging task expands to
+  constexpr int NPIECE = TPT * PPT;                   // dwords the thread expands per chunk
   // loop-invariant LDS offsets: fragment reads (per k-step; row tile and buffer are immediates)
-  // and the two 16-byte stores of each staging task
+  // and the 16-byte stores of each staging task
   int rd_off[KSC];
 #pragma unroll
   for (int ks = 0; ks < KSC; ++ks) rd_off[ks] = a_addr(n, ks * 2 + h);
@@ -176,21 +210,23 @@ dense_mfma_kernel(DenseMfmaArgs a) {
   for (int k = 0; k < TPT; ++k) {
     const int task = tid + k * 256;
     const int row = task < NTASK ? task / WPR : 0, wi = task % WPR;
-    wr_off[k][0] = a_addr(row, wi * 2);
-    wr_off[k][1] = a_addr(row, wi * 2 + 1);
+    wr_off[k][0] = U8 ? a_addr(row, wi) : a_addr(row, wi * 2);
+    wr_off[k][1] = U8 ? 0 : a_addr(row, wi * 2 + 1);
   }
   auto frag = [&](int rbuf, int s) -> v4i {
     return *(const v4i *)(abuf + rbuf * ABYTES + (s % RT) * 32 * BK + rd_off[s / RT]);
   };
-  auto fused_chunk = [&](int rbuf, const v4i (&bf)[KSC], uint32_t (&ld_stg)[TPT], v4i (&ld_bf)[KSC],
-                         int ld_chunk, const uint32_t (&st_stg)[TPT], int st_chunk) {
+  auto fused_chunk = [&](int rbuf, const v4i (&bf)[KSC], stg_t (&ld_stg)[TPT], v4i (&ld_bf)[KSC],
+                         int ld_chunk, const stg_t (&st_stg)[TPT], int st_chunk) {
     v4i av[PF + 1];
 #pragma unroll
     for (int s = 0; s < PF; ++s) av[s] = frag(rbuf, s);
-    uint32_t wv[TPT];
+    stg_t wv[TPT];
 #pragma unroll
-    for (int k = 0; k < TPT; ++k)
-      wv[k] = st_stg[k] & rmask[k] & (uint32_t)((chunk_word(st_chunk, k) - a.KS) >> 31);
+    for (int k = 0; k < TPT; ++k) {
+      if constexpr (U8) wv[k] = st_stg[k];
+      else wv[k] = st_stg[k] & rmask[k] & (uint32_t)((chunk_word(st_chunk, k) - a.KS) >> 31);
+    }
     v4i ex = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
@@ -205,22 +241,30 @@ dense_mfma_kernel(DenseMfmaArgs a) {
         const int kg = min((ld_chunk * KGROUPS + grp) * KSC + ks, a.KS - 1);
         ld_bf[ks] = (wtile + (int64_t)kg * 64)[lane];
       }
-      if (s % KSC == 1 && s / KSC < TPT) {
-        const int k = s / KSC;
-        ld_stg[k] = xw[roff[k] + (uint32_t)min(chunk_word(ld_chunk, k), a.KS - 1)];
+      if (s % LSTEP == 1 && s / LSTEP < TPT) {
+        const int k = s / LSTEP;
+        ld_stg[k] = stage_load1(ld_chunk, k);
       }
       // expansion pieces p with p * NSLOT / NPIECE == s
 #pragma unroll
       for (int p = 0; p < NPIECE; ++p) {
         if (p * NSLOT / NPIECE == s) {
-          const int k = p / 8, hf = (p / 4) & 1, d = p & 3;
+          const int k = p / PPT, d = p & 3;
           // the word passes through an empty volatile asm in every slot that expands a piece
           // of it: the piece cannot be computed before its slot (sched_barrier alone orders
           // instructions, not the values they were selected from)
-          asm volatile("" : "+v"(wv[k]));
-          ex[d] = (int)((((wv[k] >> (16 * hf + 4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u);
-          if (d == 3 && tid + k * 256 < NTASK)
-            *(v4i *)(abuf + (rbuf ^ 1) * ABYTES + wr_off[k][hf]) = ex;
+          if constexpr (U8) {
+            asm volatile("" : "+v"(wv[k]));
+            ex[d] = wv[k][d] ^ (int)0x80808080;
+            if (d == 3 && tid + k * 256 < NTASK)
+              *(v4i *)(abuf + (rbuf ^ 1) * ABYTES + wr_off[k][0]) = ex;
+          } else {
+            const int hf = (p / 4) & 1;
+            asm volatile("" : "+v"(wv[k]));
+            ex[d] = (int)((((wv[k] >> (16 * hf + 4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u);
+            if (d == 3 && tid + k * 256 < NTASK)
+              *(v4i *)(abuf + (rbuf ^ 1) * ABYTES + wr_off[k][hf]) = ex;
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -273,7 +317,9 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     const int feat = blockIdx.y * 128 + col;
     const bool live = bl < nsamp && feat < a.N;
     float bmean = 0.f, bmul = 1.f, bbias = 0.f, dec = 0.f, u = 0.0f;
+    int off = 0;                       // uint8 input: 128 * sum_k w[k][feat] (the x - 128 operand)
     if (live) {
+      if (U8) off = 128 * a.col_sum[feat];
       if (a.bn.mean) { bmean = a.bn.mean[feat]; bmul = a.bn.mul[feat]; bbias = a.bn.bias[feat]; }
       if (a.nrn.kind == SNNQP_NEURON_LIF) dec = a.nrn.decay[feat];
       if (a.u0) u = a.u0[(int64_t)(b0 + bl) * a.N + feat];
@@ -281,7 +327,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     for (int t = 0; t < a.T; ++t) {
       bool s = false;
       if (live) {
-        float cur = dequant_acc(et[(bl * a.T + t) * 128 + col], a.dq);
+        float cur = dequant_acc(et[(bl * a.T + t) * 128 + col] + off, a.dq);
         if (a.bn.mean) cur = bn_apply(cur, bmean, bmul, bbias);
         s = neuron_step(u, cur, a.nrn, dec);
       }
@@ -302,20 +348,26 @@ const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
                                    const snnqp_neuron_t *nrn, int s_type) {
   if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
   if (!wt) return "MFMA-tiled codes `wt` not given";
-  if (in_type != SNNQP_BITS) return "input must be bit-packed";
+  if (in_type != SNNQP_BITS && in_type != SNNQP_U8) return "input must be bit-packed or uint8";
   if (s_type != SNNQP_BITS) return "spike output must be bit-packed";
-  (void)K;   // any K: the tiles `wt` are zero-padded to ceil(K / 32) k-steps and the packed
-             // input rows carry zero bits beyond K
+  if (in_type == SNNQP_U8) {
+    // uint8 rows are read in 16-byte pieces, as x - 128 against the int8 codes
+    if (!w->col_sum) return "uint8 input needs snnqp_weight_t.col_sum";
+    if (K % 16) return "uint8 input needs K % 16 == 0";
+    if (K > 65536) return "uint8 input needs K <= 65536 (int32 accumulator)";
+  }
+  // bit-packed: any K -- the tiles `wt` are zero-padded to ceil(K / 32) k-steps and the packed
+  // input rows carry zero bits beyond K
   if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
   return nullptr;
 }
 
-template <int RT>
+template <int RT, int IN>
 static void launch_dense(const DenseMfmaArgs &a, unsigned gx, unsigned gy, hipStream_t st) {
-  hipLaunchKernelGGL((dense_mfma_kernel<RT>), dim3(gx, gy), dim3(256 * KGROUPS), 0, st, a);
+  hipLaunchKernelGGL((dense_mfma_kernel<RT, IN>), dim3(gx, gy), dim3(256 * KGROUPS), 0, st, a);
 }
 
-int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
+int run_dense_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
                    int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, hipStream_t st) {
@@ -325,8 +377,13 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   SNNQP_CHECK_BN(bn);
   if (T == 0 || B == 0) return SNNQP_OK;
   SNNQP_REQUIRE(T <= 96, SNNQP_EUNSUPPORTED, "dense mfma: T > 96");
+  const bool u8 = in_type == SNNQP_U8;
+  if (u8)
+    SNNQP_REQUIRE(((uintptr_t)x & 15) == 0 && xs_t % 16 == 0 && xs_b % 16 == 0, SNNQP_EUNSUPPORTED,
+                  "dense mfma: uint8 rows must be 16-byte aligned");
   DenseMfmaArgs a;
   a.x = (const uint32_t *)x; a.xs_t = xs_t; a.xs_b = xs_b;
+  a.col_sum = w->col_sum;
   a.T = T; a.B = B; a.K = K; a.N = N; a.KS = (K + 31) / 32;
   a.wt = wt;
   a.dq = make_dequant(w->L, w->m);
@@ -334,10 +391,11 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out;
   const unsigned gy = (unsigned)((N + 127) / 128);
   // largest row tile that still gives the chip enough workgroups, else the
-  // smallest one that holds a whole sample (most workgroups)
+  // smallest one that holds a whole sample (most workgroups); uint8 rows: at most 64 rows
+  // (their staging ring takes the registers of the third row tile)
   static const int rts[3] = {3, 2, 1};
   int rt = 0;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = u8 ? 1 : 0; i < 3; ++i) {
     const int sb = rts[i] * 32 / T;
     if (sb < 1) continue;
     rt = rts[i];
@@ -346,10 +404,15 @@ int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t
   SNNQP_REQUIRE(rt > 0, SNNQP_EUNSUPPORTED, "dense mfma: T too large");
   a.SB = rt * 32 / T;
   const unsigned gx = (unsigned)((B + a.SB - 1) / a.SB);
-  switch (rt) {
-    case 3: launch_dense<3>(a, gx, gy, st); break;
-    case 2: launch_dense<2>(a, gx, gy, st); break;
-    default: launch_dense<1>(a, gx, gy, st); break;
+  if (u8) {
+    if (rt == 2) launch_dense<2, SNNQP_U8>(a, gx, gy, st);
+    else launch_dense<1, SNNQP_U8>(a, gx, gy, st);
+  } else {
+    switch (rt) {
+      case 3: launch_dense<3, SNNQP_BITS>(a, gx, gy, st); break;
+      case 2: launch_dense<2, SNNQP_BITS>(a, gx, gy, st); break;
+      default: launch_dense<1, SNNQP_BITS>(a, gx, gy, st); break;
+    }
   }
   SNNQP_CHECK_LAUNCH("dense_mfma_kernel");
   return SNNQP_OK;

@@ -32,7 +32,7 @@ int run_fseq_gemm(const void *x, int in_type, int64_t NB, const snnqp_conv_geom_
 const char *dense_mfma_unsupported(int in_type, int32_t K, int32_t N,
                                    const snnqp_weight_t *w, const int8_t *wt,
                                    const snnqp_neuron_t *nrn, int s_type);
-int run_dense_mfma(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
+int run_dense_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
                    int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, hipStream_t st);

@@ -235,10 +235,13 @@ class Weight:
   abs_sum_max: int = 0      # |acc| <= abs_sum_max * x_max (max one-sided code sum over the outputs)
   code_max: int = 0         # max |code| (<= 7: exact in fp6)
   min_current_bits: int = 0  # smallest non-zero |BN(dequant(acc))| as float bits (current_min)
+  col_sum: Optional[torch.Tensor] = None   # dense: int32 [N] column sums of the codes (uint8 input)
 
   def struct(self) -> L.WeightT:
     return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
-                     int(self.abs_sum_max), int(self.code_max), int(self.min_current_bits))
+                     int(self.abs_sum_max), int(self.code_max),
+                     None if self.col_sum is None else self.col_sum.data_ptr(),
+                     int(self.min_current_bits))
 
   @property
   def is_int(self):
@@ -372,72 +375,28 @@ _u8_flag_cache = None
 
 
 def forget_inputs():
-  """Drops the cached facts about activation tensors (their maxima), as if every
-  tensor were new: bench.py calls it each step so that the per-batch inspection
-  pass of a fresh input is inside the timed region.  Inspections requested ahead with
-  prefetch_input_bound() stay pending: each is consumed by one input_max_bound()."""
+  """Drops the cached facts about activation tensors (their maxima), as if every tensor were
+  new: bench.py calls it each step so that whatever a fresh batch costs is inside the timed
+  region."""
   global _u8_flag_cache
   _u8_flag_cache = None
 
 
-_pending_bounds = None
-_inspect_stream = None
-_inspect_bufs = None
-
-
-def prefetch_input_bound(x):
-  """Starts the inspection pass of a uint8 input batch (its maximum count, which selects
-  the first layer's kernel variant) on a side stream, so that the later
-  input_max_bound(x) finds the answer instead of launching the pass and waiting for it
-  in front of the first kernel -- what a serving loop does with the NEXT batch while the
-  current one computes.  `x` must already be produced on the current stream."""
-  global _pending_bounds, _inspect_stream
-  if isinstance(x, PackedSpikes) or x.dtype != torch.uint8 or not x.is_contiguous():
-    return
-  _require_gpu(x)
-  if _pending_bounds is None:
-    from ._cache import TensorCache
-    _pending_bounds = TensorCache(8)
-    _inspect_stream = torch.cuda.Stream(device=x.device)
-  if _pending_bounds.get((x,)) is not None:
-    return
-  global _inspect_bufs
-  if _inspect_bufs is None:                        # pinned words are slow to allocate: a small ring
-    _inspect_bufs = [torch.empty(8, dtype=torch.int32, pin_memory=True),
-                     torch.zeros(8, dtype=torch.int32, device=x.device), 0]
-  host_all, dev_all, k = _inspect_bufs
-  _inspect_bufs[2] = (k + 1) % 8
-  host, flags = host_all[k:k + 1], dev_all[k:k + 1]
-  ready = torch.cuda.Event()
-  ready.record()                                   # x as of now, on the current stream
-  with torch.cuda.stream(_inspect_stream):
-    _inspect_stream.wait_event(ready)
-    flags.zero_()
-    L.check(L.lib().snnqp_inspect_u8(_ptr(x), x.numel(), _ptr(flags), _stream()))
-    host.copy_(flags, non_blocking=True)
-    done = torch.cuda.Event()
-    done.record()
-  _pending_bounds.put((x,), None, (done, host, flags))
-
-
 def input_max_bound(x) -> int:
-  """Upper bound of an integer-typed activation: 1 for spikes; for uint8 tensors
-  the maximum (at least 1) from one device pass (cached per tensor version)."""
+  """Upper bound of an integer-typed activation: 1 for spikes; for uint8 tensors the maximum
+  (at least 1) from one device pass and a 4-byte read-back (cached per tensor version).
+  Off the BASELINE configurations' paths: the event layer checks its own input (CountHint),
+  dense blocks read uint8 rows as they are; what still asks is a uint8 tensor into a conv
+  block with more than two channels, or into a dense block whose K is not a multiple of 16."""
   global _u8_flag_cache
-  if isinstance(x, PackedSpikes):
-    return 1
+  if isinstance(x, (PackedSpikes, PackedFrames)):
+    return 1 if isinstance(x, PackedSpikes) or x.fmt == L.EV1 else 15
   if x.dtype != torch.uint8:
     return 0
   if _u8_flag_cache is None:
     from ._cache import TensorCache
     _u8_flag_cache = TensorCache(16)
   v = _u8_flag_cache.get((x,))
-  if v is None and _pending_bounds is not None:
-    pend = _pending_bounds.get((x,))
-    if pend is not None:                           # requested ahead: wait for that pass only
-      pend[0].synchronize()
-      v = max(1, int(pend[1][0]) >> 8)
-      _u8_flag_cache.put((x,), None, v)
   if v is None:
     _require_gpu(x)
     xc = x.contiguous()
@@ -731,6 +690,17 @@ def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
         ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0),
         _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl, _stream()))
   return u_out, (PackedSpikes(s, N) if packed_out else s)
+
+
+def fallback_counts(reset: bool = False) -> dict:
+  """Blocks that IMPL_AUTO handed to the direct-form kernel (20-25 x slower than the MFMA
+  kernels) since the library was loaded / the last reset, with the last reason."""
+  conv, dense = ctypes.c_int64(), ctypes.c_int64()
+  buf = ctypes.create_string_buffer(256)
+  L.check(L.lib().snnqp_fallback_counts(ctypes.byref(conv), ctypes.byref(dense), buf, 256,
+                                        1 if reset else 0))
+  return {"conv_blocks": conv.value, "dense_blocks": dense.value,
+          "last_reason": buf.value.decode("utf-8", "replace")}
 
 
 # ---------------------------------------------------------------------------

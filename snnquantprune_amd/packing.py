@@ -70,8 +70,10 @@ class PackedKernel:
     # larger one-sided sum over the outputs bounds |acc| (about half of sum |code|)
     side = torch.maximum(c2.clamp(min=0).sum(0).max(), (-c2).clamp(min=0).sum(0).max())
     stats = torch.stack([side, c2.abs().max()]).tolist()             # one readback
+    # dense kernels: column sums of the codes, for uint8 rows read as x - 128 (snnqp.h col_sum)
+    col = c2.sum(0).to(torch.int32).contiguous() if self.kernel.ndim == 2 else None
     self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=int(stats[0]),
-                           code_max=int(stats[1]))
+                           code_max=int(stats[1]), col_sum=col)
     return self._int
 
   def float_weight(self) -> ops.Weight:
@@ -123,7 +125,7 @@ class PackedKernel:
         tiles_src = codes
       wt = ops.pack_codes_mfma(tiles_src, n_pad) if tiles_src.shape[0] % 32 == 0 else None
       w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max,
-                     code_max=base.code_max)
+                     code_max=base.code_max, col_sum=base.col_sum)
       self._wt[key] = w
     return w
 

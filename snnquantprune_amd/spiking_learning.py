@@ -291,11 +291,17 @@ class SpikingBlock(nn.Module):
       if not direct:
         x = ops.unpack_frames(x)
 
-    # binary uint8 activations into a dense block (config C2's first layer): pack the bits
-    # once so the int8-MFMA dense kernel serves it (it reads bit-packed rows)
+    # uint8 activations into a dense block (config C2's first layer).  The MFMA dense kernel
+    # reads uint8 rows in place, any count 0..255 as x - 128 (snnqp.h, col_sum): no packing
+    # pass, no inspection, nothing for the host to wait for.  Rows it cannot take that way
+    # (K not a multiple of 16, more than 64 timesteps) go the older way when they are binary:
+    # one inspection pass (a read-back, cached per tensor version) and a bit-packing pass.
     if (is_dense and integer and w.wtype == L.W_I8 and isinstance(x, torch.Tensor)
-        and x.dtype == torch.uint8 and self.impl == L.IMPL_AUTO and ops.input_max_bound(x) == 1):
-      x = ops.pack_bits(x)
+        and x.dtype == torch.uint8 and self.impl == L.IMPL_AUTO):
+      T_ = x.shape[0] if tm else x.shape[1]
+      direct = w.wt is not None and w.col_sum is not None and cin % 16 == 0 and T_ <= 64
+      if not direct and ops.input_max_bound(x) == 1:
+        x = ops.pack_bits(x)
     # float32 kernels -- the real-valued TCJA-gated blocks, and unquantised layers whatever
     # feeds them (float32, uint8 counts or packed spikes: widened on the fly) -- run the
     # connection on the f32 MFMA (the same fmaf chain as the direct-form kernel), then the

@@ -2034,3 +2034,156 @@ def test_evaluate_restores_feeds_and_scores_like_the_oracle(dev, oracle, tmp_pat
                                rtol=1e-6)
     assert abs(summary["accuracy"] - np.mean([w["accuracy"].mean() for w in want])) < 1e-6
     assert "QuantConv_0" in state.params["params"]
+
+
+# ---------------------------------------------------------------------------
+# dense blocks on uint8 rows, config C2 without a host synchronisation, fallbacks, capture
+# ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("shape", [(20, 37, 2048, 512), (6, 5, 208, 70), (64, 3, 96, 33),
+                                   (9, 130, 4096, 110)],
+                         ids=["c2_layer1", "ragged_n_k16", "longest_t", "many_rows"])
+def test_dense_block_reads_uint8_rows_in_place(dev, oracle, shape):
+  """The MFMA dense kernel on uint8 rows (IN = U8: x - 128 against the codes, 128 * col_sum
+  added back): binary rows, small counts and rows holding every value up to 255 give the
+  oracle's rasters and potentials, batch-major and time-major, with a carried-in state --
+  no packing pass and no inspection of the values in front of the launch."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, K, N = shape
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert w.wt is not None and w.col_sum is not None
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  rng = np.random.Generator(np.random.PCG64(K + N))
+  small = np.minimum(rng.poisson(0.15, (T, B, K)), 255).astype(np.uint8)
+  wide = small.copy()
+  wide[rng.random(wide.shape) < 0.002] = 255
+  wide[0, 0, :3] = (128, 127, 200)
+  u0 = _t(c["u0"], dev)
+  before = ops.fallback_counts()["dense_blocks"]
+  for name, x in (("binary", c["x"]), ("counts", small), ("to_255", wide)):
+    eu, es = oracle.dense_block(x, qw, None, "int", u0=c["u0"])
+    u, s = ops.dense_lif_forward(_t(x, dev), w, K, N, _mslif(), u0=u0, packed_out=True,
+                                 impl=L.IMPL_MFMA)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg=name)
+    np.testing.assert_array_equal(_np(u), eu, err_msg=name)
+    xb = _t(np.ascontiguousarray(np.swapaxes(x, 0, 1)), dev)
+    ub, sb = ops.dense_lif_forward(xb, w, K, N, _mslif(), u0=u0, packed_out=True,
+                                   impl=L.IMPL_AUTO, time_major=False)
+    np.testing.assert_array_equal(_np(sb), packbits_lastaxis(es), err_msg=name + " batch-major")
+    np.testing.assert_array_equal(_np(ub), eu, err_msg=name + " batch-major")
+  assert ops.fallback_counts()["dense_blocks"] == before          # AUTO stayed on the MFMA kernel
+
+
+def test_c2_steps_without_a_host_synchronisation(dev, oracle, monkeypatch):
+  """Config C2 (uint8 [B, T, 2048] -> qdense 512 -> qdense 110 -> vote) at its own size,
+  B = 256, T = 20: bit-exact logits, and a step neither inspects its input on the host
+  (ops.input_max_bound, ops.inspect_f32 and Tensor.item are made to raise) nor falls back to
+  the direct-form kernel; a fresh batch every step."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.dense_net_case(True, T=20, B=256, K=2048, hidden=512)
+  e = cases.dense_net_expected(oracle, c)
+  model = models.DenseSNN(num_classes=11, config=syn.make_config(bits=8, prune_percentage=0.5, hidden=512))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+  (logits, _) = model.apply(variables, x, trgt=None, train=False, rng=None)     # packs the weights
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+  ops.fallback_counts(reset=True)
+
+  def boom(*a, **k):
+    raise AssertionError("host synchronisation inside a C2 step")
+  monkeypatch.setattr(ops, "input_max_bound", boom)
+  monkeypatch.setattr(ops, "inspect_f32", boom)
+  monkeypatch.setattr(torch.Tensor, "item", boom)
+  monkeypatch.setattr(torch.Tensor, "tolist", boom)
+  outs = []
+  for i in range(3):
+    xi = torch.roll(x, i, 0)                                         # a new tensor each step
+    outs.append(model.apply(variables, xi, trgt=None, train=False, rng=None)[0])
+  monkeypatch.undo()
+  for i, o_ in enumerate(outs):
+    np.testing.assert_array_equal(_np(o_), np.roll(e["logits"], i, 0))
+  assert ops.fallback_counts() == {"conv_blocks": 0, "dense_blocks": 0, "last_reason": ""}
+
+
+def test_c1_at_its_own_size(dev, oracle):
+  """BASELINE config C1 at full size: 2048 -> 512 -> 110, float32 weights (no `weight` key:
+  flax_qdense.py:74-82 pass-through), no pruning, T = 10, B = 32 -- spikes and logits against
+  the oracle's `fseq` mode (the f32-MFMA connection runs that fmaf chain)."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.dense_net_case(False, T=10, B=32, K=2048, hidden=512)
+  e = cases.dense_net_expected(oracle, c)
+  assert 0.01 < e["s1"].mean() < 0.6 and 0.01 < e["s2"].mean() < 0.6
+  cfg = syn.make_config(bits=-1, prune_percentage=-1.0, hidden=512, quantized=False)
+  model = models.DenseSNN(num_classes=11, config=cfg)
+  (logits, _), mut = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None,
+                                 train=False, rng=None, mutable=["intermediates"])
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+  s2 = mut["intermediates"]["dense2_out"][0]
+  s2 = s2.to_dense() if hasattr(s2, "to_dense") else s2
+  np.testing.assert_array_equal(_np(s2).astype(np.uint8), e["s2"])
+
+
+def test_fallbacks_to_the_direct_form_kernel_are_counted(dev, oracle):
+  """IMPL_AUTO handing a block to the direct-form kernel (20-25 x slower) is visible: the
+  library counts such blocks and keeps the reason (snnqp_fallback_counts)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  ops.fallback_counts(reset=True)
+  # dense, T > 96 on bit-packed rows
+  c = cases.dense_block_case(T=100, B=2, K=64, N=32)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  ops.dense_lif_forward(ops.pack_bits(_t(c["x"], dev)), w, 64, 32, _mslif(), packed_out=True)
+  f = ops.fallback_counts()
+  assert f["dense_blocks"] == 1 and f["conv_blocks"] == 0 and "96" in f["last_reason"]
+  # conv, 5x5 kernel
+  rng = np.random.Generator(np.random.PCG64(4))
+  leaf = {"kernel": (rng.standard_normal((5, 5, 32, 32)) * 0.2).astype(F32),
+          "DuQ_0": {"a": F32([1.0]), "c": F32([0.9])}}
+  w5 = _weight(leaf, 4, dev)
+  x = ops.pack_bits(_t((rng.random((3, 2, 8, 8, 32)) < 0.2).astype(np.uint8), dev))
+  g = ops.ConvGeom(8, 8, 32, 32, 5, 5, (1, 1), ((2, 2), (2, 2)))
+  ops.conv_lif_forward(x, g, w5, _mslif(), packed_out=True)
+  f = ops.fallback_counts()
+  assert f["conv_blocks"] == 1 and f["last_reason"].startswith("conv: ") and "3x3" in f["last_reason"]
+  # an explicit request for the direct-form kernel is not a fallback
+  ops.conv_lif_forward(x, g, w5, _mslif(), packed_out=True, impl=L.IMPL_GENERIC)
+  assert ops.fallback_counts(reset=True)["conv_blocks"] == 1
+  assert ops.fallback_counts() == {"conv_blocks": 0, "dense_blocks": 0, "last_reason": ""}
+
+
+def test_capture_replays_the_model_as_one_graph(dev, oracle):
+  """nn.capture: model.apply recorded into a hipGraph -- C2 (uint8 rows), C3 on uint8 frames
+  and on bit-packed frames -- replayed on new inputs gives the oracle's logits; a wrong input
+  shape is refused."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.dense_net_case(True)
+  e = cases.dense_net_expected(oracle, c)
+  model = models.DenseSNN(num_classes=11, config=syn.make_config(bits=8, prune_percentage=0.5, hidden=96))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+  step = nn.capture(model, variables, torch.zeros_like(x), trgt=None, train=False, rng=None)
+  for i in range(3):
+    logits, _ = step(torch.roll(x, i, 0))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(logits), np.roll(e["logits"], i, 0))
+  with pytest.raises(ValueError):
+    step(x[:1])
+  c3 = cases.conv_net_case()
+  e3 = cases.conv_net_expected(oracle, c3)
+  m3 = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  v3 = nn.tree_from_numpy(c3["vars"], dev)
+  for inp in (_t(c3["x"], dev), ops.pack_frames(_t(c3["x"], dev), L.EV1)):
+    zero = ops.pack_frames(torch.zeros_like(_t(c3["x"], dev)), L.EV1) if isinstance(inp, ops.PackedFrames) \
+        else torch.zeros_like(inp)
+    step3 = nn.capture(m3, v3, zero, trgt=None, train=False, rng=None)
+    for _ in range(2):
+      logits, _ = step3(inp)
+      torch.cuda.synchronize()
+      np.testing.assert_array_equal(_np(logits), e3["logits"])

@@ -1,0 +1,103 @@
+// Encodings of the threshold + hard reset of the fused conv epilogues on gfx950: does the
+// VOP2/VOPC (e32, implicit VCC) form of v_cmp / v_cndmask issue faster than the VOP3 (e64,
+// SGPR pair) form the kernels use?  Per 32-pixel x 32-channel tile-step a wave runs 8 pairs of
+// { update, 2 compares, 2 selects, the spike word }.  4 waves per SIMD, no LDS, no MFMA.
+// Prints SIMD cycles per tile (2.4 GHz).  hipcc --offload-arch=gfx950 -O3 threshold_forms.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// UPD: 0 = packed update (conv0: v_pk_add + v_pk_fma), 1 = scalar update (conv1/2: 2 x sub, 2 x fma),
+//      2 = no update (threshold / reset alone)
+// THR: 0 = e64 compare into SGPR pairs + e64 select (what the kernels emit)
+//      1 = e32 compare into VCC + e32 select on VCC + s_mov of VCC (inverted sense: th > t keeps)
+//      2 = e64 compare into VCC + e64 select on VCC + s_mov
+//      3 = e32 compare into VCC + e64 select on VCC + s_mov
+//      4 = none
+template <int UPD, int THR>
+__global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, float th) {
+  v2f u[8], x[8];
+  for (int i = 0; i < 8; ++i) { u[i] = v2f{0.1f * threadIdx.x, 0.2f * i}; x[i] = v2f{0.3f + i, 0.7f}; }
+  const v2f kv = {kk, kk};
+  unsigned word = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v2f t = u[i];
+      if (UPD == 0) {
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x[i]), "v"(u[i]));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(kv), "v"(u[i]));
+      } else if (UPD == 1) {
+        float d0, d1;
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(x[i].x), "v"(u[i].x));
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d1) : "v"(x[i].y), "v"(u[i].y));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(d0), "v"(kk), "v"(u[i].x));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(d1), "v"(kk), "v"(u[i].y));
+      }
+      unsigned long long m0 = 0, m1 = 0;
+      if (THR == 0) {
+        asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m0) : "v"(th), "v"(t.x));
+        asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m1) : "v"(th), "v"(t.y));
+        asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(u[i].x) : "v"(t.x), "s"(m0));
+        asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(u[i].y) : "v"(t.y), "s"(m1));
+      } else if (THR == 1) {
+        asm volatile("v_cmp_gt_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, 0, %3, vcc\n\ts_mov_b64 %1, vcc"
+                     : "=v"(u[i].x), "=s"(m0) : "v"(th), "v"(t.x) : "vcc");
+        asm volatile("v_cmp_gt_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, 0, %3, vcc\n\ts_mov_b64 %1, vcc"
+                     : "=v"(u[i].y), "=s"(m1) : "v"(th), "v"(t.y) : "vcc");
+      } else if (THR == 2) {
+        asm volatile("v_cmp_le_f32_e64 vcc, %2, %3\n\tv_cndmask_b32_e64 %0, %3, 0, vcc\n\ts_mov_b64 %1, vcc"
+                     : "=v"(u[i].x), "=s"(m0) : "v"(th), "v"(t.x) : "vcc");
+        asm volatile("v_cmp_le_f32_e64 vcc, %2, %3\n\tv_cndmask_b32_e64 %0, %3, 0, vcc\n\ts_mov_b64 %1, vcc"
+                     : "=v"(u[i].y), "=s"(m1) : "v"(th), "v"(t.y) : "vcc");
+      } else if (THR == 3) {
+        asm volatile("v_cmp_le_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e64 %0, %3, 0, vcc\n\ts_mov_b64 %1, vcc"
+                     : "=v"(u[i].x), "=s"(m0) : "v"(th), "v"(t.x) : "vcc");
+        asm volatile("v_cmp_le_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e64 %0, %3, 0, vcc\n\ts_mov_b64 %1, vcc"
+                     : "=v"(u[i].y), "=s"(m1) : "v"(th), "v"(t.y) : "vcc");
+      } else {
+        u[i] = t;
+      }
+      if (THR != 4) {
+        // THR 1 holds the KEEP masks (th > t): spike = not keep; the pooled word is the OR of
+        // the four spike bits of a channel
+        const unsigned long long m = THR == 1 ? ~(m0 & m1) : (m0 | m1);
+        const unsigned w = (unsigned)m | (unsigned)(m >> 32);
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(w), "n"(0));
+      }
+    }
+  }
+  float s = (float)word;
+  for (int i = 0; i < 8; ++i) s += u[i].x + u[i].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int UPD, int THR>
+void run(const char *name, float *out) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 20000; float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k<UPD, THR>), dim3(256 * 4), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double tiles = (double)iters * 4;      // tile-steps per SIMD (4 waves)
+  printf("%-52s %.1f SIMD cycles per tile of 16 registers (2.4 GHz)\n", name, ms * 1e6 / tiles * 2.4);
+}
+
+int main() {
+  float *out; (void)hipMalloc(&out, 256 * 4 * 256 * 4);
+  run<2, 4>("nothing (loop only)", out);
+  run<0, 4>("packed update only", out);
+  run<1, 4>("scalar update only", out);
+  run<2, 0>("threshold+reset e64/SGPR (kernels today)", out);
+  run<2, 1>("threshold+reset e32/VCC + s_mov", out);
+  run<2, 2>("threshold+reset e64/VCC + s_mov", out);
+  run<2, 3>("threshold e32/VCC, reset e64/VCC + s_mov", out);
+  run<0, 0>("packed update + e64/SGPR (conv0 today)", out);
+  run<0, 1>("packed update + e32/VCC", out);
+  run<0, 3>("packed update + e32 cmp, e64 select", out);
+  run<1, 0>("scalar update + e64/SGPR (conv1/2 today)", out);
+  run<1, 1>("scalar update + e32/VCC", out);
+  return 0;
+}
