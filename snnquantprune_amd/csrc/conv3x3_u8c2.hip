@@ -535,7 +535,6 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                      const snnqp_weight_t *w, const int8_t *wt,
                                      const snnqp_neuron_t *nrn, int s_type) {
   if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
-  if (in_type == SNNQP_BITS && !wt) return "MFMA-tiled codes `wt` not given";
   if (g->KH != 3 || g->KW != 3) return "kernel is not 3x3";
   if (g->stride_h != 1 || g->stride_w != 1) return "stride is not 1";
   if (g->pad_h_lo != 1 || g->pad_h_hi != 1 || g->pad_w_lo != 1 || g->pad_w_hi != 1)
@@ -560,6 +559,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
     return "input must be BITS, U8 or EV1 (unpack EV4 frames first: snnqp_unpack_frames)";
   }
   if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
+  if (in_type == SNNQP_BITS && !wt) return "MFMA-tiled codes `wt` not given";
   return nullptr;
 }
 

@@ -137,9 +137,10 @@ dense_mfma_kernel(DenseMfmaArgs a) {
     }
   }
   auto chunk_word = [&](int chunk, int k) { return (chunk * KGROUPS + grp) * WPR + (tid + k * 256) % WPR; };
-  // uint8: 16-byte piece `chunk_word` of the row; K is a multiple of 16 (launch check), pieces
-  // beyond K re-read the row's first one (they meet the zero codes the tiles are padded with,
-  // and so do the rows beyond `rows`: nothing of a uint8 row needs masking)
+  // uint8: 16-byte piece `chunk_word` of the row; K is a multiple of 16 (launch check).  Pieces
+  // beyond K re-read the row's first one and are stored as zero bytes (the k-steps of a chunk
+  // beyond K reuse the last real k-step's codes); the rows beyond `rows` need no masking,
+  // nothing reads their accumulators
   auto stage_load1 = [&](int chunk, int k) -> stg_t {
     if constexpr (U8) {
       const int piece = chunk_word(chunk, k);
@@ -163,8 +164,10 @@ dense_mfma_kernel(DenseMfmaArgs a) {
         const int row = task / WPR, wi = task % WPR;
         if constexpr (U8) {
           const v4i v = stg[k];
-          *(v4i *)(base + a_addr(row, wi)) = v4i{v.x ^ (int)0x80808080, v.y ^ (int)0x80808080,
-                                                 v.z ^ (int)0x80808080, v.w ^ (int)0x80808080};
+          const int m = chunk_word(chunk, k) * 16 < a.K ? -1 : 0;
+          *(v4i *)(base + a_addr(row, wi)) =
+              v4i{(v.x ^ (int)0x80808080) & m, (v.y ^ (int)0x80808080) & m,
+                  (v.z ^ (int)0x80808080) & m, (v.w ^ (int)0x80808080) & m};
         } else {
           const uint32_t wv = stg[k] & rmask[k] & (uint32_t)((chunk_word(chunk, k) - a.KS) >> 31);
           *(v4i *)(base + a_addr(row, wi * 2)) = expand16b(wv & 0xFFFFu);
@@ -222,10 +225,16 @@ dense_mfma_kernel(DenseMfmaArgs a) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) av[s] = frag(rbuf, s);
     stg_t wv[TPT];
+    int inK[TPT];                      // uint8: all ones while the piece lies inside K
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-      if constexpr (U8) wv[k] = st_stg[k];
-      else wv[k] = st_stg[k] & rmask[k] & (uint32_t)((chunk_word(st_chunk, k) - a.KS) >> 31);
+      inK[k] = -1;
+      if constexpr (U8) {
+        wv[k] = st_stg[k];
+        inK[k] = chunk_word(st_chunk, k) * 16 < a.K ? -1 : 0;
+      } else {
+        wv[k] = st_stg[k] & rmask[k] & (uint32_t)((chunk_word(st_chunk, k) - a.KS) >> 31);
+      }
     }
     v4i ex = {0, 0, 0, 0};
 #pragma unroll
@@ -255,7 +264,7 @@ dense_mfma_kernel(DenseMfmaArgs a) {
           // instructions, not the values they were selected from)
           if constexpr (U8) {
             asm volatile("" : "+v"(wv[k]));
-            ex[d] = wv[k][d] ^ (int)0x80808080;
+            ex[d] = (wv[k][d] ^ (int)0x80808080) & inK[k];
             if (d == 3 && tid + k * 256 < NTASK)
               *(v4i *)(abuf + (rbuf ^ 1) * ABYTES + wr_off[k][0]) = ex;
           } else {

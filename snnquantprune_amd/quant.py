@@ -127,7 +127,8 @@ class QuantDesc:
 
 
 def _f32(x: float) -> float:
-  return float(torch.tensor(x, dtype=torch.float32).item())
+  import numpy as np
+  return float(np.float32(x))          # rounds a Python float to float32 (host only)
 
 
 def _check_sign(sign):
