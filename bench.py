@@ -42,6 +42,10 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0 * 1e0   # G wave-instructions / s (x 64 l
 # command: tools/pmc_profile.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed
 PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json",
                                                            "r01_pmc_traffic.json")]
+# per-kernel PMC counters of the same command (tools/pmc_profile.sh), committed: SQ_INSTS_VALU per
+# launch gives the vector instructions per neuron update of the conv kernels
+PMC_SUMMARY = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_summary.json",
+                                                           "r02_pmc_summary.json")]
 # int-vs-float deviation of the numeric contract (tools/int_vs_float.py, CPU), committed
 PARITY_VS_FLOAT = os.path.join(ROOT, "profiles", "r02_int_vs_float.json")
 
@@ -87,6 +91,10 @@ def parse(argv=None):
                        "model) instead of the freshly initialised one (mean 0, var 1, scale 1, "
                        "bias 0) of a random-init model: the kernels then run all three "
                        "BatchNorm instructions instead of the multiply alone")
+  ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                  help="weak: --batch samples per GPU whatever N is (the default, BASELINE C3 -> C4). "
+                       "strong: --global-batch samples in total, split over the N GPUs (C4's 8192)")
+  ap.add_argument("--global-batch", type=int, default=8192, help="total samples under --scaling strong")
   ap.add_argument("--cpu-samples", type=int, default=8)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--graph", action="store_true",
@@ -136,6 +144,11 @@ def launch_ranks(args, argv):
   n = args.gpus
   base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
               MASTER_PORT=str(port))
+  # RCCL shares device buffers between the rank processes of a node through IPC handles; this
+  # image's host driver only supports the dmabuf form, and with the legacy form selected
+  # hipIpcGetMemHandle fails with "invalid argument" inside the first collective.  The image
+  # exports the variable already (see the task environment notes); kept here so that ranks
+  # started from a scrubbed environment get it too.  It changes nothing on one GPU.
   base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   import tempfile
   procs = []
@@ -338,7 +351,30 @@ def main(argv=None):
     assert args.stand_in, "the gloo backend is test plumbing (--stand-in) only"
     dev = torch.device("cpu")
 
+  if args.scaling == "strong":
+    if args.global_batch % world:
+      raise SystemExit("--global-batch %d is not divisible by %d ranks" % (args.global_batch, world))
+    args.batch = args.global_batch // world
   B, T = args.batch, args.frames
+  # who is here: every rank says which device it drives (stderr), rank 0 collects the list so
+  # that a scaling record shows the collective really spanned N distinct GPUs
+  ident = {"rank": rank, "local_rank": local, "pid": os.getpid(), "backend": args.backend}
+  if gpu:
+    p = torch.cuda.get_device_properties(local)
+    ident.update(device=local, name=p.name,
+                 pci="%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0),
+                                         getattr(p, "pci_device_id", 0)),
+                 uuid=str(getattr(p, "uuid", "")))
+    try:
+      ident["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+      ident["rccl"] = "unknown"
+  print("bench.py rank %s" % json.dumps(ident), file=sys.stderr, flush=True)
+  if world > 1:
+    ids = [None] * world
+    torch.distributed.all_gather_object(ids, ident)
+  else:
+    ids = [ident]
   lb = layer_bits(args)
   build_flags = ""
   if args.stand_in:
@@ -479,7 +515,11 @@ def main(argv=None):
       assert torch.equal(out[r * B:(r + 1) * B], apply_fn(xr)), "gathered rows of rank %d" % r
 
   tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+  rank_dt = [dt]
   if world > 1:
+    every = torch.zeros(world, device=dev, dtype=torch.float64)
+    torch.distributed.all_gather_into_tensor(every, tmax)
+    rank_dt = [float(v) for v in every.tolist()]
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
   dt = float(tmax.item())
 
@@ -502,7 +542,7 @@ def main(argv=None):
       "metric": metric_name(args),
       "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
       "dtype": "int8",
       "dtype_detail": "integer codes x integer inputs, exact sums: conv0/dense int8 x u8/binary -> "
                       "int32 (i8 MFMA); conv1-2 the same integers as fp6 codes x fp4 spikes -> f32 "
@@ -526,6 +566,12 @@ def main(argv=None):
                  "batch_per_gpu": B, "global_batch": world * B, "frames": T,
                  "parallelism": "dp%d (batch-sharded, all-gather logits)" % world},
   }
+  # the ranks the collective spanned: distinct devices (PCI addresses when the backend is RCCL)
+  line["ranks_seen"] = len({(i.get("pci"), i.get("device"), i["rank"]) for i in ids})
+  line["ranks"] = [{k: i.get(k) for k in ("rank", "device", "pci", "rccl", "pid") if k in i} for i in ids]
+  line["rank_seconds"] = rank_dt
+  if ops is not None:
+    line["fallbacks"] = ops.fallback_counts()      # blocks on the direct-form kernel (should be 0)
   if args.graph:
     line["config"]["launch"] = "hipGraph replay of model.apply (kernel times from the eager warm-up)"
   if build_flags or os.environ.get("SNNQP_DIAG_LIB"):
@@ -546,7 +592,9 @@ def main(argv=None):
   line.update(rooflines_of(args, prof, B, T, lb))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:
-      line["parity_vs_float"] = json.load(f).get("summary")
+      line["parity_vs_float"] = dict(json.load(f).get("summary") or {},
+                                     source="committed %s (CPU, oracle int vs float mode; not "
+                                            "measured in this run)" % os.path.relpath(PARITY_VS_FLOAT, ROOT))
   if world == 1 and not args.no_cpu_baseline and args.model == "c3":
     line["cpu_baseline"] = cpu_baseline(args, variables_np)
   print(json.dumps(line))
@@ -580,14 +628,31 @@ def rooflines_of(args, prof, B, T, lb):
       "dense[2048->512]": (B * T * 2048 * 512, B * T * (256 + 64) + 2048 * 512, INT8_MFMA_PEAK_TOPS),
       "dense[512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 16) + 512 * 128, INT8_MFMA_PEAK_TOPS),
   }
-  traffic = {}
-  if (B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3"
-      and args.input == "u8"):
+  traffic, traffic_src, pmc, pmc_src = {}, None, {}, None
+  headline = (B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3")
+  if headline:
     for path in PMC_TRAFFIC:
       if os.path.exists(path):
         with open(path) as f:
-          traffic = json.load(f).get("bytes_per_launch", {})
+          tj = json.load(f)
+        if tj.get("input", "u8") == args.input:
+          traffic = tj.get("bytes_per_launch", {})
+          traffic_src = "committed %s (rocprofv3 --pmc passes of this command; not measured in this run)" \
+              % os.path.relpath(path, ROOT)
+          break
+    for path in PMC_SUMMARY:
+      if os.path.exists(path):
+        with open(path) as f:
+          pmc = json.load(f)
+        pmc_src = "committed %s (not measured in this run)" % os.path.relpath(path, ROOT)
         break
+
+  def pmc_valu(prefix, which=0):
+    """SQ_INSTS_VALU per launch of the `which`-th kernel whose name starts with `prefix`."""
+    names = sorted(k for k in pmc if k.startswith(prefix))
+    if which < len(names) and "SQ_INSTS_VALU" in pmc[names[which]]:
+      return pmc[names[which]]["SQ_INSTS_VALU"]
+    return None
 
   def roofline_of(tag):
     k = kern[tag]
@@ -596,6 +661,7 @@ def rooflines_of(args, prof, B, T, lb):
     tops, gbs = 2.0 * macs / sec / 1e12, nbytes / sec / 1e9
     hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tops / peak
     r = {"kernel": tag, "avg_launch_ms": k["avg_ms"], "traffic": traffic.get(tag),
+         "traffic_source": traffic_src if traffic.get(tag) is not None else None,
          "algorithmic_bytes": nbytes, "hbm_frac": hbm_frac, "mfma_frac": mfma_frac}
     if mfma_frac >= hbm_frac:
       r.update(bound="mfma", achieved=tops, peak=peak, unit="TFLOP/s", frac=mfma_frac)
@@ -634,6 +700,7 @@ def rooflines_of(args, prof, B, T, lb):
   roofline = {"kernel": dom, "launches_per_step": len(tags), "layers": tags,
               "avg_launch_ms": avg_ms, "algorithmic_bytes": nbytes,
               "traffic": (sum(tr) / len(tr)) if all(v is not None for v in tr) else None,
+              "traffic_source": traffic_src if all(v is not None for v in tr) else None,
               "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_frac": tops / peak,
               "share_of_step": gtime[dom] / sum(gtime.values())}
   if tops / peak >= gbs / HBM_PEAK_GBS:
@@ -641,6 +708,29 @@ def rooflines_of(args, prof, B, T, lb):
   else:
     roofline.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs / HBM_PEAK_GBS)
+  if dom == conv_kernel:
+    # What binds the bits kernel is the SIMD's vector issue port, shared by the MFMAs and the
+    # neuron epilogue.  Per 32-pixel x 32-channel tile-step a wave issues 18
+    # MFMAs (32 cycles of the matrix pipe each: 576) and the epilogue of 1024 neuron updates;
+    # that epilogue alone -- dequantise 3, BatchNorm multiply, sub, fma, compare, select, half
+    # a v_writelane per update, no LDS, no MFMA -- costs 462 SIMD cycles per tile-step at the
+    # kernel's two waves per SIMD (tools/ubench/threshold_forms.hip, profiles/r03_threshold_forms.txt).
+    updates = sum(B * T * hw * hw * 128 * kern[t]["launches"]
+                  for t, hw in (("conv3x3[64x64x128->128]", 64), ("conv3x3[32x32x128->128]", 32))
+                  if t in kern) / nl
+    tiles_per_simd = updates / 1024.0 / 1024.0
+    mix_ms = tiles_per_simd * 462.5 / 2.4e9 * 1e3
+    mfma_ms = tiles_per_simd * 576.0 / 2.4e9 * 1e3
+    vi = {"updates_per_launch": updates, "measured_mix_cycles_per_tile": 462.5,
+          "mfma_cycles_per_tile": 576.0, "measured_mix_ms": mix_ms, "mfma_only_ms": mfma_ms,
+          "measured_mix_frac": mix_ms / avg_ms,
+          "note": "epilogue vector instructions alone / launch time; they share the issue port "
+                  "with the MFMAs (8 issue cycles each) and the staging"}
+    v1, v2 = pmc_valu("snnqp::conv3x3_bits_kernel", 0), pmc_valu("snnqp::conv3x3_bits_kernel", 1)
+    if v1 is not None and v2 is not None and len(tags) == 2:
+      vi["instr_per_update"] = (v1 + v2) / 2.0 / (updates / 64.0)
+      vi["instr_per_update_source"] = pmc_src
+    roofline["valu_issue"] = vi
   c0 = rooflines.get("conv3x3[128x128x2->128]")
   if c0 is not None:
     # third, stated ceiling of conv0: VALU issue of the per-neuron epilogue.  updates per
@@ -656,7 +746,12 @@ def rooflines_of(args, prof, B, T, lb):
     # add / mul / fma / and every 2.3 (tools/ubench/pk_f32_rate.hip)
     tiles_per_simd = updates / 1024.0 / 1024.0           # 1024 updates per tile-step, 1024 SIMDs
     mix_ms = tiles_per_simd * 245.0 / 2.4e9 * 1e3
-    c0["valu_issue"] = {"updates": updates, "instr_per_update": instr_per_update,
+    v0 = pmc_valu("snnqp::conv3x3_u8c2_kernel")
+    if v0 is not None:
+      c0_counted = {"instr_per_update_counted": v0 / (updates / 64.0), "counted_source": pmc_src}
+    else:
+      c0_counted = {}
+    c0["valu_issue"] = {**c0_counted, "updates": updates, "instr_per_update": instr_per_update,
                         "peak_ginstr_per_s": VALU_PEAK_GINSTR, "ceiling_ms": ceiling_ms,
                         "frac": ceiling_ms / c0["avg_launch_ms"],
                         "measured_mix_cycles_per_tile": 245.0, "measured_mix_ms": mix_ms,

@@ -311,6 +311,29 @@ def test_bench_gpus_2_starts_its_own_ranks_on_gloo():
   assert d["config"]["global_batch"] == 12 and d["config"]["batch_per_gpu"] == 6
   assert d["scaling"] == "weak" and d["unit"] == "samples/s"
   assert abs(d["value"] - 12 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+  # the line shows that the collective spanned both ranks, and each rank's own time
+  assert d["ranks_seen"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1]
+  assert len({r["pid"] for r in d["ranks"]}) == 2
+  assert len(d["rank_seconds"]) == 2 and max(d["rank_seconds"]) == pytest.approx(d["ms_per_step"] * 3e-3)
+  # every rank announced itself on stderr
+  assert err.count("bench.py rank {") >= 1
+
+
+def test_bench_strong_scaling_splits_a_fixed_global_batch():
+  """--scaling strong: the global batch (BASELINE config C4: 8192) is fixed and split over the
+  ranks; an indivisible one is refused."""
+  env = {k: v for k, v in os.environ.items()
+         if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+  rc, out, err = _bench(["--gpus", "2", "--backend", "gloo", "--stand-in", "--scaling", "strong",
+                         "--global-batch", "10", "--frames", "3", "--steps", "2", "--warmup", "1"], env)
+  assert rc == 0, err
+  d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+  assert d["scaling"] == "strong" and d["n_gpus"] == 2
+  assert d["config"]["global_batch"] == 10 and d["config"]["batch_per_gpu"] == 5
+  assert abs(d["value"] - 10 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+  rc, out, err = _bench(["--gpus", "2", "--backend", "gloo", "--stand-in", "--scaling", "strong",
+                         "--global-batch", "9", "--frames", "3", "--steps", "1", "--warmup", "0"], env)
+  assert rc != 0 and "divisible" in err
 
 
 def test_bench_under_an_external_launcher_env():

@@ -15,7 +15,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //      3 = e32 compare into VCC + e64 select on VCC + s_mov
 //      4 = none
 template <int UPD, int THR>
-__global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, float th) {
+__global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float th) {
   v2f u[8], x[8];
   for (int i = 0; i < 8; ++i) { u[i] = v2f{0.1f * threadIdx.x, 0.2f * i}; x[i] = v2f{0.3f + i, 0.7f}; }
   const v2f kv = {kk, kk};
@@ -27,6 +27,20 @@ __global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, flo
       if (UPD == 0) {
         asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x[i]), "v"(u[i]));
         asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(kv), "v"(u[i]));
+      } else if (UPD == 3) {         // conv1/2 today: dequantise (3), BatchNorm multiply, sub, fma
+        float y0, y1, q0, q1, d0, d1;
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(q0) : "v"(kk), "v"(x[i].x));
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(q1) : "v"(kk), "v"(x[i].y));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q0) : "v"(x[i].x), "v"(th), "v"(q0));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q1) : "v"(x[i].y), "v"(th), "v"(q1));
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y0) : "v"(kk), "v"(q0));
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y1) : "v"(kk), "v"(q1));
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y0) : "v"(th), "v"(y0));
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y1) : "v"(th), "v"(y1));
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(y0), "v"(u[i].x));
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d1) : "v"(y1), "v"(u[i].y));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(d0), "v"(kk), "v"(u[i].x));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(d1), "v"(kk), "v"(u[i].y));
       } else if (UPD == 1) {
         float d0, d1;
         asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(x[i].x), "v"(u[i].x));
@@ -73,16 +87,17 @@ __global__ void __launch_bounds__(256, 4) k(float *out, int iters, float kk, flo
 }
 
 template <int UPD, int THR>
-void run(const char *name, float *out) {
+void run(const char *name, float *out, int waves_per_simd = 4) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 20000; float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<UPD, THR>), dim3(256 * 4), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
+    hipLaunchKernelGGL((k<UPD, THR>), dim3(256 * waves_per_simd), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
   }
-  const double tiles = (double)iters * 4;      // tile-steps per SIMD (4 waves)
-  printf("%-52s %.1f SIMD cycles per tile of 16 registers (2.4 GHz)\n", name, ms * 1e6 / tiles * 2.4);
+  const double tiles = (double)iters * waves_per_simd;      // tile-steps per SIMD
+  printf("%-52s %d waves/SIMD: %.1f SIMD cycles per tile of 16 registers (2.4 GHz)\n", name,
+         waves_per_simd, ms * 1e6 / tiles * 2.4);
 }
 
 int main() {
@@ -99,5 +114,10 @@ int main() {
   run<0, 3>("packed update + e32 cmp, e64 select", out);
   run<1, 0>("scalar update + e64/SGPR (conv1/2 today)", out);
   run<1, 1>("scalar update + e32/VCC", out);
+  // the bits kernel's whole epilogue (dequantise 3, BatchNorm multiply, sub, fma, threshold,
+  // reset, spike word) alone, at its two waves per SIMD: what its vector instructions cost
+  run<3, 0>("conv1/2 epilogue: dq + bn + update + thr", out, 2);
+  run<3, 0>("conv1/2 epilogue: dq + bn + update + thr", out, 4);
+  run<3, 4>("conv1/2 epilogue without threshold/reset", out, 2);
   return 0;
 }
