@@ -107,6 +107,10 @@ typedef struct {
   const int32_t *col_sum; /* W_I8, dense layers, nullable: device int32 [N], sum over k of the
                           codes of each output feature.  Lets the MFMA dense kernel read
                           uint8 rows as x - 128 (any count 0..255) and add 128 * col_sum back */
+  const void *wt_fp6;  /* W_I8, dense layers, nullable: the codes as fp6 MFMA tiles
+                          (snnqp_pack_codes_fp6; needs code_max <= 7).  With it a dense block
+                          over bit-packed rows runs on the f8f6f4 MFMA: 6 bits per code from
+                          HBM / L2, K = 64 per instruction */
   uint32_t min_current_bits; /* float32 bits of the smallest non-zero |input current| the block
                           can see with the BatchNorm it is used with -- snnqp_current_min()
                           with bound = abs_sum_max (bit-packed inputs);
@@ -191,6 +195,15 @@ int snnqp_quantize(int kind, const float *w, const float *mask, int64_t n,
  * wave and k-step.  K and Npad must be multiples of 32. */
 int snnqp_pack_codes_mfma(const int8_t *w, int64_t K, int32_t N, int32_t Npad,
                           int8_t *wt, snnqp_stream_t stream);
+
+/* The "packed int load" of a dense kernel whose codes have magnitude <= 7 (DuQ up to 4 bits):
+ * int8 codes [K][N] -> fp6 (e2m3) B-operand tiles of v_mfma_scale_f32_32x32x64_f8f6f4,
+ * wt6[Npad/32][ceil(K/64)][1536 B]: for column block nb and k-step ks, lane l = (n & 31) + 32 h
+ * holds k = 64 ks + 32 h + j (j < 32) of column n = 32 nb + (l & 31), value j at bits
+ * [6 j, 6 j + 6) of six dwords; a tile stores dwords 0..3 of its 64 lanes (1 KiB), then dwords
+ * 4..5 (512 B).  Rows beyond K and columns beyond N are zero.  0.75 bytes per code. */
+int snnqp_pack_codes_fp6(const int8_t *w, int64_t K, int32_t N, int32_t Npad, void *wt6,
+                         snnqp_stream_t stream);
 
 /* ---- activation format helpers ------------------------------------------
  * replaces: nothing in the reference (its activations are float32 arrays);
@@ -289,8 +302,9 @@ int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bou
  * snnqp_pack_codes_mfma (Npad = N rounded up to 32; K rows zero-padded to a multiple
  * of 32 when K is not one), s_type BITS and either BITS input (zero bits beyond K),
  * T <= 96, or U8 input (any count 0..255, read in place: no packing pass, no inspection)
- * with w->col_sum, K % 16 == 0, K <= 65536, 16-byte aligned rows and T <= 64.  Longer runs
- * and everything else: the direct-form kernel. */
+ * with w->col_sum, K % 16 == 0, K <= 65536, 16-byte aligned rows and T <= 64.  With
+ * w->wt_fp6 and code_max <= 7, BITS rows run on the fp4 x fp6 MFMA instead (T <= 160, `wt` not
+ * needed).  Longer runs and everything else: the direct-form kernel. */
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,

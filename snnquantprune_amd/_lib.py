@@ -32,7 +32,7 @@ OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
 class WeightT(Structure):
   _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
               ("abs_sum_max", c_int32), ("code_max", c_int32), ("col_sum", c_void_p),
-              ("min_current_bits", c_uint32)]
+              ("wt_fp6", c_void_p), ("min_current_bits", c_uint32)]
 
 
 BN_MEAN_ZERO, BN_BIAS_ZERO = 1, 2
@@ -64,6 +64,7 @@ _PROTOTYPES = {
                                c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snnqp_pack_codes_mfma": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                       c_void_p]),
+    "snnqp_pack_codes_fp6": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_inspect_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_inspect_u8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "snnqp_f32_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -100,6 +100,13 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                 SNNQP_EINVAL, "dense_lif_forward: unknown neuron kind %d", nrn->kind);
   SNNQP_REQUIRE(impl >= SNNQP_IMPL_AUTO && impl <= SNNQP_IMPL_MFMA, SNNQP_EINVAL,
                 "dense_lif_forward: unknown impl %d", impl);
+  // codes that fit fp6, packed as fp6 tiles, over bit-packed rows: the f8f6f4 kernel
+  if (impl != SNNQP_IMPL_GENERIC && in_type == SNNQP_BITS && s_type == SNNQP_BITS &&
+      w->wtype == SNNQP_W_I8 && w->wt_fp6 && w->code_max > 0 && w->code_max <= 7 && T <= 160 &&
+      !(nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) && x_stride_t >= 0 && x_stride_b >= 0 &&
+      (int64_t)(T > 0 ? T - 1 : 0) * x_stride_t + 160 * x_stride_b + (K + 31) / 32 < ((int64_t)1 << 31))
+    return run_dense_fp6(x, x_stride_t, x_stride_b, T, B, K, N, w, bn, nrn, u0, u_out,
+                         (uint32_t *)s_out, 0, (hipStream_t)stream);
   const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
   if (!why && T > (in_type == SNNQP_U8 ? 64 : 96))
     why = "more than 96 (uint8 input: 64) timesteps (one sample must fit a row tile)";

@@ -37,4 +37,10 @@ int run_dense_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, hipStream_t st);
 
+// codes of magnitude <= 7 on the f8f6f4 MFMA (dense_fp6.hip); row_tiles 0 = choose
+int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B, int32_t K,
+                  int32_t N, const snnqp_weight_t *w, const snnqp_bn_t *bn,
+                  const snnqp_neuron_t *nrn, const float *u0, float *u_out, uint32_t *s_out,
+                  int row_tiles, hipStream_t st);
+
 }  // namespace snnqp

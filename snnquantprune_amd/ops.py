@@ -236,11 +236,13 @@ class Weight:
   code_max: int = 0         # max |code| (<= 7: exact in fp6)
   min_current_bits: int = 0  # smallest non-zero |BN(dequant(acc))| as float bits (current_min)
   col_sum: Optional[torch.Tensor] = None   # dense: int32 [N] column sums of the codes (uint8 input)
+  wt6: Optional[torch.Tensor] = None       # dense, code_max <= 7: fp6 MFMA tiles (pack_codes_fp6)
 
   def struct(self) -> L.WeightT:
     return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
                      int(self.abs_sum_max), int(self.code_max),
                      None if self.col_sum is None else self.col_sum.data_ptr(),
+                     None if self.wt6 is None else self.wt6.data_ptr(),
                      int(self.min_current_bits))
 
   @property
@@ -355,6 +357,19 @@ def pack_codes_mfma(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.T
   wt = torch.empty((n_pad // 32, K // 32, 64, 16), dtype=torch.int8, device=codes.device)
   L.check(L.lib().snnqp_pack_codes_mfma(_ptr(c2), K, N, n_pad, _ptr(wt), _stream()))
   return wt
+
+
+def pack_codes_fp6(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
+  """[K, N] int8 codes of magnitude <= 7 -> fp6 MFMA tiles, uint8 [Npad/32, ceil(K/64), 1536]
+  (snnqp_pack_codes_fp6): the packed form the f8f6f4 dense kernel streams."""
+  _require_gpu(codes)
+  assert codes.dtype == torch.int8
+  c2 = codes.reshape(-1, codes.shape[-1]).contiguous()
+  K, N = c2.shape
+  n_pad = (N + 31) // 32 * 32 if n_pad is None else n_pad
+  wt6 = torch.empty((n_pad // 32, (K + 63) // 64, 1536), dtype=torch.uint8, device=codes.device)
+  L.check(L.lib().snnqp_pack_codes_fp6(_ptr(c2), K, N, n_pad, _ptr(wt6), _stream()))
+  return wt6
 
 
 # ---------------------------------------------------------------------------

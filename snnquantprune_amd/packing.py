@@ -124,8 +124,13 @@ class PackedKernel:
       else:
         tiles_src = codes
       wt = ops.pack_codes_mfma(tiles_src, n_pad) if tiles_src.shape[0] % 32 == 0 else None
+      # dense kernels whose codes fit fp6 (DuQ up to 4 bits): also the 6-bit packed tiles of
+      # the f8f6f4 kernel (any K: the packer pads with zero codes)
+      wt6 = None
+      if self.kernel.ndim == 2 and 0 < base.code_max <= 7:
+        wt6 = ops.pack_codes_fp6(codes, n_pad)
       w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max,
-                     code_max=base.code_max, col_sum=base.col_sum)
+                     code_max=base.code_max, col_sum=base.col_sum, wt6=wt6)
       self._wt[key] = w
     return w
 

@@ -52,3 +52,30 @@ def pack_ev4(x):
   """uint8 counts <= 15 [..., H, W, 2] -> uint8 [..., H*W] (SNNQP_EV4: polarity 0 low nibble)."""
   x = np.asarray(x).astype(np.uint8)
   return (x[..., 0] + 16 * x[..., 1]).astype(np.uint8).reshape(x.shape[:-3] + (-1,))
+
+
+def fp6_tiles(codes, n_pad=None):
+  """int8 codes [K, N] with |c| <= 7 -> the fp6 (e2m3) MFMA tiles of snnqp_pack_codes_fp6,
+  uint8 [Npad/32, ceil(K/64), 1536], restated from the layout in include/snnqp.h: lane
+  l = (n & 31) + 32 h of tile (nb, ks) holds k = 64 ks + 32 h + j, value j at bits [6j, 6j+6)
+  of six little-endian dwords; dwords 0..3 of the 64 lanes first (1 KiB), then dwords 4..5."""
+  codes = np.asarray(codes, np.int64)
+  K, N = codes.shape
+  n_pad = (N + 31) // 32 * 32 if n_pad is None else n_pad
+  KS = (K + 63) // 64
+  full = np.zeros((KS * 64, n_pad), np.int64)
+  full[:K, :N] = codes
+  mag = np.array([0x00, 0x08, 0x10, 0x14, 0x18, 0x1A, 0x1C, 0x1E], np.uint64)   # e2m3 of 0..7
+  e = (mag[np.abs(full)] | np.where(full < 0, 0x20, 0).astype(np.uint64))      # [KS*64, n_pad]
+  out = np.zeros((n_pad // 32, KS, 1536), np.uint8)
+  for nb in range(n_pad // 32):
+    blk = e[:, nb * 32:(nb + 1) * 32].reshape(KS, 2, 32, 32)       # [ks, h, j, n]
+    bits = np.zeros((KS, 2, 32, 192), np.uint8)                    # [ks, h, n, bit]
+    for j in range(32):
+      for b in range(6):
+        bits[:, :, :, 6 * j + b] = ((blk[:, :, j, :] >> np.uint64(b)) & np.uint64(1)).astype(np.uint8)
+    by = np.packbits(bits, axis=-1, bitorder="little")             # [ks, h, n, 24 bytes]
+    lanes = by.transpose(0, 1, 2, 3).reshape(KS, 64, 24)           # lane = n + 32 h
+    out[nb, :, :1024] = lanes[:, :, :16].reshape(KS, 1024)
+    out[nb, :, 1024:] = lanes[:, :, 16:].reshape(KS, 512)
+  return out

@@ -2187,3 +2187,70 @@ def test_capture_replays_the_model_as_one_graph(dev, oracle):
       logits, _ = step3(inp)
       torch.cuda.synchronize()
       np.testing.assert_array_equal(_np(logits), e3["logits"])
+
+
+# ---------------------------------------------------------------------------
+# dense blocks on the f8f6f4 MFMA (codes of magnitude <= 7, packed as fp6)
+# ---------------------------------------------------------------------------
+
+
+def test_fp6_tiles_match_the_documented_layout(dev):
+  """snnqp_pack_codes_fp6 against the layout of include/snnqp.h restated in tests/helpers.py:
+  K not a multiple of 64, N not a multiple of 32, every code value -7..7."""
+  from snnquantprune_amd import ops
+  from tests.helpers import fp6_tiles
+  rng = np.random.Generator(np.random.PCG64(66))
+  for K, N in ((64, 32), (200, 70), (4100, 110)):
+    codes = rng.integers(-7, 8, (K, N)).astype(np.int8)
+    codes[rng.random((K, N)) < 0.5] = 0
+    got = ops.pack_codes_fp6(_t(codes, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, fp6_tiles(codes))
+
+
+@pytest.mark.parametrize("shape", [(20, 64, 32768, 110, 4), (6, 5, 200, 70, 4), (33, 9, 64, 33, 3),
+                                   (10, 3, 96, 160, 2), (100, 3, 4100, 110, 4), (160, 1, 256, 40, 4),
+                                   (20, 300, 2048, 512, 4)],
+                         ids=["readout", "ragged_k_n", "t33_3bit", "two_col_blocks_2bit", "t100_odd_k",
+                              "t160", "four_col_blocks_many_rows"])
+def test_dense_block_fp6_mfma(dev, oracle, shape):
+  """Dense block whose codes fit fp6 (DuQ 2, 3 and 4 bits) on the f8f6f4 kernel: rasters and
+  potentials against the oracle, against the int8 kernel and the direct-form kernel on the
+  same inputs; carried-in state, BatchNorm, batch-major rows, every neuron form; K that is
+  not a multiple of 32 / 64 / 256, N beyond one 128-feature block, T up to 160."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, K, N, bits = shape
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N, bits=bits, p=0.9 if K > 1000 else 0.5)
+  qw = qweight_of(oracle, c["leaf"], bits)
+  w = _weight(c["leaf"], bits, dev, transposed=True)
+  assert w.wt6 is not None and 0 < w.code_max <= 7
+  x = ops.pack_bits(_t(c["x"], dev))
+  u0 = _t(c["u0"], dev)
+  ops.fallback_counts(reset=True)
+  eu, es = oracle.dense_block(c["x"], qw, None, "int", u0=c["u0"])
+  assert 0.005 < es.mean() < 0.6, es.mean()
+  u, s = ops.dense_lif_forward(x, w, K, N, _mslif(), u0=u0, packed_out=True)
+  np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+  w8 = dataclasses.replace(w, wt6=None)                           # the int8 kernel, same codes
+  if w8.wt is not None and T <= 96:
+    u8, s8 = ops.dense_lif_forward(x, w8, K, N, _mslif(), u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+    np.testing.assert_array_equal(_np(s8), _np(s))
+    np.testing.assert_array_equal(_np(u8), _np(u))
+  xb = ops.pack_bits(_t(np.ascontiguousarray(np.swapaxes(c["x"], 0, 1)), dev))
+  ub, sb = ops.dense_lif_forward(xb, w, K, N, _mslif(), u0=u0, packed_out=True, time_major=False)
+  np.testing.assert_array_equal(_np(sb), _np(s))
+  np.testing.assert_array_equal(_np(ub), _np(u))
+  if B * T * K * N < 5e9:
+    rng = np.random.Generator(np.random.PCG64(N))
+    bnd = dict(mean=(0.1 * rng.standard_normal(N)).astype(F32), var=(1 + 0.3 * rng.random(N)).astype(F32),
+               scale=(1 + 0.2 * rng.standard_normal(N)).astype(F32), bias=(0.1 * rng.standard_normal(N)).astype(F32))
+    for nrn in (ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, 0.8, 0.1),
+                ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, 0.3, 1.0, 0.0),
+                ops.Neuron(L.NEURON_LIF, 0.0, 1.0, 0.0, decay=_t(np.linspace(0.2, 0.9, N).astype(F32), dev))):
+      ua, sa = ops.dense_lif_forward(x, w, K, N, nrn, bn=_bn(bnd, dev), packed_out=True)
+      ug, sg = ops.dense_lif_forward(x, w, K, N, nrn, bn=_bn(bnd, dev), packed_out=True, impl=L.IMPL_GENERIC)
+      np.testing.assert_array_equal(_np(sa), _np(sg))
+      np.testing.assert_array_equal(_np(ua), _np(ug))
+  assert ops.fallback_counts()["dense_blocks"] == 0
