@@ -71,12 +71,14 @@ def parse(argv=None):
   ap.add_argument("--model", choices=("c3", "cextnet", "dense"), default="c3",
                   help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
                        "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
-  ap.add_argument("--input", choices=("u8", "f32", "ev1", "ev4"), default="u8",
-                  help="input format: uint8 event frames (default), the float32 frames the "
-                       "reference's pipeline hands over (inspected and narrowed on device inside "
-                       "the step), or the packed wire formats of include/snnqp.h -- ev1: bit-packed "
-                       "binary frames (81 920 B per sample instead of 655 360), ev4: nibble-packed "
-                       "counts <= 15 (327 680 B)")
+  ap.add_argument("--input", choices=("u8", "f32", "ev1", "ev4"), default=None,
+                  help="format of the resident input batch.  ev1 (default for binary frames): the "
+                       "bit-packed wire format of include/snnqp.h, 81 920 B per sample -- what the "
+                       "host feed can deliver (uint8 frames need 50 GB/s per GPU at this rate) and "
+                       "what the event layer stages directly; u8 (default with --counts and for "
+                       "--model dense): uint8 frames, 655 360 B per sample; f32: the float32 frames "
+                       "the reference's pipeline hands over (inspected and narrowed on device inside "
+                       "the step); ev4: nibble-packed counts <= 15 (327 680 B)")
   ap.add_argument("--feed", choices=("resident", "host"), default="resident",
                   help="resident: the batch is in HBM before the timed region (the contract's "
                        "`value`).  host: every step's batch comes from page-locked host memory "
@@ -108,6 +110,10 @@ def parse(argv=None):
   ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
   ap.add_argument("--stand-in", action="store_true", help=argparse.SUPPRESS)
   args = ap.parse_args(argv)
+  if args.input is None:
+    args.input = "u8" if (args.counts or args.model == "dense" or args.stand_in) else "ev1"
+  if args.input == "ev1" and args.counts:
+    ap.error("--input ev1 holds binary frames; count frames travel as ev4 or u8")
   if args.layer_bits:
     args.layer_bits = [int(b) for b in args.layer_bits.split(",")]
     if len(args.layer_bits) != 4 or args.model != "c3":
@@ -523,6 +529,25 @@ def main(argv=None):
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
   dt = float(tmax.item())
 
+  # the same steps on resident uint8 frames (the format of rounds 1 and 2's headline), when the
+  # line itself is on bit-packed frames
+  alt = None
+  if (gpu and ops is not None and frames_u8 is not None and args.input == "ev1"
+      and args.feed == "resident" and not args.no_fed_leg and not args.graph):
+    for _ in range(2):
+      parallel.all_gather_rows(apply_fn(frames_u8))
+    fence()
+    ta = time.perf_counter()
+    for _ in range(args.steps):
+      ops.forget_inputs()
+      parallel.all_gather_rows(apply_fn(frames_u8))
+    fence()
+    tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
+    if world > 1:
+      torch.distributed.all_reduce(tb, op=torch.distributed.ReduceOp.MAX)
+    alt = {"format": "u8 (uint8 frames, 655 360 B per sample)", "steps": args.steps,
+           "ms_per_step": float(tb.item()) / args.steps * 1e3,
+           "samples_per_s": world * B * args.steps / float(tb.item())}
   # the host-fed leg (every rank runs it: the step holds a collective); binary frames only
   fed = None
   if (gpu and ops is not None and frames_u8 is not None and args.feed == "resident"
@@ -549,7 +574,9 @@ def main(argv=None):
                       "(f8f6f4 MFMA, sums < 2^24 exact) when the codes fit (<= 4 bits), else int8; "
                       "membrane potentials f32",
       "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
-              % args.lam + ", N(0,1/fan_in) weights, " +
+              % args.lam + {"ev1": " as bit-packed frames (EV1, include/snnqp.h)", "ev4": " as nibble-packed "
+                            "frames (EV4)", "u8": " as uint8 frames", "f32": " as float32 frames"}[args.input] +
+              ", N(0,1/fan_in) weights, " +
               ("random BatchNorm statistics" if args.random_bn else "BatchNorm as initialised") +
               ", random seeds fixed",
       "config": {"workload": ("C2: qdense(2048->512)+LIF -> qdense(512->%d)+LIF + vote, [B, T, 2048] "
@@ -589,6 +616,8 @@ def main(argv=None):
   if fed is not None:
     fed["vs_resident"] = fed["samples_per_s_per_gpu"] / (value / world)
     line["fed"] = fed
+  if alt is not None:
+    line["resident_u8"] = alt
   line.update(rooflines_of(args, prof, B, T, lb))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:
@@ -622,8 +651,11 @@ def rooflines_of(args, prof, B, T, lb):
                                   B * T * (64 * 64 * 16 + 32 * 32 * 16), conv_peak(lb[1])),
       "conv3x3[32x32x128->128]": (B * T * 32 * 32 * 128 * 1152,
                                   B * T * (32 * 32 * 16 + 16 * 16 * 16), conv_peak(lb[2])),
-      "dense[32768->%d]" % nout: (B * T * 32768 * nout, B * T * (4096 + 16) + 32768 * 128,
-                                  INT8_MFMA_PEAK_TOPS),
+      # read-out: bit-packed rows in, spike words out, the codes once per launch -- 6-bit packed
+      # (fp6 tiles, f8f6f4 MFMA) when they fit, else int8
+      "dense[32768->%d]" % nout: (B * T * 32768 * nout,
+                                  B * T * (4096 + 16) + 32768 * 128 * (3 if lb[3] <= 4 else 4) // 4,
+                                  conv_peak(lb[3])),
       # config C2 (bit-packed spikes in and out, int8 codes once per launch)
       "dense[2048->512]": (B * T * 2048 * 512, B * T * (256 + 64) + 2048 * 512, INT8_MFMA_PEAK_TOPS),
       "dense[512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 16) + 512 * 128, INT8_MFMA_PEAK_TOPS),
@@ -680,7 +712,7 @@ def rooflines_of(args, prof, B, T, lb):
   dense_tag = "dense[2048->512]" if args.model == "dense" else "dense[32768->%d]" % nout
   groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
             "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
-            "dense_mfma_kernel": [dense_tag] + (["dense[512->%d]" % nout] if args.model == "dense" else [])}
+            "dense kernel": [dense_tag] + (["dense[512->%d]" % nout] if args.model == "dense" else [])}
   gtime = {g: sum(kern[t]["avg_ms"] * kern[t]["launches"] for t in tags if t in kern)
            for g, tags in groups.items()}
   out = {"kernels": kern}
@@ -771,7 +803,9 @@ def rooflines_of(args, prof, B, T, lb):
                       "unit": "GB/s", "frac": dn["hbm_frac"], "traffic": dn["traffic"],
                       "avg_launch_ms": dn["avg_launch_ms"], "mfma_frac": dn["mfma_frac"],
                       "ceiling_hbm_frac": nbytes / t_mfma / 1e9 / HBM_PEAK_GBS,
-                      "ceiling": "int8 MFMA peak: %.3f ms per launch" % (t_mfma * 1e3)}
+                      "ceiling": "%s MFMA peak: %.3f ms per launch; in practice the code stream "
+                                 "through each CU's vector L1 (64 B/clk) binds first, DESIGN.md 4.4"
+                                 % ("fp6" if peak == FP6_MFMA_PEAK_TOPS else "int8", t_mfma * 1e3)}
   out.update(roofline=roofline, roofline_dense=roofline_dense,
              rooflines=[rooflines[k] for k in sorted(rooflines)])
   return out

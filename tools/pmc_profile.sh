@@ -7,7 +7,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc
 mkdir -p $OUT
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-fed-leg $@"
 run() {  # name, counters...
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- \
@@ -18,5 +18,5 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
-python tools/pmc_summary.py $OUT --json $OUT/summary.json --traffic $OUT/traffic.json > $OUT/summary.txt
+python tools/pmc_summary.py $OUT --json $OUT/summary.json --traffic $OUT/traffic.json --input-format ${PMC_INPUT:-ev1} > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -63,6 +63,8 @@ if "--traffic" in sys.argv:
     if tag:
       tags[tag] = int(2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024)
   with open(sys.argv[sys.argv.index("--traffic") + 1], "w") as f:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py "
+    fmt = sys.argv[sys.argv.index("--input-format") + 1] if "--input-format" in sys.argv else "u8"
+    json.dump({"input": fmt,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py "
                          "--steps 1 --warmup 1` (tools/pmc_profile.sh), bytes = 2 * FETCH_SIZE "
                          "KiB + WRITE_SIZE KiB", "bytes_per_launch": tags}, f, indent=1, sort_keys=True)

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 pass() {  # pass name, counters...
   p=$1; shift
   ( cd /tmp; SNNQP_DIAG_LIB=$lib rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$name/$p -- \
-      python $GRAFT_REPO_ROOT/bench.py --allow-diag --steps 1 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $O/pmc_${name}_$p.json 2> $O/pmc_${name}_$p.err )
+      python $GRAFT_REPO_ROOT/bench.py --allow-diag --steps 1 --warmup 1 --no-cpu-baseline --no-fed-leg $BENCH_ARGS > $O/pmc_${name}_$p.json 2> $O/pmc_${name}_$p.err )
 }
 pass w SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 pass i SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_SCA
