@@ -23,8 +23,6 @@
 // it retires the chunk's LDS writes, not the fragments in flight).  Spike words are requested
 // four chunks ahead, B fragments two (register rings of three), and every wave interleaves its
 // MFMAs with its share of the loads and of the expansion, slot by slot.
-#include <cstdlib>
-
 #include "kernels.h"
 
 namespace snnqp {
@@ -152,11 +150,15 @@ dense_fp6_kernel(DenseFp6Args a) {
   const bool wave_on = nb * 32 < a.N;
   const int nchunks = (a.KS + F6_KSC - 1) / F6_KSC;   // chunk j of this group = 2 j + grp
   const int ngc = (nchunks + F6_KGROUPS - 1) / F6_KGROUPS;     // chunks per group
-  // Every workgroup streams the same code tiles.  Walking K in the same order, the workgroups
-  // of an XCD ask its L2 for the same lines at the same time and queue on one channel; the
-  // sums are exact integers, so each workgroup starts its walk at another chunk (step `lc` of
-  // the loop is chunk (lc + rot) mod ngc) and the requests spread over the channels.
-  const int rot = (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)ngc);
+  // Every workgroup streams the same code tiles.  Walking K in the same order, all of them ask
+  // for the same lines at the same time; the sums are exact integers, so the walk may start
+  // anywhere: step `lc` of the loop is chunk (lc + rot) mod ngc, with one `rot` per XCD
+  // (blockIdx.x mod 8 under the observed round-robin placement -- a speed assumption only).
+  // The workgroups of an XCD still share each tile in its L2 (measured HBM-side traffic 106 MB
+  // against 104 MB unrotated; a rotation per WORKGROUP thrashes the 4 MiB L2 with 32 different
+  // tiles at a time: 162 MB), the eight XCDs no longer hit the same memory channels together:
+  // 0.072 ms against 0.078.
+  const int rot = (int)(((blockIdx.x & 7u) * (unsigned)ngc) >> 3);
   auto phys = [&](int lc) -> int {     // loop step -> this group's chunk; steps beyond ngc: a dead chunk
     const int pc = lc + rot >= ngc ? lc + rot - ngc : lc + rot;
     return lc < ngc ? pc : nchunks;
@@ -412,10 +414,6 @@ int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t 
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out;
   const unsigned gy = (unsigned)((N + 127) / 128);
-  if (row_tiles <= 0) {               // tuning knob (tools/dense_fp6_sweep.sh), not an interface
-    const char *e = std::getenv("SNNQP_DENSE_FP6_RT");
-    if (e) row_tiles = std::atoi(e);
-  }
   int rt = row_tiles >= 1 && row_tiles <= 5 && row_tiles * 32 >= T ? row_tiles : pick_row_tiles(T, B, gy);
   SNNQP_REQUIRE(rt > 0, SNNQP_EUNSUPPORTED, "dense fp6: T too large");
   a.SB = rt * 32 / T;
