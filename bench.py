@@ -109,6 +109,10 @@ def parse(argv=None):
   # stand-in for model.apply (tests/test_host_cpu.py); never a measurement
   ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
   ap.add_argument("--stand-in", action="store_true", help=argparse.SUPPRESS)
+  ap.add_argument("--single-rank-collective", action="store_true",
+                  help="with --gpus 1: create the RCCL process group anyway, so that the step's "
+                       "all-gather, the barrier and the all-reduce of the timing run through RCCL "
+                       "on the one GPU (rehearsal of the multi-GPU path; the line says so)")
   args = ap.parse_args(argv)
   if args.input is None:
     args.input = "u8" if (args.counts or args.model == "dense" or args.stand_in) else "ev1"
@@ -346,7 +350,8 @@ def main(argv=None):
   from snnquantprune_amd import parallel
 
   gpu = args.backend == "nccl"
-  rank, world, local = parallel.init_from_env(args.backend)
+  rank, world, local = parallel.init_from_env(args.backend, args.single_rank_collective)
+  collective = world > 1 or args.single_rank_collective
   if world != args.gpus:
     raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
   if gpu:
@@ -376,7 +381,7 @@ def main(argv=None):
     except Exception:
       ident["rccl"] = "unknown"
   print("bench.py rank %s" % json.dumps(ident), file=sys.stderr, flush=True)
-  if world > 1:
+  if collective:
     ids = [None] * world
     torch.distributed.all_gather_object(ids, ident)
   else:
@@ -452,7 +457,7 @@ def main(argv=None):
     return parallel.all_gather_rows(apply_fn(xb))
 
   def fence():
-    if world > 1:
+    if collective:
       if gpu:
         torch.distributed.barrier(device_ids=[local])
       else:
@@ -522,7 +527,7 @@ def main(argv=None):
 
   tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
   rank_dt = [dt]
-  if world > 1:
+  if collective:
     every = torch.zeros(world, device=dev, dtype=torch.float64)
     torch.distributed.all_gather_into_tensor(every, tmax)
     rank_dt = [float(v) for v in every.tolist()]
@@ -543,7 +548,7 @@ def main(argv=None):
       parallel.all_gather_rows(apply_fn(frames_u8))
     fence()
     tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
-    if world > 1:
+    if collective:
       torch.distributed.all_reduce(tb, op=torch.distributed.ReduceOp.MAX)
     alt = {"format": "u8 (uint8 frames, 655 360 B per sample)", "steps": args.steps,
            "ms_per_step": float(tb.item()) / args.steps * 1e3,
@@ -554,7 +559,7 @@ def main(argv=None):
       and not args.no_fed_leg and not args.counts and not args.graph):
     fed = fed_leg(args, frames_u8, apply_fn, parallel, fence, dev, args.steps, min(args.warmup, 2))
     tf = torch.tensor([fed["ms_per_step"]], device=dev, dtype=torch.float64)
-    if world > 1:
+    if collective:
       torch.distributed.all_reduce(tf, op=torch.distributed.ReduceOp.MAX)
     fed["ms_per_step"] = float(tf.item())
     fed["samples_per_s_per_gpu"] = B / (fed["ms_per_step"] * 1e-3)
@@ -597,6 +602,9 @@ def main(argv=None):
   line["ranks_seen"] = len({(i.get("pci"), i.get("device"), i["rank"]) for i in ids})
   line["ranks"] = [{k: i.get(k) for k in ("rank", "device", "pci", "rccl", "pid") if k in i} for i in ids]
   line["rank_seconds"] = rank_dt
+  line["collective"] = ("%s process group of %d rank(s): all-gather of the logits every step, "
+                        "barrier + all-reduce(MAX) around the timed region" % (args.backend, world)
+                        ) if collective else "none (one process, no process group)"
   if ops is not None:
     line["fallbacks"] = ops.fallback_counts()      # blocks on the direct-form kernel (should be 0)
   if args.graph:

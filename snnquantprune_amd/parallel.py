@@ -18,12 +18,17 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None):
-  """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False):
+  """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).
+  `single_rank_group`: create the process group even for one rank, so that the collectives
+  below really run through the backend (RCCL on one GPU: the communicator, the all-gather
+  kernel and the device-bound barrier execute; what a one-GPU box can rehearse of C4)."""
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", str(rank)))
-  if world > 1 and not dist.is_initialized():
+  if single_rank_group and world == 1:
+    os.environ.setdefault("MASTER_PORT", "29599")
+  if (world > 1 or single_rank_group) and not dist.is_initialized():
     if backend is None:
       backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
@@ -49,7 +54,7 @@ def shard_batch(x, rank: int, world: int, batch_axis: int = 0):
 
 def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
   """[b, ...] on every rank -> [world * b, ...] (rank-major), one collective."""
-  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+  if not dist.is_initialized():
     return x
   x = x.contiguous()
   world = dist.get_world_size(group)
