@@ -1,6 +1,7 @@
-"""Randomised shapes through the fused conv block: the MFMA kernels (work queue, clipped
-edge patches, masked channel words, padded Cin, both operand formats, conv0 variants)
-against the direct-form kernel on the same inputs, bit for bit."""
+"""Randomised shapes through the fused blocks: the MFMA kernels (work queue, clipped edge
+patches, masked channel words, padded Cin, both operand formats, conv0 variants on uint8 and
+on bit-packed frames; dense blocks on the int8 and the fp6 instruction, on bit-packed and on
+uint8 rows) against the direct-form kernel on the same inputs, bit for bit."""
 import numpy as np
 import torch
 
@@ -60,6 +61,11 @@ def conv_block_random(dev, N, seed, verbose=False):
     if pool == 2:
       sg = ops.maxpool2x2(sg)
     ok = torch.equal(sm.bits, sg.bits) and torch.equal(um, ug)
+    if first and kind == "binary":          # the same launch on bit-packed (EV1) frames
+      ue, se = ops.conv_lif_forward(ops.pack_frames(x, L.EV1), g, w, nrn, bn=bn, u0=u0, packed_out=True,
+                                    pool=pool, impl=L.IMPL_MFMA, x_max=1)
+      ok = ok and torch.equal(se.bits, sg.bits) and torch.equal(ue, ug)
+      tag += " +ev1"
     if not ok:
       failures.append(tag)
     if verbose:
@@ -75,7 +81,7 @@ def dense_block_random(dev, N, seed, verbose=False):
   rng = np.random.Generator(np.random.PCG64(seed))
   failures = []
   for it in range(N):
-    K = int(rng.choice([rng.integers(1, 200), rng.integers(200, 6000), 2048, 512, 784]))
+    K = int(rng.choice([rng.integers(1, 200), rng.integers(200, 6000), 2048, 512, 784, 16 * rng.integers(1, 300)]))
     n_out = int(rng.choice([rng.integers(1, 40), 110, 100, 512, rng.integers(100, 600)]))
     T, B = int(rng.integers(1, 61)), int(rng.integers(1, 40))
     bits = int(rng.choice([3, 4, 5, 8]))
@@ -107,6 +113,16 @@ def dense_block_random(dev, N, seed, verbose=False):
       continue
     ug, sg = ops.dense_lif_forward(x, w, K, n_out, nrn, u0=u0, packed_out=True, impl=L.IMPL_GENERIC)
     ok = torch.equal(sm.bits, sg.bits) and torch.equal(um, ug)
+    if K % 16 == 0 and w.wt is not None and w.col_sum is not None:
+      # uint8 rows read in place (x - 128 operand), binary rows and rows with counts up to 255
+      xu = x.to_dense().to(torch.uint8)
+      uu, su = ops.dense_lif_forward(xu, w, K, n_out, nrn, u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+      ok = ok and torch.equal(su.bits, sg.bits) and torch.equal(uu, ug)
+      xc = torch.from_numpy(np.minimum(rng.poisson(0.3, (T, B, K)) * rng.integers(1, 60), 255).astype(np.uint8)).to(dev)
+      uc, sc = ops.dense_lif_forward(xc, w, K, n_out, nrn, u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+      ugc, sgc = ops.dense_lif_forward(xc, w, K, n_out, nrn, u0=u0, packed_out=True, impl=L.IMPL_GENERIC)
+      ok = ok and torch.equal(sc.bits, sgc.bits) and torch.equal(uc, ugc)
+      tag += " +u8"
     if not ok:
       failures.append(tag)
     if verbose:
