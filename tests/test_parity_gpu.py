@@ -2274,3 +2274,26 @@ def test_bench_runs_its_collectives_through_rccl_on_one_gpu(dev):
   r = d["ranks"][0]
   assert r["rccl"] not in (None, "", "unknown") and r["pci"].count(":") == 2
   assert d["fallbacks"]["conv_blocks"] == 0 and d["value"] > 0
+
+
+def test_eval_command_line_on_a_synthetic_workdir(dev, tmp_path):
+  """`python -m snnquantprune_amd.eval --workdir DIR --config DIR/config.py` on a work directory
+  written by tools/make_synthetic_eval.py (checkpoint file, frames, config file): the harness
+  restores, feeds bit-packed frames, evaluates every sample once and prints one JSON summary;
+  run again on uint8 frames it reports the same metrics."""
+  import json, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+  out = {}
+  for feed in ("ev1", "u8"):
+    wd = str(tmp_path / feed)
+    subprocess.run([sys.executable, os.path.join(root, "tools", "make_synthetic_eval.py"), wd, "--samples",
+                    "12", "--hw", "16", "--frames", "4", "--batch", "4", "--feed", feed], check=True, cwd=root)
+    p = subprocess.run([sys.executable, "-m", "snnquantprune_amd.eval", "--workdir", wd, "--config",
+                        os.path.join(wd, "config.py")], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out[feed] = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out[feed]["steps"] == 3 and out[feed]["samples"] == 12 and out[feed]["world"] == 1
+    assert 0.0 <= out[feed]["accuracy"] <= 1.0 and out[feed]["loss"] > 0
+  assert out["ev1"] == out["u8"]
