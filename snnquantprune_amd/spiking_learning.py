@@ -344,10 +344,11 @@ class SpikingBlock(nn.Module):
     elif isinstance(x, ops.PackedFrames):
       x_max = 1                          # EV1: binary by construction
     else:
-      x_max = ops.input_max_bound(x) if integer else 0
+      # spikes are 1; uint8 counts into a layer with more than two channels go to the direct-form
+      # kernel whatever their values (the C side decides and counts the fallback): nothing to
+      # inspect, nothing for the host to wait for
+      x_max = 1 if isinstance(x, ops.PackedSpikes) else 0
     impl = self.impl
-    if x_max > 127 and impl == L.IMPL_AUTO and cin != 2:
-      impl = L.IMPL_GENERIC            # only the 2-channel event kernel takes counts > 127
     T, B = (x.shape[0], x.shape[1]) if tm else (x.shape[1], x.shape[0])
     if nsp == 1 and not tm:
       raise NotImplementedError("batch-major input for 1-D convolution blocks")
