@@ -271,9 +271,12 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       MFMA kernels dequantise through.  It is a hint, not a promise: the U8 kernel takes
  *       the maximum of every chunk of input it stages and runs the general path (any count up
  *       to 255, arithmetic dequantisation) for a chunk that exceeds it -- same results, slower.
- * x_seen nullable device word (the caller zeroes it): atomically max-ed with the largest U8
- *       input value the launch met, so the caller can refine its next hint asynchronously;
- *       nothing ever waits for it. */
+ * x_seen nullable, EIGHT device words the caller zeroes: [0] is atomically max-ed with the
+ *       largest U8 input value the launch met, [1..5] receive the number of staged chunks (a
+ *       patch x up to 32 timesteps) whose largest value was <= 1, 2, <= 7, <= 31, above; [6..7]
+ *       are reserved.  From these the caller refines its next hint asynchronously -- a hint
+ *       that covers MOST chunks is the fast one: a hot pixel then costs its own few chunks the
+ *       general path instead of the whole batch the slower tables.  Nothing ever waits for it. */
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
                            const snnqp_conv_geom_t *g, const snnqp_weight_t *w,

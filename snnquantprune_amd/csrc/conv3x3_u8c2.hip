@@ -42,7 +42,8 @@ namespace snnqp {
 // its maximum, and a chunk that holds a larger value (a hot pixel, event counts where
 // binary frames were expected, a stale hint) runs the general path -- input as x - 128,
 // arithmetic dequantisation, any count up to 255 -- for that chunk only.  The largest
-// value a launch saw goes to *x_seen, from which the caller refines its next hint without
+// value a launch saw goes to x_seen[0] and the count of staged chunks by their largest value to
+// x_seen[1..5] (<= 1, <= 2, <= 7, <= 31, above), from which the caller refines its next hint without
 // ever waiting for it (no inspection pass, no host synchronisation before the launch).
 // ---------------------------------------------------------------------------
 constexpr int HROW2 = 24;                 // LDS bytes per halo row
@@ -195,6 +196,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int ob1 = out_pix<POOL>(1, lane) * 4 + wave;
   const bool store_lane = POOL ? lane < 8 : lane < 32;
   uint32_t seen = 0;                       // largest input value this thread's waves met
+  // staged chunks by their largest value: <= 1, <= 2, <= 7, <= 31, above (workgroup-uniform
+  // counters; they reach x_seen[1..5] once, at the end of the launch)
+  uint32_t hist[5] = {0, 0, 0, 0, 0};
   // staging tasks: waves 0-1 take the even timesteps of a chunk, waves 2-3 the odd ones; the
   // first 100 threads of each pair take one halo pixel each.  The timestep is uniform over a
   // wave, so a load is a scalar frame address plus this thread's 32-bit pixel offset.
@@ -292,6 +296,11 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       const uint32_t cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wgw[1]);   // one word
       seen = max(seen, cmax);
       pseen = max(pseen, cmax);
+      hist[0] += cmax <= 1u;
+      hist[1] += cmax == 2u;
+      hist[2] += cmax > 2u && cmax <= 7u;
+      hist[3] += cmax > 7u && cmax <= 31u;
+      hist[4] += cmax > 31u;
       general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
       if (s_task) {
 #pragma unroll
@@ -365,7 +374,12 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     }
     r = r_next;
   }
-  if (a.x_seen && tid == 0 && seen != 0) atomicMax(a.x_seen, seen);
+  if (a.x_seen && tid == 0) {
+    if (seen != 0) atomicMax(a.x_seen, seen);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (hist[k] != 0) atomicAdd((uint32_t *)a.x_seen + 1 + k, hist[k]);
+  }
   if (pw.queue && tid == 0) pw.finish();
 }
 

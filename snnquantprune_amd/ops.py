@@ -424,18 +424,30 @@ def input_max_bound(x) -> int:
 
 
 class CountHint:
-  """What the first layer's kernel should size its tables for: the largest event count it
-  is likely to meet on this device (1 = binary frames).  The kernel never trusts it -- it
-  checks every chunk of input it stages and falls back per chunk (snnqp.h, x_max) -- and
-  reports the largest value it saw into `word`; that word is copied back with a
-  non-blocking copy and looked at on a later call, when the copy has long finished, so
-  the host never waits for the device to learn about its input."""
+  """What the first layer's kernel should size its tables for: the largest event count MOST of
+  its staged chunks will hold on this device (1 = binary frames).  The kernel never trusts it
+  -- it checks every chunk of input it stages and falls back per chunk (snnqp.h, x_max) -- and
+  reports into `word` (eight int32 words: the largest value it saw and the number of chunks by
+  their largest value, <= 1, 2, <= 7, <= 31, above); the words are copied back with a
+  non-blocking copy and looked at on a later call, when the copy has long finished, so the host
+  never waits for the device to learn about its input.
+
+  The hint is the bucket bound that minimises the estimated time of the next launch: chunks
+  within the hint run the table sized for it (the larger the table, the slower: COST), chunks
+  above it the general path.  One hot pixel -- real DVS sensors have them -- therefore costs the
+  few chunks that hold it, not the batch (a hint that followed the maximum would put every
+  chunk on the slowest path)."""
+
+  BOUNDS = (1, 2, 7, 31)                    # the buckets' upper bounds; above 31: no table
+  COST = (1.0, 1.15, 1.25, 1.25)            # relative time of a chunk in the table mode of a bound
+  GENERAL = 2.3                             # ... and on the general path (x - 128, arithmetic)
 
   def __init__(self, device):
     self.value = 1
-    self.word = torch.zeros(1, dtype=torch.int32, device=device)
-    self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    self.word = torch.zeros(8, dtype=torch.int32, device=device)
+    self._host = torch.zeros(8, dtype=torch.int32).pin_memory()
     self._event = None
+    self.max_seen = 0
 
   @staticmethod
   def capturing() -> bool:
@@ -445,16 +457,34 @@ class CountHint:
     shared word -- so a captured launch gets no `x_seen` word and the last known hint."""
     return torch.cuda.is_current_stream_capturing()
 
+  @classmethod
+  def choose(cls, hist) -> int:
+    """hist = chunks with largest value <= 1, 2, <= 7, <= 31, above -> the hint."""
+    total = sum(hist)
+    if total == 0:
+      return 1
+    best, best_cost = 255, cls.GENERAL * total          # no table fits: every chunk general
+    below = 0
+    for k, (bound, cost) in enumerate(zip(cls.BOUNDS, cls.COST)):
+      below += hist[k]
+      c = cost * below + cls.GENERAL * (total - below)
+      if c < best_cost - 1e-9:
+        best, best_cost = bound, c
+    return best
+
   def current(self) -> int:
     if self.capturing():
       return self.value
     if self._event is not None and self._event.query():
       self._event = None
-      self.value = max(1, int(self._host[0]))
+      words = [int(v) for v in self._host]
+      self.max_seen = words[0]
+      if sum(words[1:6]) > 0:
+        self.value = self.choose(words[1:6])
     return self.value
 
   def seen_word(self):
-    """The device word a launch reports into, or None under graph capture."""
+    """The device words a launch reports into, or None under graph capture."""
     return None if self.capturing() else self.word
 
   def launched(self):
@@ -642,11 +672,14 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
                      x_seen: Optional[torch.Tensor] = None):
   """x [T, B, H, W, Cin] (or [B, T, ...] with time_major=False) ->
   (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout]).
-  x_max: the largest input value expected (a hint, snnqp.h); x_seen: int32 device word that
-  receives the largest uint8 input value the launch met."""
+  x_max: the largest input value expected (a hint, snnqp.h); x_seen: eight int32 device words
+  that receive the largest uint8 input value the launch met and the chunk counts by maximum."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
+  if x_seen is not None:
+    assert x_seen.dtype == torch.int32 and x_seen.numel() >= 8 and x_seen.is_cuda, \
+        "x_seen: eight int32 device words (snnqp.h)"
   T, B = (xt.shape[0], xt.shape[1]) if time_major else (xt.shape[1], xt.shape[0])
   if isinstance(x, PackedFrames):        # [T, B, words / bytes of a frame]
     assert (x.H, x.W, 2) == (geom.H, geom.W, geom.Cin) and xt.ndim == 3, (x.shape, geom)

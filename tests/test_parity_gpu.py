@@ -1529,11 +1529,17 @@ def test_event_layer_checks_its_input_instead_of_trusting_the_hint(dev, oracle):
     cc = dict(c, x=x)
     e = cases.conv_block_expected(oracle, cc)
     for hint in (1, 4, int(x.max())):
-      seen = torch.zeros(1, dtype=torch.int32, device=dev)
+      seen = torch.zeros(8, dtype=torch.int32, device=dev)
       _, s = ops.conv_lif_forward(_t(x, dev), g, w, nrn, bn=bn, want_u=False, packed_out=True,
                                   pool=2, impl=L.IMPL_MFMA, x_max=hint, x_seen=seen)
       np.testing.assert_array_equal(_np(s), e["pooled_bits"], err_msg="%s hint %d" % (name, hint))
-      assert int(seen.item()) == int(x.max()), (name, hint)
+      st = seen.cpu().numpy()
+      assert int(st[0]) == int(x.max()), (name, hint)
+      # every staged chunk (5 samples x 3 x 3 patches, one chunk of 9 timesteps each) is counted
+      # once, by its largest value; the hot pixel (200) sits in the halo of few of them
+      assert int(st[1:6].sum()) == 5 * 9 and int(st[6:].sum()) == 0, st
+      if name == "hot":
+        assert 1 <= int(st[5]) <= 4 and int(st[1]) == 5 * 9 - int(st[5]), st
   # the model path: hints adapt from what the kernel reports, results never change
   cm = cases.conv_net_case(counts=True)
   em = cases.conv_net_expected(oracle, cm)
@@ -1544,7 +1550,8 @@ def test_event_layer_checks_its_input_instead_of_trusting_the_hint(dev, oracle):
     (logits, _) = model.apply(variables, _t(cm["x"], dev), trgt=None, train=False, rng=None)
     np.testing.assert_array_equal(_np(logits), em["logits"])
     torch.cuda.synchronize()
-  assert hint.current() == int(cm["x"].max()) > 1          # learnt without a blocking read
+  # learnt without a blocking read: the bound of the bucket that holds most chunks' maxima
+  assert hint.max_seen == int(cm["x"].max()) > 1 and hint.current() in (2, 7, 31)
   cb = cases.conv_net_case()
   eb = cases.conv_net_expected(oracle, cb)
   vb = nn.tree_from_numpy(cb["vars"], dev)
@@ -1788,7 +1795,7 @@ def test_event_layer_fallback_in_a_later_chunk(dev, oracle):
   for carry in (None, u0):
     eu, es = oracle.conv_block(x, qw, c["bn"], None, "int", u0=carry)
     for hint in (1, 4):
-      seen = torch.zeros(1, dtype=torch.int32, device=dev)
+      seen = torch.zeros(8, dtype=torch.int32, device=dev)
       for pool in (1, 2):
         u, s = ops.conv_lif_forward(_t(x, dev), g, w, nrn, bn=bn,
                                     u0=None if carry is None else _t(carry, dev), want_u=True,
@@ -1798,7 +1805,7 @@ def test_event_layer_fallback_in_a_later_chunk(dev, oracle):
         tag = "hint %d pool %d carry %s" % (hint, pool, carry is not None)
         np.testing.assert_array_equal(_np(s), packbits_lastaxis(exp), err_msg=tag)
         np.testing.assert_array_equal(_np(u), eu, err_msg=tag)
-      assert int(seen.item()) == 200
+      assert int(seen[0].item()) == 200
 
 
 def test_model_captured_into_a_graph_then_called_eagerly(dev, oracle):
@@ -2297,3 +2304,27 @@ def test_eval_command_line_on_a_synthetic_workdir(dev, tmp_path):
     assert out[feed]["steps"] == 3 and out[feed]["samples"] == 12 and out[feed]["world"] == 1
     assert 0.0 <= out[feed]["accuracy"] <= 1.0 and out[feed]["loss"] > 0
   assert out["ev1"] == out["u8"]
+
+
+def test_count_hint_follows_the_chunks_not_the_hot_pixel(dev, oracle):
+  """Binary frames with one hot pixel (count 200): the kernel reports how many staged chunks
+  held which maximum, and the hint the model path derives from it stays at 1 -- the chunks
+  around the hot pixel take the general path, everything else keeps the fast tables -- while
+  every result stays the oracle's.  Count frames move the hint to the bucket that covers them."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.conv_net_case(B=4, hw=32)
+  x = c["x"].copy()
+  x[2, :, 11, 17, 1] = 200                                    # a stuck pixel, every frame of sample 2
+  c = dict(c, x=x)
+  e = cases.conv_net_expected(oracle, c)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  hint = ops.count_hint(dev)
+  for i in range(4):
+    (logits, _) = model.apply(variables, _t(x, dev), trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(logits), e["logits"])
+    torch.cuda.synchronize()
+  assert hint.max_seen == 200 and hint.current() == 1
+  assert ops.CountHint.choose([100, 0, 0, 0, 3]) == 1 and ops.CountHint.choose([0, 0, 90, 10, 0]) == 31
+  assert ops.CountHint.choose([10, 5, 80, 0, 5]) == 7 and ops.CountHint.choose([0, 0, 0, 0, 9]) == 255
