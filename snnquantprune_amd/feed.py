@@ -86,14 +86,24 @@ class DeviceFeeder:
     self._next_slot = (slot + 1) % self._nslots
     bufs = self._slots[slot]
     out = {}
+    leaves = {key: _leaf(val) for key, val in host.items()}
+    # device buffers are allocated on the CONSUMER's stream (the caching allocator ties a block
+    # to the stream current at allocation: freed later, it must not be handed to a new user
+    # while the consumer's kernels still read it); the copy stream only ever writes into them,
+    # ordered against the consumer by the events below
+    fresh = False
+    for key, (src, _) in leaves.items():
+      ent = bufs.get(key)
+      if ent is None or ent[1].shape != src.shape or ent[1].dtype != src.dtype:
+        bufs[key] = [None, torch.empty(src.shape, dtype=src.dtype, device=self.device)]
+        fresh = True
     with torch.cuda.stream(self._stream):
       if self._free[slot] is not None:
         self._stream.wait_event(self._free[slot])
-      for key, val in host.items():
-        src, rebuild = _leaf(val)
-        ent = bufs.get(key)
-        if ent is None or ent[1].shape != src.shape or ent[1].dtype != src.dtype:
-          ent = bufs[key] = [None, torch.empty(src.shape, dtype=src.dtype, device=self.device)]
+      if fresh:                            # memory the consumer's stream may just have released
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+      for key, (src, rebuild) in leaves.items():
+        ent = bufs[key]
         if not src.is_pinned():
           if ent[0] is None:
             ent[0] = torch.empty(src.shape, dtype=src.dtype).pin_memory()
