@@ -76,7 +76,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr bool EV1 = IN == SNNQP_EV1;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int tc = a.tchunk;                       // multiple of 8, <= TCHUNK
+  const int tc = a.tchunk;                       // <= TCHUNK
   const int lut_off = tc * HIMG2;
   uint32_t *obuf = (uint32_t *)(lds + lut_off + u8c2_table_bytes(LUTM, a.lut_bound));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -620,7 +620,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const int64_t bound = (int64_t)w->abs_sum_max * xm;
   const bool lut = w->abs_sum_max > 0 && xm > 0 && xm <= LUT_XMAX && bound <= LUT_CAP;
   a.lut_bound = lut ? (int32_t)bound : 0;
-  a.tchunk = T >= TCHUNK ? TCHUNK : (T + 7) & ~7;
+  a.tchunk = T >= TCHUNK ? TCHUNK : T;
   // images | table | spike-word ring | 4 workgroup words | EV1: byte -> 8-byte table
   const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 + (ev1 ? 2048 : 0) +
                            (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
@@ -663,12 +663,15 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
     // LDS decides how many workgroups share a CU (every variant needs < 128 VGPRs: up to four
     // waves per SIMD): stage fewer timesteps per pass rather than lose a workgroup to LDS --
-    // four per CU measured 7.1 ms on the headline shape, three 7.8, two 11.2
+    // four per CU measured 7.1 ms on the headline shape, three 7.8, two 11.2.  Any chunk length
+    // works (the staging loops test every timestep against it), so the chunk is the largest
+    // that fits: at T = 20 all of it in ONE pass (5.35 ms against 5.57 for 16 + 4: a staging
+    // phase, a flush and three barriers fewer per patch), at T = 50 20 + 20 + 10.
     const size_t lds_rest = lds_fixed - (size_t)a.tchunk * HIMG2 + u8c2_table_bytes(lm, a.lut_bound);
     for (int wgs = 4; wgs >= 2; --wgs) {
-      const size_t per_wg = (size_t)(160 * 1024) / wgs - 1024;
+      const size_t per_wg = (size_t)(160 * 1024) / wgs - 512;
       int tc = a.tchunk;
-      while (tc > 16 && (size_t)tc * HIMG2 + lds_rest > per_wg) tc -= 8;
+      while (tc > 16 && (size_t)tc * HIMG2 + lds_rest > per_wg) tc -= 1;
       if ((size_t)tc * HIMG2 + lds_rest <= per_wg) {
         a.tchunk = tc;
         break;

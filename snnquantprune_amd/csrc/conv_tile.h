@@ -79,7 +79,7 @@ struct ConvMfmaArgs {
   int32_t x_limit;    // u8c2 kernel: largest input value the table mode is sized for
   int32_t *x_seen;    // u8c2 kernel: (nullable) atomically max-ed with the largest input seen
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
-  int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (multiple of 8, <= 32)
+  int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (<= 32)
   uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk
   int32_t patch_h;    // rows of a patch: 8 (two 4x8 tiles), or 4 (conv3x3_bits.hip, one tile)
 };
