@@ -480,7 +480,9 @@ class CountHint:
       words = [int(v) for v in self._host]
       self.max_seen = words[0]
       if sum(words[1:6]) > 0:
-        self.value = self.choose(words[1:6])
+        # (never above what was seen: the tables are sized by abs_sum_max * hint, and a bucket
+        # bound of 7 where the data stops at 4 can push 8-bit codes past the table's capacity)
+        self.value = max(1, min(self.choose(words[1:6]), self.max_seen))
     return self.value
 
   def seen_word(self):
