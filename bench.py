@@ -627,7 +627,7 @@ def main(argv=None):
     line["fed"] = fed
   if alt is not None:
     line["resident_u8"] = alt
-  line.update(rooflines_of(args, prof, B, T, lb))
+  line.update(rooflines_of(args, prof, B, T, lb, dict(ops.PROFILE_NOTES) if ops is not None else {}))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:
       line["parity_vs_float"] = dict(json.load(f).get("summary") or {},
@@ -638,7 +638,7 @@ def main(argv=None):
   print(json.dumps(line))
 
 
-def rooflines_of(args, prof, B, T, lb):
+def rooflines_of(args, prof, B, T, lb, notes=None):
   """Per-kernel rooflines from the HIP events recorded on the launch stream inside the timed
   region: {roofline (dominant kernel), roofline_dense, rooflines, kernels}."""
   kern = {}
@@ -750,19 +750,23 @@ def rooflines_of(args, prof, B, T, lb):
     roofline.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs / HBM_PEAK_GBS)
   if dom == conv_kernel:
-    # What binds the bits kernel is the SIMD's vector issue port, shared by the MFMAs and the
-    # neuron epilogue.  Per 32-pixel x 32-channel tile-step a wave issues 18
-    # MFMAs (32 cycles of the matrix pipe each: 576) and the epilogue of 1024 neuron updates;
-    # that epilogue alone -- dequantise 3, BatchNorm multiply, sub, fma, compare, select, half
-    # a v_writelane per update, no LDS, no MFMA -- costs 462 SIMD cycles per tile-step at the
-    # kernel's two waves per SIMD (tools/ubench/threshold_forms.hip, profiles/r03_threshold_forms.txt).
+    # Beside the MFMAs the SIMD issues the neuron epilogue.  Per 32-pixel x
+    # 32-channel tile-step a wave issues 18 MFMAs (32 cycles of the matrix pipe each: 576) and the
+    # epilogue of 1024 neuron updates; that epilogue's vector instructions alone -- [dequantise 3,]
+    # BatchNorm multiply, sub, fma, compare, select, half a v_writelane per update, no LDS, no
+    # MFMA -- cost 466 SIMD cycles per tile-step at the kernel's two waves per SIMD with the
+    # arithmetic dequantisation and 318 with the table form, which reads the current from LDS
+    # instead (tools/ubench/threshold_forms.hip, profiles/r03_threshold_forms.txt).
+    forms = sorted({(notes or {}).get(t, {}).get("dequant", "arith") for t in tags})
+    mix_cycles = 318.0 if forms == ["table"] else 466.0
     updates = sum(B * T * hw * hw * 128 * kern[t]["launches"]
                   for t, hw in (("conv3x3[64x64x128->128]", 64), ("conv3x3[32x32x128->128]", 32))
                   if t in kern) / nl
     tiles_per_simd = updates / 1024.0 / 1024.0
-    mix_ms = tiles_per_simd * 462.5 / 2.4e9 * 1e3
+    mix_ms = tiles_per_simd * mix_cycles / 2.4e9 * 1e3
     mfma_ms = tiles_per_simd * 576.0 / 2.4e9 * 1e3
-    vi = {"updates_per_launch": updates, "measured_mix_cycles_per_tile": 462.5,
+    vi = {"updates_per_launch": updates, "dequant": "/".join(forms),
+          "measured_mix_cycles_per_tile": mix_cycles,
           "mfma_cycles_per_tile": 576.0, "measured_mix_ms": mix_ms, "mfma_only_ms": mfma_ms,
           "measured_mix_frac": mix_ms / avg_ms,
           "note": "epilogue vector instructions alone / launch time; they share the issue port "

@@ -162,9 +162,9 @@ typedef struct {
 /* ABI version of this header: bumped whenever a struct or a signature below changes
  * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
  * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
- * snnqp_fallback_counts).  A binding compares snnqp_version() with the SNNQP_VERSION it was
+ * snnqp_fallback_counts; 301: snnqp_conv_dequant_form).  A binding compares snnqp_version() with the SNNQP_VERSION it was
  * written against and refuses a library of another version (_lib.py does). */
-#define SNNQP_VERSION 300
+#define SNNQP_VERSION 301
 int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build
@@ -292,6 +292,18 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
  * new reason is also printed to stderr.  No reference counterpart (diagnostic). */
 int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *reason,
                           int32_t reason_len, int reset);
+
+/* How the bit-input 3x3 MFMA kernels of snnqp_conv_lif_forward turn the integer accumulator
+ * into the current fl(fl(acc / L) * m) for these weights and this neuron (host-side query, no
+ * device work; < 0: error).  SNNQP_DQ_ARITH: three float32 instructions per value;
+ * SNNQP_DQ_ONE: L == 1, one multiply; SNNQP_DQ_TABLE: codes within +-7, multi-step LIF / PLIF
+ * with v_reset = 0 and abs_sum_max <= 2047 -- the accumulator's bit pattern is the address of
+ * the current in an LDS table, no vector instruction (csrc/conv3x3_bits.hip).  All three give
+ * the same bits.  No reference counterpart (diagnostic). */
+#define SNNQP_DQ_ARITH 1
+#define SNNQP_DQ_ONE 2
+#define SNNQP_DQ_TABLE 3
+int snnqp_conv_dequant_form(const snnqp_weight_t *w, const snnqp_neuron_t *nrn);
 
 /* Smallest non-zero |BatchNorm_c(fl(fl(acc / L) * m))| over |acc| <= bound and the Cout
  * channels (bn nullable: identity), as float32 bits, atomically min-ed into *out_bits

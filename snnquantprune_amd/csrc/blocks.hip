@@ -50,6 +50,12 @@ int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *rea
   return SNNQP_OK;
 }
 
+int snnqp_conv_dequant_form(const snnqp_weight_t *w, const snnqp_neuron_t *nrn) {
+  SNNQP_REQUIRE(w && nrn, SNNQP_EINVAL, "conv_dequant_form: null descriptor");
+  SNNQP_REQUIRE(w->wtype == SNNQP_W_I8, SNNQP_EINVAL, "conv_dequant_form: int8 codes only");
+  return conv3x3_bits_dequant_form(w, nrn);
+}
+
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
                            const snnqp_conv_geom_t *g, const snnqp_weight_t *w,

@@ -49,6 +49,8 @@ constexpr int F6_NBUF = 3;                   // halo images in the ring
 // byte -> 8 fp4 nibbles, 32 interleaved copies: entry e of copy c at dword 32 e + c, so lane
 // l of a 32-lane group reads bank l whatever its byte is (ds_read_b32 banks: (a / 4) % 32)
 constexpr int F6_TAB = 256 * 32 * 4;
+// (DQT_MAXA = 2047, conv_tile.h: the |acc| bound DQ_TABLE's table is sized for)
+constexpr int DQT_BYTES = 16384 + 16;        // 4095 entries, then the chain constant x 4
 
 // 4 int8 codes (|c| <= 7) -> 4 e2m3 codes, one per byte
 __device__ __forceinline__ uint32_t fp6_codes4(uint32_t x) {
@@ -87,9 +89,19 @@ __device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d
 // DQ (conv_tile.h): how the accumulator becomes the current fl(fl(acc / L) * m)
 //   DQ_ARITH: three float32 instructions (the exact two-instruction division of common.h)
 //   DQ_ONE  : L == 1 (2-bit DuQ codes, the step quantisers): one multiply
-// (an LDS table indexed by the accumulator, the round-1 form, costs the same time: one v_cvt
-// and one ds_read_b32 per value against three VALU instructions, but its reads are gathers
-// -- 36 % of the kernel's LDS cycles were bank conflicts, 59 % of those from the table)
+//   DQ_TABLE: (FMT_FP6, |acc| <= DQT_MAXA) no vector instruction at all.  The block scales of
+//             the matrix instruction are chosen so that one code unit is 2^-147 = four steps of
+//             the float32 DENORMAL range, and the chain starts from the constant whose bit
+//             pattern is (LDS address of the table's middle entry): the accumulator's bit pattern
+//             IS the byte address of fl(fl(acc / L) * m) in a table the workgroup built with the
+//             DQ_ARITH instructions -- one ds_read_b32 per value, addressed by the accumulator
+//             register itself.  The matrix pipe adds denormals exactly
+//             (tools/ubench/mfma_denorm.hip: bit patterns equal to the integer sums over the
+//             whole range, at the speed of the normal range); partial sums never leave
+//             [-A, A], so the pattern never goes negative.  The constants of the next chain are
+//             re-read into the consumed accumulator registers, four at a time (ds_read_b128).
+//   (round 1's table form -- v_cvt + shift + ds_read_b32 on an int32 accumulator -- saved one
+//   instruction per value; this one saves three of the epilogue's 8.6)
 // BNF: every BatchNorm mean and bias of the launch is zero (snnqp_bn_t.flags): x = y * mul
 enum { FMT_FP6 = 0, FMT_I8 = 1 };
 
@@ -101,8 +113,10 @@ template <int FMT, int CIN, int NF, bool POOL, int DQ, bool FMA = false, bool BN
 __global__ void __launch_bounds__(F6_NT, 2)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
-  static_assert(DQ == DQ_ARITH || DQ == DQ_ONE, "dequantisation mode");
+  static_assert(DQ == DQ_ARITH || DQ == DQ_ONE || DQ == DQ_TABLE, "dequantisation mode");
   constexpr bool I8 = FMT == FMT_I8;
+  constexpr bool TABLE = DQ == DQ_TABLE;
+  static_assert(!(TABLE && I8), "the table is addressed by a float32 accumulator");
   typedef typename std::conditional<I8, v16i, v16f>::type acc_t;
   constexpr int KCH = I8 ? 32 : 64;              // input channels of one k-step
   constexpr int BR = I8 ? 4 : 6;                 // registers of one B fragment
@@ -115,7 +129,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   constexpr int NPIX = OutStage<POOL>::NPIX / 2;
   constexpr int TAB_OFF = F6_NBUF * HALO_B;
   constexpr int OB_OFF = TAB_OFF + (I8 ? 0 : F6_TAB);
-  __shared__ __attribute__((aligned(128))) uint8_t lds[OB_OFF + SLOTS * NPIX * 16 + 16];
+  constexpr int DQT_OFF = OB_OFF + SLOTS * NPIX * 16 + 16;
+  __shared__ __attribute__((aligned(128))) uint8_t lds[DQT_OFF + (TABLE ? DQT_BYTES : 0)];
   uint32_t *nxt = (uint32_t *)(lds + OB_OFF + SLOTS * NPIX * 16);   // claimed patch (PatchWalk)
   uint32_t *obuf = (uint32_t *)(lds + OB_OFF);
   const uint32_t lds0 = lds_addr(lds) & 0x3FFFFu;   // < 2^18: offsets fold into immediates
@@ -162,12 +177,30 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     }
   }
 
+  // DQ_TABLE: entry i of the table is the current of acc = i - A (A = a.lut_bound), computed
+  // with the instructions DQ_ARITH would run on the accumulator; the chain constant is the
+  // address of entry A as a bit pattern
+  const uint32_t dqt_mid = lds0 + (uint32_t)DQT_OFF + 4u * (uint32_t)(TABLE ? a.lut_bound : 0);
+  const float chain0 = TABLE ? __uint_as_float(dqt_mid) : 0.0f;
+  uint32_t chain_addr = lds0 + (uint32_t)DQT_OFF + 16384u;
+  if (TABLE) {
+    for (int i = tid; i <= 2 * a.lut_bound; i += F6_NT) {
+      const float af = (float)(i - a.lut_bound);
+      const float q = __builtin_fmaf(af, a.dq.rL, af * a.dq.rLlo);   // exact af / L (common.h)
+      ((float *)(lds + DQT_OFF))[i] = q * a.dq.m;
+    }
+    if (tid < 4) ((uint32_t *)(lds + DQT_OFF + 16384))[tid] = dqt_mid;
+    asm volatile("" : "+v"(chain_addr));       // one register, not a constant per use
+  }
+
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
   if (a.bn.mean) { lc.bmean = a.bn.mean[cpar]; lc.bmul = a.bn.mul[cpar]; lc.bbias = a.bn.bias[cpar]; }
   if (a.nrn.kind == SNNQP_NEURON_LIF) lc.dec = a.nrn.decay[cpar];
 
-  constexpr int SCALE_A = 127;                   // E8M0: 2^(s - 127); the chain starts from
-                                                 // the inline constant 0: no accumulator preload
+  // E8M0 block scales 2^(s - 127).  DQ_TABLE: 2^-63 * 2^-84 = 2^-147 per (spike x code unit);
+  // both are inline constants.  Otherwise 1: the chain starts from the inline constant 0.
+  constexpr int SCALE_A = TABLE ? 64 : 127;
+  constexpr int SCALE_B = TABLE ? 43 : 127;
 
   const int ty = ((n >> 2) & 1) | ((n >> 4) << 1);
   const int tx = (n & 3) | (((n >> 3) & 1) << 2);
@@ -264,11 +297,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
             v8i{av.x, av.y, av.z, av.w, 0, 0, 0, 0},
             v8i{bf[ks][0], bf[ks][1], bf[ks][2], bf[ks][3], bf[ks][4], bf[ks][5], 0, 0}, c,
-            4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, 127);
+            4 /* A: fp4 */, 2 /* B: fp6 */, 0, SCALE_A, 0, SCALE_B);
       }
     };
     const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto dequant1 = [&](auto a0) -> float {
+      if constexpr (TABLE) return *(lds_cfloat_t *)(uintptr_t)__float_as_uint((float)a0);
       const float af = (float)a0;                // exact integer
       if (DQ == DQ_ONE) return af * a.dq.m;      // L == 1
       const float q = __builtin_fmaf(af, a.dq.rL, af * a.dq.rLlo);   // exact af / L (common.h)
@@ -283,7 +317,19 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     //   stage 3  threshold                 stage 4  reset + spike word
     // Executed strictly in order; the slots of a pipelined step take an even share each.
     constexpr int NST = 5;
-    constexpr int YD = 0;                        // pairs the dequantisation runs ahead
+    constexpr int YD = TABLE ? 1 : 0;            // pairs the dequantisation runs ahead (the
+                                                 // table reads: an LDS round trip)
+    // GP pairs advance through the stages together (stage q of pair 2g, stage q of pair 2g + 1,
+    // stage q + 1 of pair 2g, ...).  Alone, the table-mode epilogue takes 320 SIMD cycles per
+    // tile-step pair after pair and 287 two pairs at a time (two waves per SIMD: a stage right
+    // behind the one it depends on waits for its result; tools/ubench/threshold_forms.hip);
+    // among the MFMAs and the other wave's instructions the kernel measures the same either
+    // way (conv1 5.30 / 5.30 ms, 8-bit codes 8.63 / 8.64, random BatchNorm 5.58 / 5.57), so
+    // pairs go one at a time: four temporaries fewer
+    constexpr int GP = 1;
+    constexpr int EYN = YD + GP;                 // currents in flight (ring over pairs)
+    auto st_j = [](int st) { return (st / (NST * GP)) * GP + (st % (NST * GP)) % GP; };
+    auto st_q = [](int st) { return (st % (NST * GP)) / GP; };
     // (the temporaries live inside a step: masks that crossed the loop's back edge would
     // leave the scalar registers)
     // The spike word: the compare masks are wave-uniform 64-bit lane masks (lane = channel).
@@ -292,7 +338,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // round trips: 0.5 of 4.3 ms measured), so the masks of pair j are combined during pair
     // j + 1 and written into the word during pair j + 2.
     struct ETmp {
-      float ey[YD + 1][2], ex[2], euu[2];
+      float ey[EYN][2], ex[GP][2], euu[GP][2];
       unsigned long long m0[8], m1[8];
       uint32_t pw[8];                            // pooled word of a pair (scalar)
       uint32_t ew;
@@ -315,31 +361,44 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         e.ew = writelane_u32((uint32_t)(e.m1[j] >> 32), r0 + 5, e.ew);
       }
     };
-    auto estage = [&](const acc_t &accC, int st, ETmp &e) {
-      const int j = st / NST, q = st % NST;
+    // DQ_TABLE: registers 4 g .. 4 g + 3 of a consumed accumulator take the constants the next
+    // chain starts from (the table reads that used them as addresses are issued: an LDS
+    // instruction reads its address register at issue)
+    auto chain_reload = [&](acc_t &accC, int g) {
+      if constexpr (TABLE) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const v4f lds_cv4f_t;
+        const v4f c = *(lds_cv4f_t *)(uintptr_t)chain_addr;
+        accC[4 * g] = c.x; accC[4 * g + 1] = c.y; accC[4 * g + 2] = c.z; accC[4 * g + 3] = c.w;
+      }
+    };
+    auto estage = [&](acc_t &accC, int st, ETmp &e) {
+      const int j = st_j(st), q = st_q(st), jg = j % GP;
       if (q == 0) {
         if (j + YD < 8) {
-          e.ey[(j + YD) % (YD + 1)][0] = dequant1(accC[2 * (j + YD)]);
-          e.ey[(j + YD) % (YD + 1)][1] = dequant1(accC[2 * (j + YD) + 1]);
+          e.ey[(j + YD) % EYN][0] = dequant1(accC[2 * (j + YD)]);
+          e.ey[(j + YD) % EYN][1] = dequant1(accC[2 * (j + YD) + 1]);
+          if ((j + YD) & 1) chain_reload(accC, (j + YD) >> 1);
         }
       } else if (q == 1) {
         if (BNF) {                   // mean == 0: fl(y - 0) = y
-          e.ex[0] = e.ey[j % (YD + 1)][0] * lc.bmul;
-          e.ex[1] = e.ey[j % (YD + 1)][1] * lc.bmul;
+          e.ex[jg][0] = e.ey[j % EYN][0] * lc.bmul;
+          e.ex[jg][1] = e.ey[j % EYN][1] * lc.bmul;
         } else {
-          e.ex[0] = (e.ey[j % (YD + 1)][0] - lc.bmean) * lc.bmul;
-          e.ex[1] = (e.ey[j % (YD + 1)][1] - lc.bmean) * lc.bmul;
+          e.ex[jg][0] = (e.ey[j % EYN][0] - lc.bmean) * lc.bmul;
+          e.ex[jg][1] = (e.ey[j % EYN][1] - lc.bmean) * lc.bmul;
         }
       } else if (q == 2) {                // (bias == 0: fl(x + 0) = x)
-        const v2f xx = BNF ? v2f{e.ex[0], e.ex[1]} : v2f{e.ex[0] + lc.bbias, e.ex[1] + lc.bbias};
+        const v2f xx = BNF ? v2f{e.ex[jg][0], e.ex[jg][1]}
+                           : v2f{e.ex[jg][0] + lc.bbias, e.ex[jg][1] + lc.bbias};
         const v2f uu = neuron_update<NF, FMA, false>(xx, v2f{u[2 * j], u[2 * j + 1]}, lc, a.nrn);
-        e.euu[0] = uu.x; e.euu[1] = uu.y;
+        e.euu[jg][0] = uu.x; e.euu[jg][1] = uu.y;
       } else if (q == 3) {
-        e.m0[j] = __ballot(e.euu[0] >= a.nrn.vth);
-        e.m1[j] = __ballot(e.euu[1] >= a.nrn.vth);
+        e.m0[j] = __ballot(e.euu[jg][0] >= a.nrn.vth);
+        e.m1[j] = __ballot(e.euu[jg][1] >= a.nrn.vth);
       } else {
-        u[2 * j] = neuron_reset<NF>(e.euu[0], e.m0[j], lc);
-        u[2 * j + 1] = neuron_reset<NF>(e.euu[1], e.m1[j], lc);
+        u[2 * j] = neuron_reset<NF>(e.euu[jg][0], e.m0[j], lc);
+        u[2 * j + 1] = neuron_reset<NF>(e.euu[jg][1], e.m1[j], lc);
         if (j >= 1) word_combine(e, j - 1);
         if (j >= 2) word_insert(e, j - 2);
         if (j == 7) {                     // drain
@@ -349,15 +408,17 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         }
       }
     };
-    auto estage_head = [&](const acc_t &accC, ETmp &e) {   // the dequantisations that run ahead
+    auto estage_head = [&](acc_t &accC, ETmp &e) {   // the dequantisations that run ahead
       e.ew = 0;
-      e.ex[0] = e.ex[1] = e.euu[0] = e.euu[1] = 0.f;
 #pragma unroll
-      for (int j = 0; j <= YD; ++j) e.ey[j][0] = e.ey[j][1] = 0.f;
+      for (int g = 0; g < GP; ++g) e.ex[g][0] = e.ex[g][1] = e.euu[g][0] = e.euu[g][1] = 0.f;
+#pragma unroll
+      for (int j = 0; j < EYN; ++j) e.ey[j][0] = e.ey[j][1] = 0.f;
 #pragma unroll
       for (int j = 0; j < YD; ++j) {
         e.ey[j][0] = dequant1(accC[2 * j]);
         e.ey[j][1] = dequant1(accC[2 * j + 1]);
+        if (j & 1) chain_reload(accC, j >> 1);
       }
     };
     constexpr int NSTAGES = 8 * NST;             // 40 stages per timestep
@@ -378,7 +439,18 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     constexpr int BAR_SLOT = F6_BAR_SLOT < KS - PF ? F6_BAR_SLOT : WR_SLOT + 1;
     static_assert(WR_SLOT < BAR_SLOT && BAR_SLOT < KS - PF,
                   "the halo is written before the barrier, the next step's fragments read after it");
-    auto fused_step = [&](acc_t &accN, const acc_t &accC, int s, uint32_t rd_e, uint32_t rd_o,
+    // LDS instructions the epilogue stages of slots WR_SLOT + 1 .. BAR_SLOT issue (DQ_TABLE)
+    constexpr int TAB_OPS = [] {
+      int n = 0;
+      if (TABLE)
+        for (int st = (WR_SLOT + 1) * (8 * NST) / KS; st < (BAR_SLOT + 1) * (8 * NST) / KS; ++st)
+          if ((st % (NST * GP)) / GP == 0) {       // stage 0 of pair j (st_q, st_j)
+            const int j = (st / (NST * GP)) * GP + (st % (NST * GP)) % GP;
+            if (j + YD < 8) n += 2 + ((j + YD) & 1);
+          }
+      return n;
+    }();
+    auto fused_step = [&](acc_t &accN, acc_t &accC, int s, uint32_t rd_e, uint32_t rd_o,
                           uint32_t rn_e, uint32_t rn_o, uint32_t wr_off, int par, bool more) {
       if (s + 2 < a.T) stage_expand(par);
       if (s + 4 < a.T) stage_load(s + 4, par);
@@ -386,8 +458,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       estage_head(accC, e);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks == 0) accN = mfma_acc(0, A[0], zero16);    // C = inline 0: no preload
-        else accN = mfma_acc(ks, A[ks % RING], accN);
+        if (ks == 0) accN = mfma_acc(0, A[0], TABLE ? accN : zero16);   // C = inline 0 (table:
+        else accN = mfma_acc(ks, A[ks % RING], accN);                   // the reloaded constants)
         __builtin_amdgcn_sched_barrier(0);
         // the slot's A read: PF slots ahead, wrapping into the next step's image
         if (ks + PF < KS) A[(ks + PF) % RING] = a_read(rd_e, rd_o, ks + PF);
@@ -407,19 +479,27 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           // retires the write without draining the A fragments in flight across the barrier
           // (lgkmcnt(0), which a release fence emits, cost an LDS round trip per step).  No
           // scalar load is in flight here (they return out of order): the loop has none.
-          asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_SLOT - WR_SLOT) : "memory");
+          // (DQ_TABLE: the table reads and constant reloads of the slots in between count too)
+          asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_SLOT - WR_SLOT + TAB_OPS) : "memory");
           if (s >= FL && s % FL == 0)              // timesteps < s are behind this barrier
             flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, s - FL, FL, b, y0, x0, tid);
         }
         // pin the slot: what it produced is an operand of an (empty) volatile asm, so neither
         // the MFMA nor the stages drift into another slot
-        asm volatile("" : "+v"(accN), "+v"(e.ey[0][0]), "+v"(e.ey[0][1]), "+v"(e.ex[0]), "+v"(e.ex[1]),
-                     "+v"(e.euu[0]), "+v"(e.euu[1]), "+v"(e.ew));
+        // (the table's values are not pinned: that would wait for a read in the slot that issued it)
+        asm volatile("" : "+v"(accN), "+v"(e.ew));
+#pragma unroll
+        for (int g = 0; g < GP; ++g)
+          asm volatile("" : "+v"(e.ex[g][0]), "+v"(e.ex[g][1]), "+v"(e.euu[g][0]), "+v"(e.euu[g][1]));
+        if constexpr (!TABLE) {
+#pragma unroll
+          for (int g = 0; g < EYN; ++g) asm volatile("" : "+v"(e.ey[g][0]), "+v"(e.ey[g][1]));
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       store_word(s, e.ew);
     };
-    auto epilogue = [&](const acc_t &acc, int t) {
+    auto epilogue = [&](acc_t &acc, int t) {
       ETmp e;
       estage_head(acc, e);
 #pragma unroll
@@ -433,6 +513,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
     // pipeline prologue: halo(0), halo(1) staged; MFMA(0) alone
     acc_t accA, accB;
+    if constexpr (TABLE) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accA[i] = accB[i] = chain0;
+    }
     stage_load(0, 0);
     if (a.T > 1) stage_load(1, 1);
     stage_expand(0);
@@ -452,7 +536,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       for (int i = 0; i < PF; ++i) A[i] = a_read(e0, o0, i);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks == 0) accA = mfma_acc(0, A[0], zero16);
+        if (ks == 0) accA = mfma_acc(0, A[0], TABLE ? accA : zero16);
         else accA = mfma_acc(ks, A[ks % RING], accA);
         if (ks + PF < KS) A[(ks + PF) % RING] = a_read(e0, o0, ks + PF);
         else if (a.T > 1) A[(ks + PF) % RING] = a_read(e1, o1, ks + PF - KS);
@@ -513,6 +597,12 @@ static void launch_bits_nf(const ConvMfmaArgs &a, int nf, bool pool, int dq, boo
   if (nf == NF_DIV) return launch_bits_pool<FMT, CIN, NF_DIV, DQ_ARITH, false, false>(a, pool, gy, st);
   if (nf == NF_DECAY) return launch_bits_pool<FMT, CIN, NF_DECAY, DQ_ARITH, false, false>(a, pool, gy, st);
   if constexpr (FMT == FMT_FP6) {
+    if (dq == DQ_TABLE) {
+      if (fma && bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, true, true>(a, pool, gy, st);
+      if (fma) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, true, false>(a, pool, gy, st);
+      if (bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, false, true>(a, pool, gy, st);
+      return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, false, false>(a, pool, gy, st);
+    }
     if (dq == DQ_ONE) {
       if (fma && bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ONE, true, true>(a, pool, gy, st);
       if (fma) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_ONE, true, false>(a, pool, gy, st);

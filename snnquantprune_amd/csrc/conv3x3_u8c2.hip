@@ -577,6 +577,15 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   return nullptr;
 }
 
+// DQ_ONE / DQ_TABLE / DQ_ARITH (conv_tile.h) for a bit-input block on these weights
+int conv3x3_bits_dequant_form(const snnqp_weight_t *w, const snnqp_neuron_t *nrn) {
+  if (w->L == 1.0f) return DQ_ONE;
+  const bool fp6 = w->code_max > 0 && w->code_max <= 7;
+  const bool tab = fp6 && neuron_form(make_neuron(nrn)) == NF_MUL0 && w->abs_sum_max > 0 &&
+                   w->abs_sum_max <= DQT_MAXA;
+  return tab ? DQ_TABLE : DQ_ARITH;
+}
+
 int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      int32_t T, int32_t B, const snnqp_conv_geom_t *g,
                      const snnqp_weight_t *w, const int8_t *wt,
@@ -652,13 +661,17 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     const bool fma = nf == NF_MUL0 && w->min_current_bits != 0 && w->abs_sum_max > 0 &&
                      lif_fma_is_exact(w->min_current_bits, a.nrn.k_log2, T, u0 != nullptr);
     // dequantisation of the bits kernel: one multiply when L == 1 (2-bit DuQ, the step
-    // quantisers), else the three-instruction form; BatchNorm is the multiply alone when the
-    // caller knows every mean and bias is zero
-    const int dq = w->L == 1.0f ? DQ_ONE : DQ_ARITH;
+    // quantisers), else the current is read from an LDS table at the address the accumulator
+    // spells (fp6 instruction, |acc| <= abs_sum_max <= DQT_MAXA; conv3x3_bits.hip), else the
+    // three-instruction form; BatchNorm is the multiply alone when the caller knows every mean
+    // and bias is zero
+    const bool i8 = !(w->code_max > 0 && w->code_max <= 7);
+    const int dq = conv3x3_bits_dequant_form(w, nrn);
+    const bool tab = dq == DQ_TABLE;
     const bool bnf = (a.bn.flags & (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO)) ==
                      (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO);
-    a.lut_bound = 0;
-    launch_conv3x3_bits(a, !(w->code_max > 0 && w->code_max <= 7), nf, pl, dq, fma, bnf, gy, st);
+    a.lut_bound = tab ? (int32_t)w->abs_sum_max : 0;
+    launch_conv3x3_bits(a, i8, nf, pl, dq, fma, bnf, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
     // LDS decides how many workgroups share a CU (every variant needs < 128 VGPRs: up to four

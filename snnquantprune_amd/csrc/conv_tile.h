@@ -556,11 +556,13 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
 
 // conv3x3_bits.hip: bit-packed input, Cin <= 128; i8 = codes wider than fp6 holds
 // dq: how the accumulator becomes the current -- DQ_ARITH (three float32 instructions),
-// DQ_ONE (L == 1: one multiply)
+// DQ_ONE (L == 1: one multiply), DQ_TABLE (fp6 instruction, NF_MUL0, 0 < a.lut_bound =
+// abs_sum_max <= DQT_MAXA: an LDS table addressed by the accumulator's bit pattern)
 // fma: the membrane update as one fused multiply-add (NF_MUL0, proven exact for this launch
 // by the caller: snnqp_weight_t.min_current_bits + lif_fma_is_exact)
 // bnf: every BatchNorm mean and bias is zero (snnqp_bn_t.flags): x = y * mul
-enum { DQ_ARITH = 1, DQ_ONE = 2 };
+enum { DQ_ARITH = 1, DQ_ONE = 2, DQ_TABLE = 3 };
+constexpr int DQT_MAXA = 2047;
 void launch_conv3x3_bits(const ConvMfmaArgs &a, bool i8, int nf, bool pool, int dq, bool fma,
                          bool bnf, unsigned gy, hipStream_t st);
 

@@ -16,6 +16,7 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                      const snnqp_neuron_t *nrn, int s_type);
 int run_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound, int32_t Cout,
                     uint32_t *out_bits, hipStream_t st);
+int conv3x3_bits_dequant_form(const snnqp_weight_t *w, const snnqp_neuron_t *nrn);
 int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      int32_t T, int32_t B, const snnqp_conv_geom_t *g,
                      const snnqp_weight_t *w, const int8_t *wt,

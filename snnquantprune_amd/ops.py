@@ -596,11 +596,13 @@ def conv_forward(x, geom: ConvGeom, weight: Weight, want_acc: bool = False):
 # ---------------------------------------------------------------------------
 
 _PROFILE = None
+PROFILE_NOTES = {}      # tag -> facts about the launches of the last profiled region
 
 
 def profile_start():
   global _PROFILE
   _PROFILE = {}
+  PROFILE_NOTES.clear()
 
 
 def profile_stop():
@@ -703,8 +705,10 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
     s = torch.empty(oshape + (geom.Cout,), dtype=torch.float32, device=dev)
   g, w, n = geom.struct(), weight.struct(), neuron.struct()
   b = bn.struct() if bn is not None else None
-  with _timed("conv%dx%d[%dx%dx%d->%d]" % (geom.KH, geom.KW, geom.H, geom.W, geom.Cin,
-                                          geom.Cout)):
+  tag = "conv%dx%d[%dx%dx%d->%d]" % (geom.KH, geom.KW, geom.H, geom.W, geom.Cin, geom.Cout)
+  if _PROFILE is not None and in_type == L.BITS and weight.is_int and tag not in PROFILE_NOTES:
+    PROFILE_NOTES[tag] = {"dequant": conv_dequant_form(weight, neuron)}
+  with _timed(tag):
     L.check(L.lib().snnqp_conv_lif_forward(
         _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
         _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
@@ -751,6 +755,20 @@ def fallback_counts(reset: bool = False) -> dict:
                                         1 if reset else 0))
   return {"conv_blocks": conv.value, "dense_blocks": dense.value,
           "last_reason": buf.value.decode("utf-8", "replace")}
+
+
+DQ_FORMS = {1: "arith", 2: "one", 3: "table"}
+
+
+def conv_dequant_form(w: Weight, nrn: Neuron) -> str:
+  """How the bit-input 3x3 MFMA kernels dequantise with these weights and this neuron
+  (snnqp_conv_dequant_form): "arith" (three instructions per value), "one" (L == 1: a
+  multiply) or "table" (the accumulator's bit pattern addresses an LDS table)."""
+  ws, ns = w.struct(), nrn.struct()
+  rc = L.lib().snnqp_conv_dequant_form(ctypes.byref(ws), ctypes.byref(ns))
+  if rc < 0:
+    L.check(rc)
+  return DQ_FORMS[rc]
 
 
 # ---------------------------------------------------------------------------

@@ -669,3 +669,28 @@ def test_feeder_on_cpu_is_the_plain_iterator():
   assert len(got) == 5 and f.batches == 5
   for i, b in enumerate(got):
     assert int(np.asarray(b["dvs_matrix"]).max()) == i
+
+
+def test_conv_dequant_form_query():
+  """snnqp_conv_dequant_form (host-side, no device work): which of the three bit-equal
+  dequantisation forms the bit-input conv kernels run -- the table addressed by the accumulator
+  needs fp6 codes, |acc| <= 2047 and the multi-step LIF / PLIF form with v_reset = 0."""
+  import dataclasses
+  import torch
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  codes = torch.zeros((3, 3, 4, 32), dtype=torch.int8)
+  w = ops.Weight(L.W_I8, codes, 7.0, 0.37, abs_sum_max=700, code_max=7)
+  mslif = ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, 1.0, 0.0)
+  assert ops.conv_dequant_form(w, mslif) == "table"
+  assert ops.conv_dequant_form(dataclasses.replace(w, abs_sum_max=2047), mslif) == "table"
+  assert ops.conv_dequant_form(dataclasses.replace(w, abs_sum_max=2048), mslif) == "arith"
+  assert ops.conv_dequant_form(dataclasses.replace(w, abs_sum_max=0), mslif) == "arith"      # unknown bound
+  assert ops.conv_dequant_form(dataclasses.replace(w, code_max=127, L=127.0), mslif) == "arith"
+  assert ops.conv_dequant_form(dataclasses.replace(w, L=1.0), mslif) == "one"
+  assert ops.conv_dequant_form(w, ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, 1.0, 0.25)) == "arith"
+  lif = ops.Neuron(L.NEURON_LIF, 2.0, 1.0, 0.0, decay=torch.full((32,), 0.5))
+  assert ops.conv_dequant_form(w, lif) == "arith"
+  wf = ops.Weight(L.W_F32, torch.zeros((3, 3, 4, 32)), 1.0, 1.0)
+  with pytest.raises(L.SnnqpError):
+    ops.conv_dequant_form(wf, mslif)

@@ -1747,6 +1747,51 @@ def test_conv_bits_kernel_fused_membrane_update(dev, oracle, bits, tiny):
       np.testing.assert_array_equal(_np(u), e["u"])
 
 
+@pytest.mark.parametrize("cin,table", [(32, True), (64, False), (128, False)])
+def test_conv_bits_kernel_dequantises_through_the_accumulator_addressed_table(dev, oracle, cin, table):
+  """fp6 kernel, |acc| <= abs_sum_max <= 2047: the current is read from an LDS table at the
+  address the accumulator's (denormal) bit pattern spells (conv3x3_bits.hip, DQ_TABLE); larger
+  bounds keep the three-instruction form.  Codes of +7 / -7 over whole output channels and
+  frames of all ones drive the accumulator to both ends of the table (+-288 * 7 at Cin = 32)
+  and through every partial sum on the way; the other channels and frames are random.
+  Rasters, pooled rasters and potentials bit-exact, with the fused and the two-rounding update."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops, synthetic as syn
+  rng = np.random.Generator(np.random.PCG64(7700 + cin))
+  T, B, H, W, cout = 6, 2, 8, 12, 64
+  a = F32(0.5)
+  k = (rng.integers(-7, 8, size=(3, 3, cin, cout)) * (a / F32(7))).astype(F32)
+  k[..., 0] = a; k[..., 1] = -a; k[..., 2] = a; k[:, :, ::2, 2] = -a       # codes +7, -7, alternating
+  mask = (rng.random((3, 3, cin, cout)) < (0.9 if cin == 32 else 0.6)).astype(F32)
+  mask[..., :3] = 1
+  leaf = {"kernel": k, "DuQ_0": {"a": np.array([a], F32), "c": np.array([0.37], F32)},
+          "prune_0": {"mask": mask}}
+  x = (rng.random((T, B, H, W, cin)) < 0.3).astype(np.uint8)
+  x[1] = 1; x[4, 0] = 1; x[5, 1, :, :, ::2] = 1
+  bp, bs = syn.bn_leaf(cout, True, 7701)
+  bn = dict(mean=bs["mean"], var=bs["var"], scale=bp["scale"], bias=bp["bias"])
+  qw = qweight_of(oracle, leaf, 4)
+  eu, es = oracle.conv_block(x, qw, bn, None, "int")
+  assert 0.02 < es.mean() < 0.9, es.mean()
+  w = _weight(leaf, 4, dev, transposed=True)
+  assert w.code_max == 7 and (int(w.abs_sum_max) <= 2047) == table, w.abs_sum_max
+  assert ops.conv_dequant_form(w, _mslif()) == ("table" if table else "arith")
+  if cin == 32:
+    assert int(w.abs_sum_max) == 288 * 7
+  bnc = _bn(bn, dev)
+  geom = ops.ConvGeom(H, W, cin, cout, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(x, dev))
+  mb = ops.current_min_bits(w, bnc, int(w.abs_sum_max), cout)
+  for ww in (w, dataclasses.replace(w, min_current_bits=mb)):
+    u, s = ops.conv_lif_forward(xin, geom, ww, _mslif(), bn=bnc, packed_out=True, impl=L.IMPL_MFMA)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(u), eu)
+    _, sp = ops.conv_lif_forward(xin, geom, ww, _mslif(), bn=bnc, packed_out=True, pool=2,
+                                 impl=L.IMPL_MFMA, want_u=False)
+    np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
+
+
 def test_conv_work_queues_on_concurrent_streams(dev, oracle):
   """The patch work queues come from a per-device pool of slots: launches that overlap on
   different streams (and more than 64 launches in a row, so slots are reused) still give

@@ -41,6 +41,14 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
         asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d1) : "v"(y1), "v"(u[i].y));
         asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(d0), "v"(kk), "v"(u[i].x));
         asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(d1), "v"(kk), "v"(u[i].y));
+      } else if (UPD == 4) {         // conv1/2 with the table dequantisation: BatchNorm multiply, sub, fma
+        float y0, y1, d0, d1;
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y0) : "v"(th), "v"(x[i].x));
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y1) : "v"(th), "v"(x[i].y));
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(y0), "v"(u[i].x));
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d1) : "v"(y1), "v"(u[i].y));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(d0), "v"(kk), "v"(u[i].x));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(d1), "v"(kk), "v"(u[i].y));
       } else if (UPD == 1) {
         float d0, d1;
         asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(x[i].x), "v"(u[i].x));
@@ -86,6 +94,55 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The table-mode epilogue (BatchNorm multiply, sub, fma, compare, select, spike word) with G
+// pairs advanced together stage by stage: 2 G independent instructions between dependent ones.
+template <int G>
+__global__ void __launch_bounds__(256) kg(float *out, int iters, float kk, float th) {
+  float u[16], x[16];
+  for (int i = 0; i < 16; ++i) { u[i] = 0.1f * threadIdx.x + 0.2f * i; x[i] = 0.3f + i; }
+  unsigned word = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int b = 0; b < 16; b += 2 * G) {
+      float y[2 * G], d[2 * G], t[2 * G];
+      unsigned long long m[2 * G];
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y[i]) : "v"(th), "v"(x[b + i]));
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d[i]) : "v"(y[i]), "v"(u[b + i]));
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t[i]) : "v"(d[i]), "v"(kk), "v"(u[b + i]));
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m[i]) : "v"(th), "v"(t[i]));
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(u[b + i]) : "v"(t[i]), "s"(m[i]));
+#pragma unroll
+      for (int i = 0; i < 2 * G; i += 2) {
+        const unsigned long long mm = m[i] | m[i + 1];
+        const unsigned w = (unsigned)mm | (unsigned)(mm >> 32);
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(w), "n"(0));
+      }
+    }
+  }
+  float s = (float)word;
+  for (int i = 0; i < 16; ++i) s += u[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int G>
+void run_g(float *out, int waves_per_simd) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 20000; float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kg<G>), dim3(256 * waves_per_simd), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double tiles = (double)iters * waves_per_simd;
+  printf("table-mode epilogue, %d pairs advanced together          %d waves/SIMD: %.1f SIMD cycles per tile of 16 registers\n",
+         G, waves_per_simd, ms * 1e6 / tiles * 2.4);
+}
+
 template <int UPD, int THR>
 void run(const char *name, float *out, int waves_per_simd = 4) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -119,5 +176,9 @@ int main() {
   run<3, 0>("conv1/2 epilogue: dq + bn + update + thr", out, 2);
   run<3, 0>("conv1/2 epilogue: dq + bn + update + thr", out, 4);
   run<3, 4>("conv1/2 epilogue without threshold/reset", out, 2);
+  run<4, 0>("conv1/2 epilogue, table dequantisation: bn + update + thr", out, 2);
+  run<4, 0>("conv1/2 epilogue, table dequantisation: bn + update + thr", out, 4);
+  run_g<1>(out, 2); run_g<2>(out, 2); run_g<4>(out, 2); run_g<8>(out, 2);
+  run_g<1>(out, 4); run_g<2>(out, 4);
   return 0;
 }

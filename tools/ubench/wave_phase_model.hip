@@ -40,12 +40,47 @@ __device__ __forceinline__ void pair(float &u0, float &u1, float a0, float a1, f
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(w), "n"(0));
 }
 
+// The pair with the dequantisation read from an LDS table instead (round 3's question: the
+// accumulator's bit pattern as the table address): the six dequantisation instructions become
+// two ds_read_b32 issued a pair ahead, plus AV address instructions per value (1: v_and of a
+// magic-constant accumulator; 0: the accumulator is the address).
+template <int AV>
+__device__ __forceinline__ void pair_tab_issue(float &y0, float &y1, float a0, float a1, uint32_t tab) {
+  uint32_t i0 = __float_as_uint(a0), i1 = __float_as_uint(a1);
+  if (AV) {
+    asm volatile("v_and_b32 %0, %1, %2" : "=v"(i0) : "s"(0x7FCu), "v"(i0));
+    asm volatile("v_and_b32 %0, %1, %2" : "=v"(i1) : "s"(0x7FCu), "v"(i1));
+  }
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y0) : "v"(i0), "n"(32768));
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y1) : "v"(i1), "n"(32768));
+  (void)tab;
+}
+__device__ __forceinline__ void pair_tab_use(float &u0, float &u1, float y0, float y1, float k, float th,
+                                             unsigned &word) {
+  float d0, d1, t0, t1;
+  unsigned long long m0, m1;
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y0) : "v"(th), "v"(y0));
+  asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(y1) : "v"(th), "v"(y1));
+  asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(y0), "v"(u0));
+  asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(d1) : "v"(y1), "v"(u1));
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(d0), "v"(k), "v"(u0));
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(d1), "v"(k), "v"(u1));
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m0) : "v"(th), "v"(t0));
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m1) : "v"(th), "v"(t1));
+  asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(u0) : "v"(t0), "s"(m0));
+  asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(u1) : "v"(t1), "s"(m1));
+  const unsigned long long m = m0 | m1;
+  const unsigned w = (unsigned)m | (unsigned)(m >> 32);
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(w), "n"(0));
+}
+
 // PHASED 0: interleaved, 1: phased.  NX: extra plain vector instructions per tile-step.
-template <int PHASED, int NX>
+// TAB 0: arithmetic dequantisation; 1: table, one address instruction per value; 2: table, none
+template <int PHASED, int NX, int TAB = 0>
 __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float th) {
-  __shared__ __attribute__((aligned(16))) int lds[8192];
+  __shared__ __attribute__((aligned(16))) int lds[8192 + 512];
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = 0x22222222;
+  for (int i = threadIdx.x; i < 8192 + 512; i += 256) lds[i] = i < 8192 ? 0x22222222 : 0x3f800000 + i;
   __syncthreads();
   v16f fa = {0}, fb = {0};
   v8i b8 = {0x08208208, lane & 7, 0, 0, 0, 0, 0, 0};
@@ -53,6 +88,10 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
 #pragma unroll
   for (int i = 0; i < 16; ++i) u[i] = 0.01f * lane + i;
   int xs[4] = {lane, lane + 1, lane + 2, lane + 3};
+  float ty[2][2] = {{0, 0}, {0, 0}};
+  float adr[16];            // TAB == 2: addresses that look like the accumulator of a sparse layer
+#pragma unroll
+  for (int i = 0; i < 16; ++i) adr[i] = __uint_as_float((uint32_t)(4 * ((lane * 7 + i * 13) % 97 + 200)));
   unsigned word = 0;
   v4i q[4];
 #pragma unroll
@@ -91,11 +130,25 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
           mfma(fn, s);
           // 8 pairs over 18 slots: pair j in slot 2 j + 1 (a pair is 17 instructions: the
           // kernel spreads them more finely, 8-9 per slot; the totals are the same)
-          if ((s & 1) && s / 2 < 8) pair(u[s - 1], u[s], fc[s - 1], fc[s], kk, th, word);
+          if (TAB == 0) {
+            if ((s & 1) && s / 2 < 8) pair(u[s - 1], u[s], fc[s - 1], fc[s], kk, th, word);
+          } else if ((s & 1) && s / 2 < 8) {
+            // the reads of pair j were issued in slot 2 j - 1 (pair 0: slot 0); LDS results return
+            // in order: all but this slot's A read have arrived
+            if (s == 1) pair_tab_issue<TAB == 1>(ty[0][0], ty[0][1], TAB == 1 ? fc[0] : adr[0], TAB == 1 ? fc[1] : adr[1], 0);
+            const int j = s / 2;
+            if (j + 1 < 8)
+              pair_tab_issue<TAB == 1>(ty[(j + 1) & 1][0], ty[(j + 1) & 1][1], TAB == 1 ? fc[2 * j + 2] : adr[2 * j + 2],
+                                       TAB == 1 ? fc[2 * j + 3] : adr[2 * j + 3], 0);
+            asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(2));   // (j + 1 < 8: the two just issued stay out)
+            __builtin_amdgcn_sched_barrier(0);
+            pair_tab_use(u[s - 1], u[s], ty[j & 1][0], ty[j & 1][1], kk, th, word);
+          }
           extra((NX * (s + 1)) / 18 - (NX * s) / 18);
-          asm volatile("s_waitcnt lgkmcnt(2)");
+          asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(TAB ? 4 : 2));
           __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("" : "+v"(fn));       // (TAB == 2 does not read the accumulators: keep the chain)
       }
     }
   }
@@ -105,19 +158,19 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
   out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
 }
 
-template <int PHASED, int NX>
+template <int PHASED, int NX, int TAB = 0>
 void run(float *out, int wps) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 4000; float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<PHASED, NX>), dim3(256 * wps), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
+    hipLaunchKernelGGL((k<PHASED, NX, TAB>), dim3(256 * wps), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
   }
   const double steps = (double)iters * wps;      // tile-steps per SIMD
   const double cyc = ms * 1e6 / steps * 2.4;
-  printf("%-12s extra %2d  waves/SIMD %d: %7.1f SIMD cycles per tile-step  (matrix pipe %4.1f %% busy)\n",
-         PHASED ? "phased" : "interleaved", NX, wps, cyc, 100.0 * 576.0 / cyc);
+  printf("%-12s %s extra %2d  waves/SIMD %d: %7.1f SIMD cycles per tile-step  (matrix pipe %4.1f %% busy)\n",
+         PHASED ? "phased" : "interleaved", TAB == 0 ? "arith  " : TAB == 1 ? "table+1" : "table+0", NX, wps, cyc, 100.0 * 576.0 / cyc);
 }
 
 int main() {
@@ -129,6 +182,11 @@ int main() {
   for (int w = 2; w <= 4; ++w) {
     run<0, 0>(out, w);
     run<1, 0>(out, w);
+  }
+  for (int w = 2; w <= 3; ++w) {
+    run<0, 48, 0>(out, w);
+    run<0, 48, 1>(out, w);
+    run<0, 48, 2>(out, w);
   }
   return 0;
 }
