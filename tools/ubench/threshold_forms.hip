@@ -77,6 +77,12 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
                      : "=v"(u[i].x), "=s"(m0) : "v"(th), "v"(t.x) : "vcc");
         asm volatile("v_cmp_le_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e64 %0, %3, 0, vcc\n\ts_mov_b64 %1, vcc"
                      : "=v"(u[i].y), "=s"(m1) : "v"(th), "v"(t.y) : "vcc");
+      } else if (THR == 5) {     // v_cmpx into EXEC (and the mask), zero the spiking lanes, EXEC back
+        asm volatile("v_cmpx_le_f32_e64 %1, %2, %0\n\tv_mov_b32_e32 %0, 0\n\ts_mov_b64 exec, -1"
+                     : "+v"(t.x), "=s"(m0) : "v"(th));
+        asm volatile("v_cmpx_le_f32_e64 %1, %2, %0\n\tv_mov_b32_e32 %0, 0\n\ts_mov_b64 exec, -1"
+                     : "+v"(t.y), "=s"(m1) : "v"(th));
+        u[i] = t;
       } else {
         u[i] = t;
       }
@@ -166,6 +172,8 @@ int main() {
   run<2, 1>("threshold+reset e32/VCC + s_mov", out);
   run<2, 2>("threshold+reset e64/VCC + s_mov", out);
   run<2, 3>("threshold e32/VCC, reset e64/VCC + s_mov", out);
+  run<2, 5>("threshold+reset v_cmpx + masked v_mov", out);
+  run<0, 5>("packed update + v_cmpx + masked v_mov", out);
   run<0, 0>("packed update + e64/SGPR (conv0 today)", out);
   run<0, 1>("packed update + e32/VCC", out);
   run<0, 3>("packed update + e32 cmp, e64 select", out);
