@@ -158,6 +158,78 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float kk, float 
   out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
 }
 
+// The same tile-step on v_mfma_scale_f32_16x16x128_f8f6f4: a wave owns 16 channels x 64 pixels
+// (four 16 x 16 tiles, nine dependent MFMAs of 16 cycles each per tile, chains interleaved), half
+// the B fragments (54 VGPRs: a third wave per SIMD fits) and twice the A reads (36 per tile-step).
+template <int NX>
+__global__ void __launch_bounds__(256) k16(float *out, int iters, float kk, float th) {
+  __shared__ __attribute__((aligned(16))) int lds[8192];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = 0x22222222;
+  __syncthreads();
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f fa[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, fb[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  v8i b8 = {0x08208208, lane & 7, 0, 0, 0, 0, 0, 0};
+  float u[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) u[i] = 0.01f * lane + i;
+  int xs[4] = {lane, lane + 1, lane + 2, lane + 3};
+  unsigned word = 0;
+  v4i q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = v4i{0x22222222, 0, 0, 0};
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)lds + lane * 16;
+  for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      v4f *fn = half ? fa : fb;
+      const v4f *fc = half ? fb : fa;
+#pragma unroll
+      for (int s = 0; s < 36; ++s) {
+        const int m = s & 3;
+        v8i av = {q[s % 4].x, q[s % 4].y, q[s % 4].z, q[s % 4].w, 0, 0, 0, 0};
+        if (s < 4) fn[m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, b8, v4f{0, 0, 0, 0}, 4, 2, 0, 127, 0, 127);
+        else fn[m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, b8, fn[m], 4, 2, 0, 127, 0, 127);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[(s + 3) % 4]) : "v"(addr), "n"(1024));
+        // 8 pairs over 36 slots: pair j in slot 4 j + 3
+        if ((s & 3) == 3 && s / 4 < 8) {
+          const int j = s / 4;
+          float a0 = fc[j >> 1][2 * (j & 1)], a1 = fc[j >> 1][2 * (j & 1) + 1];
+          pair(u[2 * j], u[2 * j + 1], a0, a1, kk, th, word);
+        }
+#pragma unroll
+        for (int i = 0; i < (NX * (s + 1)) / 36 - (NX * s) / 36; ++i)
+          asm volatile("v_add_u32 %0, %1, %2" : "=v"(xs[i % 4]) : "v"(xs[i % 4]), "v"(lane));
+        asm volatile("s_waitcnt lgkmcnt(2)");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(fn[m]));
+    }
+  }
+  float sacc = (float)word + xs[0] + xs[1] + xs[2] + xs[3];
+  for (int i = 0; i < 16; ++i) sacc += u[i];
+  for (int m = 0; m < 4; ++m) for (int i = 0; i < 4; ++i) sacc += fa[m][i] + fb[m][i];
+  for (int i = 0; i < 4; ++i) sacc += q[i].x;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
+}
+
+template <int NX>
+void run16(float *out, int wps) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 4000; float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k16<NX>), dim3(256 * wps), dim3(256), 0, 0, out, iters, 0.5f, 1.0f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double steps = (double)iters * wps;
+  const double cyc = ms * 1e6 / steps * 2.4;
+  printf("16x16x128    arith   extra %2d  waves/SIMD %d: %7.1f SIMD cycles per tile-step  (matrix pipe %4.1f %% busy)\n",
+         NX, wps, cyc, 100.0 * 576.0 / cyc);
+}
+
 template <int PHASED, int NX, int TAB = 0>
 void run(float *out, int wps) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -183,6 +255,7 @@ int main() {
     run<0, 0>(out, w);
     run<1, 0>(out, w);
   }
+  for (int w = 2; w <= 4; ++w) run16<48>(out, w);
   for (int w = 2; w <= 3; ++w) {
     run<0, 48, 0>(out, w);
     run<0, 48, 1>(out, w);
