@@ -554,6 +554,27 @@ def main(argv=None):
     alt = {"format": "u8 (uint8 frames, 655 360 B per sample)", "steps": args.steps,
            "ms_per_step": float(tb.item()) / args.steps * 1e3,
            "samples_per_s": world * B * args.steps / float(tb.item())}
+  # the same steps as ONE graph launch each (the product's nn.capture; the reference's step is
+  # jit-compiled, examples/eval.py:108-116): the conv kernels keep their work queues inside a
+  # capture, and the launches lose the per-launch memset / event / Python between them
+  cap_leg = None
+  if (gpu and ops is not None and not args.stand_in and not args.graph and args.feed == "resident"
+      and not args.no_fed_leg):
+    captured = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
+    for _ in range(2):
+      parallel.all_gather_rows(captured()[0])
+    fence()
+    tc0 = time.perf_counter()
+    for _ in range(args.steps):
+      parallel.all_gather_rows(captured()[0])
+    fence()
+    tcv = torch.tensor([time.perf_counter() - tc0], device=dev, dtype=torch.float64)
+    if collective:
+      torch.distributed.all_reduce(tcv, op=torch.distributed.ReduceOp.MAX)
+    cap_leg = {"api": "nn.capture: model.apply recorded into a hipGraph, one graph launch per step",
+               "steps": args.steps, "ms_per_step": float(tcv.item()) / args.steps * 1e3,
+               "samples_per_s": world * B * args.steps / float(tcv.item())}
+    del captured
   # the host-fed leg (every rank runs it: the step holds a collective); binary frames only
   fed = None
   if (gpu and ops is not None and frames_u8 is not None and args.feed == "resident"
@@ -627,6 +648,8 @@ def main(argv=None):
     line["fed"] = fed
   if alt is not None:
     line["resident_u8"] = alt
+  if cap_leg is not None:
+    line["captured"] = cap_leg
   line.update(rooflines_of(args, prof, B, T, lb, dict(ops.PROFILE_NOTES) if ops is not None else {}))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:

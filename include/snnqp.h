@@ -11,11 +11,13 @@
  * Conventions
  *  - every pointer named x/w/y/u/s/... is a DEVICE pointer owned by the caller
  *    (torch); the library allocates nothing that outlives a call, with one exception:
- *    the fused conv kernels keep 32 KiB of work-queue counters per device (the device of
- *    `stream`), in 64 round-robin slots.  A slot is zeroed on `stream` right before its
- *    launch and guarded by an event: a launch that finds its slot still in flight (more
- *    than 64 conv launches outstanding on the device), or whose stream is being captured
- *    into a graph, walks its patches statically instead -- same results, no queue;
+ *    the fused conv kernels keep 512 KiB of work-queue counters per device (the device of
+ *    `stream`): 64 round-robin slots for eager launches -- a slot is zeroed on `stream`
+ *    right before its launch and guarded by an event; a launch that finds its slot still in
+ *    flight (more than 64 conv launches outstanding on the device) walks its patches
+ *    statically instead: same results, no queue -- and 960 slots that launches captured into
+ *    a graph take one each, for good (the pool must exist before the capture: one eager
+ *    launch on the device);
  *  - descriptor structs (snnqp_*_t) are HOST structs read during the call;
  *  - all work is enqueued on `stream` (a hipStream_t); no call synchronises;
  *  - return value: 0 on success, <0 on error (SNNQP_E*); the message is

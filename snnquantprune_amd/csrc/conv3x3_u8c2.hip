@@ -417,6 +417,7 @@ struct SchedPool {
   bool has_event[SCHED_SLOTS] = {};
   bool retired[SCHED_SLOTS] = {};      // no event could be made: never handed out again
   unsigned next = 0;
+  unsigned next_capture = 0;           // slots SCHED_SLOTS + i: one per captured launch
 };
 std::mutex g_sched_mu;
 SchedPool g_sched[64];
@@ -442,19 +443,37 @@ struct DeviceGuard {
 uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
   int dev = 0;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
   hipDevice_t sdev;
   if (hipStreamGetDevice(st, &sdev) == hipSuccess) dev = (int)sdev;
   else if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   if (dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lock(g_sched_mu);
   SchedPool &p = g_sched[dev];
+  if (capturing) {
+    // a slot of its own, zero since the pool was allocated and zero again after every launch
+    // that walked it (conv_tile.h)
+    if (!p.words || p.next_capture >= (unsigned)SCHED_CAPTURE_SLOTS) return nullptr;
+    const int slot = SCHED_SLOTS + (int)p.next_capture++;
+    *dev_out = dev;
+    *slot_out = slot;
+    return p.words + (size_t)slot * SCHED_WORDS;
+  }
   if (!p.words) {
     DeviceGuard on(dev);
     if (!on.ok) return nullptr;
     uint32_t *w = nullptr;
-    if (hipMalloc((void **)&w, (size_t)SCHED_SLOTS * SCHED_WORDS * sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc((void **)&w, (size_t)(SCHED_SLOTS + SCHED_CAPTURE_SLOTS) * SCHED_WORDS *
+                                   sizeof(uint32_t)) != hipSuccess) {
       (void)hipGetLastError();
+      return nullptr;
+    }
+    // (synchronous, once per device: the capture slots rely on it)
+    if (hipMemset(w, 0, (size_t)(SCHED_SLOTS + SCHED_CAPTURE_SLOTS) * SCHED_WORDS * sizeof(uint32_t)) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(w);
       return nullptr;
     }
     p.words = w;
@@ -486,6 +505,7 @@ uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
 }
 
 void sched_release(int dev, int slot, hipStream_t st) {
+  if (slot >= SCHED_SLOTS) return;      // a captured launch's slot: never reused, nothing to track
   std::lock_guard<std::mutex> lock(g_sched_mu);
   SchedPool &p = g_sched[dev];
   // (the event was created in sched_acquire).  A failed record leaves the event at its

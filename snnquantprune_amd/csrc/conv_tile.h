@@ -89,6 +89,7 @@ struct ConvMfmaArgs {
 constexpr int SCHED_Y = 8;                  // blockIdx.y values a slot serves (Cout <= 1024)
 constexpr int SCHED_WORDS = SCHED_Y * 16;   // words of one slot
 constexpr int SCHED_SLOTS = 64;             // launches in flight per device
+constexpr int SCHED_CAPTURE_SLOTS = 960;    // launches captured into graphs per device (never reused)
 
 // 16 spike bits -> 16 bytes {0, 1} (or {0, 4} when the accumulator indexes a table)
 template <bool X4>
@@ -136,8 +137,11 @@ struct PatchWalk {
   // their patches sooner and would otherwise idle while the youngest still has a quarter
   // of its static share left: 4.75 against 7.44 ms measured inside conv0).  One thread
   // claims, a patch ahead so that the atomic's round trip hides behind the patch.
+  // (never beyond `count`, whatever the counter holds: a word that was not zero at the start
+  // of the launch costs patches, it must not cost an out-of-range patch index)
   __device__ __forceinline__ int64_t claim() const {
-    return stride + (int64_t)atomicAdd(queue, 1u);
+    const int64_t r = stride + (int64_t)atomicAdd(queue, 1u);
+    return r < count ? r : count;
   }
   // after the last claim of the workgroup (one thread): count it; the last of the launch
   // zeroes the slot
@@ -522,9 +526,18 @@ __device__ __forceinline__ v16i splat16(int v) {
 //    possibly aborted, launch left in it cannot be walked), and
 //  * an event recorded after the launch marks it busy: when the round-robin pointer comes
 //    back to a slot whose last launch has not completed (more than SCHED_SLOTS launches in
-//    flight across streams / threads), or the stream is being captured into a graph (events
-//    cannot be queried there), the launch takes the static walk instead (sched = nullptr),
-//    which is always correct, only less well balanced.
+//    flight across streams / threads), the launch takes the static walk instead (sched =
+//    nullptr), which is always correct, only less well balanced (C3 under a graph without
+//    queues: 13.6 ms against 12.3).
+// A launch that is being CAPTURED into a graph (events cannot be queried there) gets a slot of
+// its own out of SCHED_CAPTURE_SLOTS further ones, never handed out again.  Nothing is added to
+// the graph for it: the pool is zeroed when it is allocated, the last workgroup of every launch
+// leaves the slot's words zero again (PatchWalk::finish), and a graph does not run concurrently
+// with itself -- every replay finds zeroed words.  (A memset node in front of the kernel node,
+// the obvious way, faulted on the second graph captured in a process: ROCm 7.2.)  The pool must
+// exist by then -- nothing may be allocated during a capture: one eager launch on the device,
+// the usual warm-up.  After 960 captured launches, or without the pool, a captured launch takes
+// the static walk.
 // sched_acquire returns the slot's words (or nullptr) and its index; sched_release records
 // the event.  The device comes from the stream, not from the calling thread's current device.
 uint32_t *sched_acquire(hipStream_t st, int *dev, int *slot);

@@ -1456,7 +1456,8 @@ def test_work_queue_slots_with_many_launches_in_flight_and_graph_capture(dev, or
   snnqp.h).  96 launches enqueued on 8 streams without a synchronisation in between (more
   than there are slots: the launches that find their slot busy walk statically), both conv
   kernels, must all produce the result of a lone launch; and a launch captured into a HIP
-  graph (no queue inside a capture) replays bit-identically."""
+  graph (a queue slot of its own, which every launch leaves zeroed for the next replay) replays
+  bit-identically."""
   from snnquantprune_amd import _lib as L
   from snnquantprune_amd import ops
   outs = {}
@@ -1486,7 +1487,7 @@ def test_work_queue_slots_with_many_launches_in_flight_and_graph_capture(dev, or
   assert len(results) == 96
   for name, s, e in results:
     np.testing.assert_array_equal(_np(s), e["pooled_bits"], err_msg=name)
-  # graph capture: the launch inside the capture takes the static walk
+  # graph capture: the launch inside the capture takes one of the capture-only slots
   name, xin, g, w, nrn, bn, x_max, e = jobs[0]
   out = torch.zeros_like(results[0][1].bits)
   graph = torch.cuda.CUDAGraph()
@@ -2374,3 +2375,37 @@ def test_count_hint_follows_the_chunks_not_the_hot_pixel(dev, oracle):
   assert hint.max_seen == 200 and hint.current() == 1
   assert ops.CountHint.choose([100, 0, 0, 0, 3]) == 1 and ops.CountHint.choose([0, 0, 90, 10, 0]) == 31
   assert ops.CountHint.choose([10, 5, 80, 0, 5]) == 7 and ops.CountHint.choose([0, 0, 0, 0, 9]) == 255
+
+
+def test_zz_captured_launches_beyond_the_capture_slots_walk_statically(dev, oracle):
+  """A device has 960 work-queue slots for launches captured into graphs, each taken for good
+  (snnqp.h).  One graph of 1000 conv launches uses them up: the launches beyond take the static
+  walk, and every one of the 1000 outputs is the oracle's, on the first replay and on the
+  second.  (Last in the file: captures of later tests in this process would find no slot.)"""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=3, B=8, hw=8)
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  bn, nrn = _bn(c["bn"], dev), _mslif()
+  g = ops.ConvGeom(8, 8, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+  cap = torch.cuda.Stream(device=dev)
+  graph = torch.cuda.CUDAGraph()
+  n = 1000
+  with torch.cuda.stream(cap):
+    _, s0 = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                                 impl=L.IMPL_MFMA, x_max=1)
+    outs = torch.zeros((n,) + tuple(s0.bits.shape), dtype=s0.bits.dtype, device=dev)
+    cap.synchronize()
+    with torch.cuda.graph(graph, stream=cap):
+      for i in range(n):
+        _, s = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                                    impl=L.IMPL_MFMA, x_max=1)
+        outs[i].copy_(s.bits)
+  for _ in range(2):
+    outs.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = _np(outs).view(np.uint32)
+    assert (got == e["pooled_bits"][None]).all()
