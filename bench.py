@@ -556,10 +556,12 @@ def main(argv=None):
            "samples_per_s": world * B * args.steps / float(tb.item())}
   # the same steps as ONE graph launch each (the product's nn.capture; the reference's step is
   # jit-compiled, examples/eval.py:108-116): the conv kernels keep their work queues inside a
-  # capture, and the launches lose the per-launch memset / event / Python between them
+  # capture, and the launches lose the per-launch memset / event / Python between them.  One
+  # process only: a capture that failed on some rank of a multi-GPU job would take the whole
+  # line with it, and the figure is a per-GPU one anyway (--graph runs it on every rank).
   cap_leg = None
   if (gpu and ops is not None and not args.stand_in and not args.graph and args.feed == "resident"
-      and not args.no_fed_leg):
+      and not args.no_fed_leg and world == 1):
     captured = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
     for _ in range(2):
       parallel.all_gather_rows(captured()[0])
