@@ -377,8 +377,22 @@ def pack_codes_fp6(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.Te
 # ---------------------------------------------------------------------------
 
 
+class NotCapturable(RuntimeError):
+  """The step needs a value on the host (the inspection of float32 activations: are they
+  integers, spikes, how large?) and is being recorded into a hipGraph, which cannot wait for
+  one.  Feed the model integer frames (uint8 or the packed formats of snnqp.h), or run it
+  eagerly."""
+
+
+def _no_capture(what: str):
+  if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+    raise NotCapturable("%s reads a device value back to the host and cannot be captured into a "
+                        "graph (nn.capture): pass integer frames, or call the model eagerly" % what)
+
+
 def inspect_f32(x: torch.Tensor) -> int:
   """Flags of a float32 activation tensor (one device pass + a 4-byte readback)."""
+  _no_capture("the inspection of float32 activations (ops.inspect_f32)")
   x = _f32c(x)
   _require_gpu(x)
   flags = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -413,6 +427,7 @@ def input_max_bound(x) -> int:
     _u8_flag_cache = TensorCache(16)
   v = _u8_flag_cache.get((x,))
   if v is None:
+    _no_capture("the inspection of uint8 activations (ops.input_max_bound)")
     _require_gpu(x)
     xc = x.contiguous()
     flags = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -523,6 +538,7 @@ def narrow_f32(x: torch.Tensor):
   """float32 activations -> (uint8 copy | None, max value): one device pass that
   inspects and narrows; None when some element is not an integer in [0, 255]."""
   global _u8_flag_cache
+  _no_capture("narrowing float32 frames (ops.narrow_f32)")
   x = _f32c(x)
   _require_gpu(x)
   y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)

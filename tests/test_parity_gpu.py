@@ -2377,6 +2377,26 @@ def test_count_hint_follows_the_chunks_not_the_hot_pixel(dev, oracle):
   assert ops.CountHint.choose([10, 5, 80, 0, 5]) == 7 and ops.CountHint.choose([0, 0, 0, 0, 9]) == 255
 
 
+def test_capture_refuses_steps_that_read_back(dev, oracle):
+  """nn.capture of a step that needs a host read-back (float32 frames are inspected and
+  narrowed per batch) raises ops.NotCapturable from inside the capture, before anything illegal
+  is recorded; the same model then runs eagerly and captures on integer frames."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c3 = cases.conv_net_case()
+  e3 = cases.conv_net_expected(oracle, c3)
+  m3 = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  v3 = nn.tree_from_numpy(c3["vars"], dev)
+  x = _t(c3["x"], dev)
+  with pytest.raises(ops.NotCapturable):
+    nn.capture(m3, v3, x.to(torch.float32), trgt=None, train=False, rng=None)
+  torch.cuda.synchronize()
+  logits = m3.apply(v3, x.to(torch.float32), trgt=None, train=False, rng=None)[0]
+  np.testing.assert_array_equal(_np(logits), e3["logits"])
+  step = nn.capture(m3, v3, x, trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(step(x)[0]), e3["logits"])
+
+
 def test_zz_captured_launches_beyond_the_capture_slots_walk_statically(dev, oracle):
   """A device has 960 work-queue slots for launches captured into graphs, each taken for good
   (snnqp.h).  One graph of 1000 conv launches uses them up: the launches beyond take the static
