@@ -230,6 +230,90 @@ void run16(float *out, int wps) {
          NX, wps, cyc, 100.0 * 576.0 / cyc);
 }
 
+// Wave specialisation: a workgroup of 8 waves, waves 0-3 run only the matrix side of a tile-step
+// (18 dependent MFMAs, a ds_read_b128 each, then the 16 accumulator registers written to LDS),
+// waves 4-7 only the vector side (accumulators read back from LDS, the neuron epilogue, the
+// staging stand-in), one s_barrier per tile-step between them (double-buffered hand-over).
+// Two workgroups per CU: per SIMD two matrix waves and two vector waves.
+template <int NX>
+__global__ void __launch_bounds__(512) kspec(float *out, int iters, float kk, float th) {
+  __shared__ __attribute__((aligned(16))) int lds[8192 + 2 * 4 * 1024];     // A image | 2 x 4 waves x 4 KiB of accumulators
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 8192; i += 512) lds[i] = 0x22222222;
+  __syncthreads();
+  const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)lds;
+  const uint32_t addr = base + lane * 16;
+  const uint32_t xaddr = base + 32768 + (wave & 3) * 4096 + lane * 16;      // hand-over slot of the pair
+  float sacc = 0;
+  if (wave < 4) {
+    v16f f = {0};
+    v8i b8 = {0x08208208, lane & 7, 0, 0, 0, 0, 0, 0};
+    v4i q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = v4i{0x22222222, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        v8i av = {q[s % 4].x, q[s % 4].y, q[s % 4].z, q[s % 4].w, 0, 0, 0, 0};
+        if (s == 0) f = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b8, v16f{0}, 4, 2, 0, 127, 0, 127);
+        else f = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b8, f, 4, 2, 0, 127, 0, 127);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[(s + 3) % 4]) : "v"(addr), "n"(1024));
+        asm volatile("s_waitcnt lgkmcnt(2)");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const uint32_t xa = xaddr + (it & 1) * 16384;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(xa), "v"(v4i{__float_as_int(f[4 * g]), __float_as_int(f[4 * g + 1]), __float_as_int(f[4 * g + 2]), __float_as_int(f[4 * g + 3])}), "n"(0) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    }
+    for (int i = 0; i < 16; ++i) sacc += f[i];
+    for (int i = 0; i < 4; ++i) sacc += q[i].x;
+  } else {
+    float u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = 0.01f * lane + i;
+    int xs[4] = {lane, lane + 1, lane + 2, lane + 3};
+    unsigned word = 0;
+    for (int it = 0; it < iters; ++it) {
+      asm volatile("s_barrier" : : : "memory");                  // the accumulators of step it are in slot it & 1
+      const uint32_t xa = xaddr + (it & 1) * 16384;
+      v4i a4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(a4[g]) : "v"(xa + 0 * g));
+      asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int g = j >> 1, e = (j & 1) * 2;
+        pair(u[2 * j], u[2 * j + 1], __int_as_float(a4[g][e]), __int_as_float(a4[g][e + 1]), kk, th, word);
+#pragma unroll
+        for (int i = 0; i < (NX * (j + 1)) / 8 - (NX * j) / 8; ++i)
+          asm volatile("v_add_u32 %0, %1, %2" : "=v"(xs[i % 4]) : "v"(xs[i % 4]), "v"(lane));
+      }
+    }
+    sacc = (float)word + xs[0] + xs[1] + xs[2] + xs[3];
+    for (int i = 0; i < 16; ++i) sacc += u[i];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
+}
+
+template <int NX>
+void run_spec(float *out, int wgs_per_cu) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 4000; float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kspec<NX>), dim3(256 * wgs_per_cu), dim3(512), 0, 0, out, iters, 0.5f, 1.0f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  // a workgroup finishes 4 tile-steps per iteration on 4 SIMDs: one per SIMD
+  const double steps = (double)iters * wgs_per_cu;
+  const double cyc = ms * 1e6 / steps * 2.4;
+  printf("specialised  arith   extra %2d  %d workgroup(s) of 4 + 4 waves per CU: %7.1f SIMD cycles per tile-step  (matrix pipe %4.1f %% busy)\n",
+         NX, wgs_per_cu, cyc, 100.0 * 576.0 / cyc);
+}
+
 template <int PHASED, int NX, int TAB = 0>
 void run(float *out, int wps) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -246,7 +330,7 @@ void run(float *out, int wps) {
 }
 
 int main() {
-  float *out; (void)hipMalloc(&out, 256 * 8 * 256 * 4);
+  float *out; (void)hipMalloc(&out, 256 * 8 * 512 * 4);
   for (int w = 1; w <= 4; ++w) {
     run<0, 48>(out, w);
     run<1, 48>(out, w);
@@ -256,6 +340,7 @@ int main() {
     run<1, 0>(out, w);
   }
   for (int w = 2; w <= 4; ++w) run16<48>(out, w);
+  for (int w = 1; w <= 3; ++w) run_spec<48>(out, w);
   for (int w = 2; w <= 3; ++w) {
     run<0, 48, 0>(out, w);
     run<0, 48, 1>(out, w);
