@@ -265,8 +265,9 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       of the kernel zero-padded along Cin to Cpad = 64 (Cin <= 64) or 128,
  *       tiled by snnqp_pack_codes_mfma with K = 9 * Cpad (row = tap * Cpad + cin);
  *       a pixel keeps its ceil(Cin / 32) spike words, zero bits beyond Cin --
- *       or U8 input with Cin == 2, any count 0..255; or EV1 input, Cin == 2: the bit-packed
- *       frames are staged directly, 1/8 of the uint8 bytes), s_type BITS;
+ *       or U8 input with Cin == 2, any count 0..255; or EV1 / EV4 input, Cin == 2: the packed
+ *       frames are staged directly, 1/8 (binary) or 1/2 (counts <= 15) of the uint8 bytes;
+ *       x_max / x_seen apply to EV4 as to U8), s_type BITS;
  *       any H, W, Cout and neuron kind.  SNNQP_IMPL_AUTO picks MFMA when it can.
  * x_max the largest input value the caller EXPECTS (1 for spikes and binary event frames;
  *       0 = unknown, taken as 1): with the weights' abs_sum_max it sizes the LDS tables the

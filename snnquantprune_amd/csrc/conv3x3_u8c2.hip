@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256, U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
   constexpr bool EV1 = IN == SNNQP_EV1;
+  constexpr bool EV4 = IN == SNNQP_EV4;     // one byte per pixel: polarity 0 low nibble, 1 high
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tc = a.tchunk;                       // <= TCHUNK
@@ -225,7 +226,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     const bool s_valid = s_task && s_gy >= 0 && s_gy < a.H && s_gx >= 0 && s_gx < a.W;
     // byte offset of the pixel within a frame (frames are below 2 GiB: launch check); threads
     // without a pixel read the frame's first one and drop it
-    const uint32_t s_off = s_valid ? (uint32_t)(s_gy * a.W + s_gx) * 2u : 0u;
+    const uint32_t s_off = s_valid ? (uint32_t)(s_gy * a.W + s_gx) * (EV4 ? 1u : 2u) : 0u;
     const uint8_t *s_frames = xb + (int64_t)b * a.xs_b;
     // EV1: the 20 bits of a halo row start `lead` bits before pixel x0 of the row (none when
     // x0 = 0: the pixel left of the image does not exist); pixels outside the image are
@@ -281,7 +282,14 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       for (int i = 0; i < STG_N; ++i) {    // all loads first; the skip is a scalar branch
         const int tt = 2 * i + s_half;
         v[i] = 0;
-        if (tt < nt) v[i] = *(const uint16_t *)(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
+        if (tt < nt) {
+          if constexpr (EV4) {           // nibble-packed counts: the two bytes the uint8 frame would hold
+            const uint32_t pb = *(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
+            v[i] = (pb | (pb << 4)) & 0x0F0Fu;          // 0xHL -> 0x0H0L
+          } else {
+            v[i] = *(const uint16_t *)(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < STG_N; ++i) {
@@ -589,8 +597,11 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   } else if (in_type == SNNQP_EV1) {    // bit-packed binary event frames, staged directly
     if (g->Cin != 2) return "EV1 frames have Cin == 2";
     if ((int64_t)g->H * g->W * 2 >= (int64_t)1 << 31) return "EV1 frame of 2^31 bits or more";
+  } else if (in_type == SNNQP_EV4) {    // nibble-packed count frames (<= 15), staged directly
+    if (g->Cin != 2) return "EV4 frames have Cin == 2";
+    if ((int64_t)g->H * g->W >= (int64_t)1 << 31) return "EV4 frame of 2 GiB or more";
   } else {
-    return "input must be BITS, U8 or EV1 (unpack EV4 frames first: snnqp_unpack_frames)";
+    return "input must be BITS, U8, EV1 or EV4";
   }
   if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
   if (in_type == SNNQP_BITS && !wt) return "MFMA-tiled codes `wt` not given";
@@ -661,6 +672,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
 #define SNNQP_CONV_LAUNCH_IN(KERN, NFV, PL, LM, LDS)                               \
   do {                                                                             \
     if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
+    else if (in_type == SNNQP_EV4) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV4>, a, gy, st, LDS); \
     else launch_persistent(KERN<NFV, PL, LM, SNNQP_U8>, a, gy, st, LDS);            \
   } while (0)
 #define SNNQP_CONV_LAUNCH_NF(KERN, NFV, LM, LDS)                                   \

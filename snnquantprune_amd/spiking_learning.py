@@ -281,11 +281,11 @@ class SpikingBlock(nn.Module):
     bn = norm.coeffs(conn.features) if norm is not None else None
 
     # Packed event frames (the host feed's wire formats): the fused 3x3 event layer stages
-    # bit-packed binary frames (EV1) directly; every other consumer -- nibble-packed count
-    # frames, other geometries, the float32 and direct-form kernels -- gets the uint8 frames
-    # back with one device pass.
+    # them directly, bit-packed binary frames (EV1) and nibble-packed count frames (EV4); every
+    # other consumer -- other geometries, the float32 and direct-form kernels -- gets the uint8
+    # frames back with one device pass.
     if isinstance(x, ops.PackedFrames):
-      direct = (x.fmt == L.EV1 and not is_dense and w.wtype == L.W_I8
+      direct = (not is_dense and w.wtype == L.W_I8
                 and self.impl != L.IMPL_GENERIC and x.ndim == 5
                 and self._event_layer_geometry(conn.geometry(tuple(x.shape[2:-1]), cin)))
       if not direct:
@@ -335,8 +335,9 @@ class SpikingBlock(nn.Module):
                        % (x.shape,))
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
     hint = None
-    if (integer and isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and cin == 2
-        and nsp == 2):
+    if (integer and cin == 2 and nsp == 2 and
+        ((isinstance(x, torch.Tensor) and x.dtype == torch.uint8) or
+         (isinstance(x, ops.PackedFrames) and x.fmt == L.EV4))):
       # the 2-channel event layer: the kernel checks its input itself and only wants to know
       # what to expect -- no inspection pass, no read-back in front of the launch
       hint = ops.count_hint(x.device)

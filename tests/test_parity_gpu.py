@@ -1988,6 +1988,51 @@ def test_event_layer_stages_bit_packed_frames(dev, oracle, hw, T):
         np.testing.assert_array_equal(_np(bm_u), eu, err_msg=tag + " batch-major")
 
 
+@pytest.mark.parametrize("hw", [(16, 16), (13, 17), (34, 30)])
+def test_event_layer_stages_nibble_packed_counts(dev, oracle, hw):
+  """conv0 on EV4 frames (counts <= 15, one byte per pixel, staged directly: a byte becomes
+  the two bytes the uint8 frame would hold) against the oracle and against the same launch on
+  uint8 frames: rasters and potentials bit-equal for hints below, at and above the real
+  maximum (tables / general path per chunk), 4- and 8-bit codes, pooled or not, time- and
+  batch-major; the count-hint words see the same maxima as on uint8 frames."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  H, W = hw
+  T, B = 7, 3
+  rng = np.random.Generator(np.random.PCG64(4400 + H))
+  x = np.minimum(rng.poisson(0.35, (T, B, H, W, 2)), 15).astype(np.uint8)
+  x[2, 1, H // 2, W // 2, 1] = 15                # one pixel at the format's limit
+  x[:, :, 0, 0, 0] = 3
+  g = ops.ConvGeom(H, W, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  nrn = _mslif()
+  for bits in (4, 8):
+    c = cases.conv_block_case(T=2, B=1, hw=8, cin=2, bits=bits, seed=961 + bits, gain=4.0)
+    qw = qweight_of(oracle, c["leaf"], bits)
+    w = _weight(c["leaf"], bits, dev, transposed=True)
+    bn = _bn(c["bn"], dev)
+    eu, es = oracle.conv_block(x, qw, c["bn"], None, "int")
+    assert 0.01 < es.mean() < 0.8
+    pf = ops.pack_frames(_t(x, dev), L.EV4)
+    for hint in (1, 3, 15):
+      for pool in (1, 2) if H % 2 == 0 and W % 2 == 0 else (1,):
+        exp = packbits_lastaxis(oracle.max_pool_2x2(es) if pool == 2 else es)
+        seen_a = torch.zeros(8, dtype=torch.int32, device=dev)
+        seen_b = torch.zeros(8, dtype=torch.int32, device=dev)
+        kw = dict(bn=bn, want_u=True, packed_out=True, pool=pool, impl=L.IMPL_MFMA, x_max=hint)
+        tag = "bits %d hint %d pool %d" % (bits, hint, pool)
+        ev_u, ev_s = ops.conv_lif_forward(pf, g, w, nrn, x_seen=seen_a, **kw)
+        u8_u, u8_s = ops.conv_lif_forward(_t(x, dev), g, w, nrn, x_seen=seen_b, **kw)
+        np.testing.assert_array_equal(_np(ev_s), exp, err_msg=tag)
+        np.testing.assert_array_equal(_np(ev_u), eu, err_msg=tag)
+        np.testing.assert_array_equal(_np(u8_s), exp, err_msg=tag)
+        assert seen_a.tolist() == seen_b.tolist() and seen_a[0].item() == 15, (tag, seen_a.tolist())
+    pfb = ops.pack_frames(_t(np.ascontiguousarray(np.swapaxes(x, 0, 1)), dev), L.EV4)
+    bm_u, bm_s = ops.conv_lif_forward(pfb, g, w, nrn, bn=bn, want_u=True, packed_out=True,
+                                      impl=L.IMPL_MFMA, x_max=3, time_major=False)
+    np.testing.assert_array_equal(_np(bm_s), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(bm_u), eu)
+
+
 def test_models_take_packed_frames(dev, oracle):
   """model.apply on PackedFrames -- EV1 (binary, staged directly by the event layer) and EV4
   (counts, unpacked on the device first) -- gives the logits of the uint8 input and of the
