@@ -50,7 +50,7 @@ constexpr int F6_NBUF = 3;                   // halo images in the ring
 // l of a 32-lane group reads bank l whatever its byte is (ds_read_b32 banks: (a / 4) % 32)
 constexpr int F6_TAB = 256 * 32 * 4;
 // (DQT_MAXA = 2047, conv_tile.h: the |acc| bound DQ_TABLE's table is sized for)
-constexpr int DQT_BYTES = 16384 + 16;        // 4095 entries, then the chain constant x 4
+constexpr int DQT_BYTES = 16384;             // 4095 entries
 
 // 4 int8 codes (|c| <= 7) -> 4 e2m3 codes, one per byte
 __device__ __forceinline__ uint32_t fp6_codes4(uint32_t x) {
@@ -98,8 +98,11 @@ __device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d
 //             register itself.  The matrix pipe adds denormals exactly
 //             (tools/ubench/mfma_denorm.hip: bit patterns equal to the integer sums over the
 //             whole range, at the speed of the normal range); partial sums never leave
-//             [-A, A], so the pattern never goes negative.  The constants of the next chain are
-//             re-read into the consumed accumulator registers, four at a time (ds_read_b128).
+//             [-A, A], so the pattern never goes negative.  The chain constant sits in sixteen
+//             registers of its own (the C operand of every chain's first MFMA); the A-fragment
+//             ring is 3 deep in this form to make room for them (re-reading the constants into
+//             the consumed accumulator registers, four ds_read_b128 per timestep, with the ring
+//             of 6: 1 % slower).
 //   (round 1's table form -- v_cvt + shift + ds_read_b32 on an int32 accumulator -- saved one
 //   instruction per value; this one saves three of the epilogue's 8.6)
 // BNF: every BatchNorm mean and bias of the launch is zero (snnqp_bn_t.flags): x = y * mul
@@ -182,15 +185,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   // address of entry A as a bit pattern
   const uint32_t dqt_mid = lds0 + (uint32_t)DQT_OFF + 4u * (uint32_t)(TABLE ? a.lut_bound : 0);
   const float chain0 = TABLE ? __uint_as_float(dqt_mid) : 0.0f;
-  uint32_t chain_addr = lds0 + (uint32_t)DQT_OFF + 16384u;
   if (TABLE) {
     for (int i = tid; i <= 2 * a.lut_bound; i += F6_NT) {
       const float af = (float)(i - a.lut_bound);
       const float q = __builtin_fmaf(af, a.dq.rL, af * a.dq.rLlo);   // exact af / L (common.h)
       ((float *)(lds + DQT_OFF))[i] = q * a.dq.m;
     }
-    if (tid < 4) ((uint32_t *)(lds + DQT_OFF + 16384))[tid] = dqt_mid;
-    asm volatile("" : "+v"(chain_addr));       // one register, not a constant per use
   }
 
   LaneConsts lc = {0.f, 1.f, 0.f, 0.f, a.nrn.vr};
@@ -301,6 +301,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       }
     };
     const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc_t cblk = zero16;                         // DQ_TABLE: where every chain starts
+    if constexpr (TABLE) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cblk[i] = chain0;
+      asm volatile("" : "+v"(cblk));             // sixteen registers, not a constant per use
+    }
     auto dequant1 = [&](auto a0) -> float {
       if constexpr (TABLE) return *(lds_cfloat_t *)(uintptr_t)__float_as_uint((float)a0);
       const float af = (float)a0;                // exact integer
@@ -361,24 +367,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         e.ew = writelane_u32((uint32_t)(e.m1[j] >> 32), r0 + 5, e.ew);
       }
     };
-    // DQ_TABLE: registers 4 g .. 4 g + 3 of a consumed accumulator take the constants the next
-    // chain starts from (the table reads that used them as addresses are issued: an LDS
-    // instruction reads its address register at issue)
-    auto chain_reload = [&](acc_t &accC, int g) {
-      if constexpr (TABLE) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) const v4f lds_cv4f_t;
-        const v4f c = *(lds_cv4f_t *)(uintptr_t)chain_addr;
-        accC[4 * g] = c.x; accC[4 * g + 1] = c.y; accC[4 * g + 2] = c.z; accC[4 * g + 3] = c.w;
-      }
-    };
     auto estage = [&](acc_t &accC, int st, ETmp &e) {
       const int j = st_j(st), q = st_q(st), jg = j % GP;
       if (q == 0) {
         if (j + YD < 8) {
           e.ey[(j + YD) % EYN][0] = dequant1(accC[2 * (j + YD)]);
           e.ey[(j + YD) % EYN][1] = dequant1(accC[2 * (j + YD) + 1]);
-          if ((j + YD) & 1) chain_reload(accC, (j + YD) >> 1);
         }
       } else if (q == 1) {
         if (BNF) {                   // mean == 0: fl(y - 0) = y
@@ -418,7 +412,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       for (int j = 0; j < YD; ++j) {
         e.ey[j][0] = dequant1(accC[2 * j]);
         e.ey[j][1] = dequant1(accC[2 * j + 1]);
-        if (j & 1) chain_reload(accC, j >> 1);
       }
     };
     constexpr int NSTAGES = 8 * NST;             // 40 stages per timestep
@@ -427,7 +420,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     };
 
     // ---- A-fragment ring: PF fragments in flight, across step boundaries ----------------
-    constexpr int RING = KS % 6 == 0 ? 6 : 3;    // divides KS (9, 18, 36): static indices
+    constexpr int RING = KS % 6 == 0 && !TABLE ? 6 : 3;    // divides KS (9, 18, 36): static indices
     constexpr int PF = RING == 6 ? F6_PF : 2;
     static_assert(KS % RING == 0 && PF < RING, "ring indices must repeat every step");
     v4i A[RING];
@@ -446,7 +439,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
         for (int st = (WR_SLOT + 1) * (8 * NST) / KS; st < (BAR_SLOT + 1) * (8 * NST) / KS; ++st)
           if ((st % (NST * GP)) / GP == 0) {       // stage 0 of pair j (st_q, st_j)
             const int j = (st / (NST * GP)) * GP + (st % (NST * GP)) % GP;
-            if (j + YD < 8) n += 2 + ((j + YD) & 1);
+            if (j + YD < 8) n += 2;
           }
       return n;
     }();
@@ -458,8 +451,8 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       estage_head(accC, e);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks == 0) accN = mfma_acc(0, A[0], TABLE ? accN : zero16);   // C = inline 0 (table:
-        else accN = mfma_acc(ks, A[ks % RING], accN);                   // the reloaded constants)
+        if (ks == 0) accN = mfma_acc(0, A[0], TABLE ? cblk : zero16);   // C = inline 0 (table:
+        else accN = mfma_acc(ks, A[ks % RING], accN);                   // the chain constants)
         __builtin_amdgcn_sched_barrier(0);
         // the slot's A read: PF slots ahead, wrapping into the next step's image
         if (ks + PF < KS) A[(ks + PF) % RING] = a_read(rd_e, rd_o, ks + PF);
@@ -479,7 +472,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           // retires the write without draining the A fragments in flight across the barrier
           // (lgkmcnt(0), which a release fence emits, cost an LDS round trip per step).  No
           // scalar load is in flight here (they return out of order): the loop has none.
-          // (DQ_TABLE: the table reads and constant reloads of the slots in between count too)
+          // (DQ_TABLE: the table reads of the slots in between count too)
           asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_SLOT - WR_SLOT + TAB_OPS) : "memory");
           if (s >= FL && s % FL == 0)              // timesteps < s are behind this barrier
             flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, s - FL, FL, b, y0, x0, tid);
@@ -513,10 +506,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
     // pipeline prologue: halo(0), halo(1) staged; MFMA(0) alone
     acc_t accA, accB;
-    if constexpr (TABLE) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) accA[i] = accB[i] = chain0;
-    }
     stage_load(0, 0);
     if (a.T > 1) stage_load(1, 1);
     stage_expand(0);
@@ -536,7 +525,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       for (int i = 0; i < PF; ++i) A[i] = a_read(e0, o0, i);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks == 0) accA = mfma_acc(0, A[0], TABLE ? accA : zero16);
+        if (ks == 0) accA = mfma_acc(0, A[0], TABLE ? cblk : zero16);
         else accA = mfma_acc(ks, A[ks % RING], accA);
         if (ks + PF < KS) A[(ks + PF) % RING] = a_read(e0, o0, ks + PF);
         else if (a.T > 1) A[(ks + PF) % RING] = a_read(e1, o1, ks + PF - KS);
