@@ -428,8 +428,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // One pipelined step s: MFMA(s + 1) from the image (rd_e, rd_o) while the epilogue of
     // timestep s runs on accC; halo(s + 2) is written early, the barrier follows two slots
     // later; the last PF slots request the first fragments of the NEXT step from (rn_e, rn_o).
-    constexpr int WR_SLOT = F6_WR_SLOT < KS - PF - 2 ? F6_WR_SLOT : 1;
-    constexpr int BAR_SLOT = F6_BAR_SLOT < KS - PF ? F6_BAR_SLOT : WR_SLOT + 1;
+    // The table form wants both late (write after 5/9 of the slots, barrier after 5/6, right
+    // before the next step's first fragments are requested): conv1 5.19 ms against 5.28 with
+    // the early pair, 5.28 again with the write one slot before the barrier.
+    constexpr int BAR_LATE = KS * 5 / 6 < KS - PF ? KS * 5 / 6 : KS - PF - 1;
+    constexpr int WR_SLOT = TABLE ? KS * 5 / 9 : F6_WR_SLOT < KS - PF - 2 ? F6_WR_SLOT : 1;
+    constexpr int BAR_SLOT = TABLE ? BAR_LATE : F6_BAR_SLOT < KS - PF ? F6_BAR_SLOT : WR_SLOT + 1;
     static_assert(WR_SLOT < BAR_SLOT && BAR_SLOT < KS - PF,
                   "the halo is written before the barrier, the next step's fragments read after it");
     // LDS instructions the epilogue stages of slots WR_SLOT + 1 .. BAR_SLOT issue (DQ_TABLE)
@@ -473,7 +477,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           // (lgkmcnt(0), which a release fence emits, cost an LDS round trip per step).  No
           // scalar load is in flight here (they return out of order): the loop has none.
           // (DQ_TABLE: the table reads of the slots in between count too)
-          asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_SLOT - WR_SLOT + TAB_OPS) : "memory");
+          // (the counter holds 15: a larger count means "everything but the 15 youngest", which
+          // still covers the write)
+          constexpr int BAR_WAIT = BAR_SLOT - WR_SLOT + TAB_OPS < 15 ? BAR_SLOT - WR_SLOT + TAB_OPS : 15;
+          asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" : : "n"(BAR_WAIT) : "memory");
           if (s >= FL && s % FL == 0)              // timesteps < s are behind this barrier
             flush_ring<POOL, SLOTS, F6_NT, NPIX>(obuf, a, s - FL, FL, b, y0, x0, tid);
         }
