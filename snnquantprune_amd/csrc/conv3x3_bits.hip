@@ -428,12 +428,15 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     // One pipelined step s: MFMA(s + 1) from the image (rd_e, rd_o) while the epilogue of
     // timestep s runs on accC; halo(s + 2) is written early, the barrier follows two slots
     // later; the last PF slots request the first fragments of the NEXT step from (rn_e, rn_o).
-    // The table form wants both late (write after 5/9 of the slots, barrier after 5/6, right
-    // before the next step's first fragments are requested): conv1 5.19 ms against 5.28 with
-    // the early pair, 5.28 again with the write one slot before the barrier.
+    // The table form and the int8 instruction want both late (write after 5/9 of the slots,
+    // barrier after 5/6, right before the next step's first fragments are requested): conv1
+    // 5.19 ms against 5.28 with the early pair (5.28 again with the write one slot before the
+    // barrier), 8-bit codes 8.70 against 8.89; the fp6 kernel with arithmetic dequantisation
+    // keeps the early pair (2-bit layer of C5: 1.50 against 1.53 ms late).
+    constexpr bool LATE = TABLE || I8;
     constexpr int BAR_LATE = KS * 5 / 6 < KS - PF ? KS * 5 / 6 : KS - PF - 1;
-    constexpr int WR_SLOT = TABLE ? KS * 5 / 9 : F6_WR_SLOT < KS - PF - 2 ? F6_WR_SLOT : 1;
-    constexpr int BAR_SLOT = TABLE ? BAR_LATE : F6_BAR_SLOT < KS - PF ? F6_BAR_SLOT : WR_SLOT + 1;
+    constexpr int WR_SLOT = LATE ? KS * 5 / 9 : F6_WR_SLOT < KS - PF - 2 ? F6_WR_SLOT : 1;
+    constexpr int BAR_SLOT = LATE ? BAR_LATE : F6_BAR_SLOT < KS - PF ? F6_BAR_SLOT : WR_SLOT + 1;
     static_assert(WR_SLOT < BAR_SLOT && BAR_SLOT < KS - PF,
                   "the halo is written before the barrier, the next step's fragments read after it");
     // LDS instructions the epilogue stages of slots WR_SLOT + 1 .. BAR_SLOT issue (DQ_TABLE)
