@@ -7,11 +7,11 @@ O=$GRAFT_REPO_ROOT/gpurun_out/${1:-s3m}; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done: $(python -c "import json;d=json.load(open('$O/bench.json'));print(round(d['value']), d['roofline']['frac'])")"
-( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof.err )
+( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof.err )
 f=$(ls $O/prof/*/*kernel_stats.csv | head -1); python tools/trim_rocprof_stats.py $f $O/kernel_stats.csv; head -8 $O/kernel_stats.csv
 bash tools/pmc_profile.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc/summary.json $O/pmc_summary.json; cp gpurun_out/pmc/traffic.json $O/pmc_traffic.json; cp gpurun_out/pmc/summary.txt $O/pmc_summary.txt
 bash tools/pmc_variant.sh ${1:-s3m} product > $O/pmc_lds.log 2>&1
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --steps 6 --warmup 2 "$@" > $O/bench_$name.json 2> $O/bench_$name.err || echo "$name failed"; }
+run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --steps 6 --warmup 4 "$@" > $O/bench_$name.json 2> $O/bench_$name.err || echo "$name failed"; }
 run random_bn --random-bn
 run c5 --frames 50 --batch 512 --layer-bits 2,4,2,4 --prune 0.95 --classes 10
 run 8bit --bits 8 --prune 0.3
