@@ -1793,6 +1793,32 @@ def test_conv_bits_kernel_dequantises_through_the_accumulator_addressed_table(de
     np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
 
 
+def test_conv_bits_kernel_forms_agree_at_the_headline_shape(dev):
+  """The dequantisation forms of the bits kernel are bit-equal by construction; at conv1's own
+  shape (64 x 64 x 128 -> 128, T = 20, 4-bit / 90 % pruned, B = 32: 4096 patches, every
+  workgroup walks several) the table form (what AUTO picks) and the arithmetic form (forced by
+  hiding the accumulator bound) give the same pooled rasters and the same potentials, with and
+  without a carried-in state."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=2, B=1, hw=8, cin=128, cout=128, seed=5150, gain=5.0)
+  w = _weight(c["leaf"], 4, dev, transposed=True)
+  assert ops.conv_dequant_form(w, _mslif()) == "table"
+  wa = dataclasses.replace(w, abs_sum_max=0, min_current_bits=0)
+  assert ops.conv_dequant_form(wa, _mslif()) == "arith"
+  bn = _bn(c["bn"], dev)
+  g = ops.ConvGeom(64, 64, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  gen = torch.Generator(device=dev); gen.manual_seed(5151)
+  x = ops.pack_bits((torch.rand((20, 32, 64, 64, 128), device=dev, generator=gen) < 0.15).to(torch.uint8))
+  u0 = torch.rand((32, 64, 64, 128), device=dev, generator=gen) * 0.7
+  for carry in (None, u0):
+    ut, st = ops.conv_lif_forward(x, g, w, _mslif(), bn=bn, u0=carry, packed_out=True, pool=2, impl=L.IMPL_MFMA)
+    ua, sa = ops.conv_lif_forward(x, g, wa, _mslif(), bn=bn, u0=carry, packed_out=True, pool=2, impl=L.IMPL_MFMA)
+    assert torch.equal(st.bits, sa.bits) and torch.equal(ut, ua)
+    assert 0.01 < float(st.to_dense().float().mean()) < 0.9
+
+
 def test_conv_work_queues_on_concurrent_streams(dev, oracle):
   """The patch work queues come from a per-device pool of slots: launches that overlap on
   different streams (and more than 64 launches in a row, so slots are reused) still give
