@@ -230,6 +230,13 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
 
   lds_barrier();                                 // tables are visible
 
+  // DQ_TABLE: where every chain starts -- sixteen registers for the whole launch
+  acc_t cblk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (TABLE) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cblk[i] = chain0;
+    asm volatile("" : "+v"(cblk));               // not a constant per use
+  }
   PatchWalk pw(a);
   // patch indices (+ one grid stride) stay below 2^31 (run_conv3x3_mfma refuses launches of
   // 2^30 patches or more) and are workgroup-uniform: scalar registers
@@ -301,12 +308,6 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
       }
     };
     const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc_t cblk = zero16;                         // DQ_TABLE: where every chain starts
-    if constexpr (TABLE) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) cblk[i] = chain0;
-      asm volatile("" : "+v"(cblk));             // sixteen registers, not a constant per use
-    }
     auto dequant1 = [&](auto a0) -> float {
       if constexpr (TABLE) return *(lds_cfloat_t *)(uintptr_t)__float_as_uint((float)a0);
       const float af = (float)a0;                // exact integer
