@@ -696,8 +696,16 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
                                   B * T * (4096 + 16) + 32768 * 128 * (3 if lb[3] <= 4 else 4) // 4,
                                   conv_peak(lb[3])),
       # config C2 (bit-packed spikes in and out, int8 codes once per launch)
-      "dense[2048->512]": (B * T * 2048 * 512, B * T * (256 + 64) + 2048 * 512, INT8_MFMA_PEAK_TOPS),
+      # (uint8 rows are read in place: 2048 B per sample-step, not the 256 B of a bit-packed row)
+      "dense[2048->512]": (B * T * 2048 * 512, B * T * ((2048 if args.input == "u8" else 256) + 64) + 2048 * 512,
+                           INT8_MFMA_PEAK_TOPS),
       "dense[512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 16) + 512 * 128, INT8_MFMA_PEAK_TOPS),
+      # config C2 as ONE launch (snnqp_dense_head_forward): the uint8 rows as the kernel reads them
+      # (2048 B per sample-step, in place), both code matrices once, the logits; the hidden
+      # raster never leaves the CU
+      "dense_head[2048->512->%d]" % nout: (B * T * (2048 * 512 + 512 * nout),
+                                           B * T * (2048 if args.input == "u8" else 256) + 2048 * 512
+                                           + 512 * 128 + B * 4 * args.classes, INT8_MFMA_PEAK_TOPS),
   }
   traffic, traffic_src, pmc, pmc_src = {}, None, {}, None
   headline = (B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3")
@@ -749,6 +757,8 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
   # achieved = algorithmic ops (bytes) per launch / average launch duration
   conv_kernel = "conv3x3_bits_kernel"   # one device function, fp6 or int8 instruction inside
   dense_tag = "dense[2048->512]" if args.model == "dense" else "dense[32768->%d]" % nout
+  if args.model == "dense" and "dense_head[2048->512->%d]" % nout in kern:
+    dense_tag = "dense_head[2048->512->%d]" % nout
   groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
             "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
             "dense kernel": [dense_tag] + (["dense[512->%d]" % nout] if args.model == "dense" else [])}

@@ -164,9 +164,9 @@ typedef struct {
 /* ABI version of this header: bumped whenever a struct or a signature below changes
  * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
  * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
- * snnqp_fallback_counts; 301: snnqp_conv_dequant_form).  A binding compares snnqp_version() with the SNNQP_VERSION it was
+ * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward).  A binding compares snnqp_version() with the SNNQP_VERSION it was
  * written against and refuses a library of another version (_lib.py does). */
-#define SNNQP_VERSION 301
+#define SNNQP_VERSION 400
 int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build
@@ -322,7 +322,9 @@ int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bou
  * T <= 96, or U8 input (any count 0..255, read in place: no packing pass, no inspection)
  * with w->col_sum, K % 16 == 0, K <= 65536, 16-byte aligned rows and T <= 64.  With
  * w->wt_fp6 and code_max <= 7, BITS rows run on the fp4 x fp6 MFMA instead (T <= 160, `wt` not
- * needed).  Longer runs and everything else: the direct-form kernel. */
+ * needed).  Longer runs and everything else: the direct-form kernel.  (More than 128 features
+ * with T <= 64: a workgroup per 256 / 512-column block that reads every row once,
+ * csrc/dense_wide.hip; else 128 columns per workgroup, csrc/dense_mfma.hip.) */
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,
@@ -330,6 +332,33 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             const snnqp_neuron_t *nrn, const float *u0,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream);
+
+/* ---- the dense head as one launch -----------------------------------------------
+ * replaces: the two dense SpikingBlocks and the vote that end CextNet,
+ *           examples/tcja/models.py:200-255 --
+ *             SpikingBlock(QuantDense(N1), neuron) -> SpikingBlock(QuantDense(N2), neuron)
+ *             -> mean over T -> mean over each class's `group` neurons
+ *           (per block spiking_learning.py:446-462 with flax_qdense.py:74-89; no norm_fn, no
+ *           bias: models.py:200-208, 231-236), i.e. config C2 of BASELINE.json as a whole.
+ * x     [T][B][K] by strides, SNNQP_U8 (any count 0..255, read in place; needs w1->col_sum,
+ *       K % 16 == 0, 16-byte aligned rows) or SNNQP_BITS (zero bits beyond K).
+ * w1/wt1  int8 codes [K][N1] and their tiles (snnqp_pack_codes_mfma, Npad = N1 rounded up to 32,
+ *       K rows zero-padded to a multiple of 32); w2/wt2 the same for [N1][N2] (its K is N1).
+ * logits  float32 [B][N2 / group], as snnqp_vote gives them.
+ * s1_out / s2_out  nullable: the two spike rasters, SNNQP_BITS [T][B][ceil(N / 32)], as
+ *       snnqp_dense_lif_forward writes them (the hidden raster otherwise never leaves the CU).
+ * Membrane potentials start from zero (initialize_carry, spiking_learning.py:464-472) and are
+ * not returned: a caller that carries state uses snnqp_dense_lif_forward per block.
+ * SNNQP_EUNSUPPORTED (nothing enqueued) unless N1 <= 512, N2 <= 128, 1 <= T <= 64 and both
+ * weights are W_I8 with tiles: the caller then runs the blocks one by one. */
+int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_stride_t,
+                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
+                             int32_t N1, const snnqp_weight_t *w1, const int8_t *wt1,
+                             const snnqp_neuron_t *nrn1, int32_t N2,
+                             const snnqp_weight_t *w2, const int8_t *wt2,
+                             const snnqp_neuron_t *nrn2, int32_t group,
+                             uint32_t *s1_out, uint32_t *s2_out, float *logits,
+                             snnqp_stream_t stream);
 
 /* ---- element-wise pieces ----------------------------------------------------
  * replaces: neural_dynamics(u, x) scanned over T, spiking_learning.py:460

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
 
 # include/snnqp.h SNNQP_VERSION the prototypes below were written against
-ABI_VERSION = 301
+ABI_VERSION = 400
 
 # enums of include/snnqp.h
 F32, U8, BITS, EV1, EV4 = 0, 1, 2, 3, 4
@@ -86,6 +86,10 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
         c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "snnqp_dense_head_forward": (c_int, [
+        c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(WeightT),
+        c_void_p, POINTER(NeuronT), c_int32, POINTER(WeightT), c_void_p, POINTER(NeuronT), c_int32,
+        c_void_p, c_void_p, c_void_p, c_void_p]),
     "snnqp_fallback_counts": (c_int, [POINTER(c_int64), POINTER(c_int64), c_char_p, c_int32, c_int]),
     "snnqp_conv_dequant_form": (c_int, [POINTER(WeightT), POINTER(NeuronT)]),
     "snnqp_current_min": (c_int, [POINTER(WeightT), POINTER(BnT), c_int32, c_int32, c_void_p, c_void_p]),

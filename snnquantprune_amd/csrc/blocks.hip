@@ -113,6 +113,11 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
       (int64_t)(T > 0 ? T - 1 : 0) * x_stride_t + 160 * x_stride_b + (K + 31) / 32 < ((int64_t)1 << 31))
     return run_dense_fp6(x, x_stride_t, x_stride_b, T, B, K, N, w, bn, nrn, u0, u_out,
                          (uint32_t *)s_out, 0, (hipStream_t)stream);
+  // more than 128 features: a workgroup per 256 / 512-column block, every row read once
+  if (impl != SNNQP_IMPL_GENERIC &&
+      !dense_wide_unsupported(in_type, T, K, N, x_stride_t, x_stride_b, x, w, wt, nrn, s_type))
+    return run_dense_wide(x, in_type, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn, u0, u_out,
+                          (uint32_t *)s_out, (hipStream_t)stream);
   const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
   if (!why && T > (in_type == SNNQP_U8 ? 64 : 96))
     why = "more than 96 (uint8 input: 64) timesteps (one sample must fit a row tile)";

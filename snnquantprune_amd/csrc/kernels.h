@@ -38,6 +38,16 @@ int run_dense_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, hipStream_t st);
 
+// all the columns of a 256 / 512-column block per workgroup, neuron from the accumulator
+// registers (dense_wide.hip); nullptr when it can serve the request
+const char *dense_wide_unsupported(int in_type, int32_t T, int32_t K, int32_t N, int64_t xs_t,
+                                   int64_t xs_b, const void *x, const snnqp_weight_t *w,
+                                   const int8_t *wt, const snnqp_neuron_t *nrn, int s_type);
+int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
+                   int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
+                   const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                   float *u_out, uint32_t *s_out, hipStream_t st);
+
 // codes of magnitude <= 7 on the f8f6f4 MFMA (dense_fp6.hip); row_tiles 0 = choose
 int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B, int32_t K,
                   int32_t N, const snnqp_weight_t *w, const snnqp_bn_t *bn,

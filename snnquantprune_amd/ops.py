@@ -239,11 +239,17 @@ class Weight:
   wt6: Optional[torch.Tensor] = None       # dense, code_max <= 7: fp6 MFMA tiles (pack_codes_fp6)
 
   def struct(self) -> L.WeightT:
-    return L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
+    # (built once per object: a Weight is not modified after the pack step made it --
+    # dataclasses.replace makes a new one -- and it keeps its tensors alive)
+    st = self.__dict__.get("_cstruct")
+    if st is None:
+      st = L.WeightT(self.wtype, self.w.data_ptr(), float(self.L), float(self.m),
                      int(self.abs_sum_max), int(self.code_max),
                      None if self.col_sum is None else self.col_sum.data_ptr(),
                      None if self.wt6 is None else self.wt6.data_ptr(),
                      int(self.min_current_bits))
+      self.__dict__["_cstruct"] = st
+    return st
 
   @property
   def is_int(self):
@@ -760,6 +766,34 @@ def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
         ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0),
         _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl, _stream()))
   return u_out, (PackedSpikes(s, N) if packed_out else s)
+
+
+def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight, N2: int,
+                       nrn2: Neuron, group: int = 10, want_s1: bool = False,
+                       want_s2: bool = False, time_major: bool = True):
+  """The dense head as ONE launch (snnqp_dense_head_forward; examples/tcja/models.py:200-255):
+  x [T, B, K] uint8 or PackedSpikes -> (logits [B, N2 // group], hidden raster | None,
+  output raster | None).  Raises SnnqpError(EUNSUPPORTED) when the head does not fit the fused
+  kernel; the caller then runs the two blocks and the vote one by one."""
+  xt, in_type = _in_desc(x)
+  xt = xt.contiguous()
+  _require_gpu(xt, w1.w, w2.w)
+  T, B = (xt.shape[0], xt.shape[1]) if time_major else (xt.shape[1], xt.shape[0])
+  xs_t, xs_b = _tb_strides(xt, T, B, time_major, xt.shape[-1])
+  dev = xt.device
+  if N2 % group:
+    raise ValueError("vote: %d features not divisible by group %d" % (N2, group))
+  logits = torch.empty((B, N2 // group), dtype=torch.float32, device=dev)
+  s1 = torch.empty((T, B, (N1 + 31) // 32), dtype=torch.int32, device=dev) if want_s1 else None
+  s2 = torch.empty((T, B, (N2 + 31) // 32), dtype=torch.int32, device=dev) if want_s2 else None
+  a, b, n1, n2 = w1.struct(), w2.struct(), nrn1.struct(), nrn2.struct()
+  with _timed("dense_head[%d->%d->%d]" % (K, N1, N2)):
+    L.check(L.lib().snnqp_dense_head_forward(
+        _ptr(xt), in_type, xs_t, xs_b, T, B, K, N1, ctypes.byref(a), _ptr(w1.wt), ctypes.byref(n1),
+        N2, ctypes.byref(b), _ptr(w2.wt), ctypes.byref(n2), int(group), _ptr(s1), _ptr(s2),
+        _ptr(logits), _stream()))
+  return (logits, PackedSpikes(s1, N1) if want_s1 else None,
+          PackedSpikes(s2, N2) if want_s2 else None)
 
 
 def fallback_counts(reset: bool = False) -> dict:

@@ -194,6 +194,50 @@ def _flat_perm(c, h, w, device):
   return perm
 
 
+def fused_dense_head(block1, block2, inputs, group: int = 10, want_s1: bool = False,
+                     want_s2: bool = False):
+  """SpikingBlock(QuantDense) -> SpikingBlock(QuantDense) -> vote of examples/tcja/models.py:
+  200-255 as ONE launch (snnqp_dense_head_forward) when both blocks are plain fusable dense blocks
+  over integer inputs with int8 codes; returns (logits, s1 | None, s2 | None), or None when the
+  head does not fit (the caller then runs the blocks one by one: same numbers).  The parameters
+  are created in the order the two blocks would create them."""
+  for blk in (block1, block2):
+    if (not blk._fusable() or not isinstance(blk.connection_fn, QuantDense) or blk.norm_fn is not None
+        or blk.pool != 1 or blk.impl != L.IMPL_AUTO or blk.return_state):
+      return None
+  if block2.batch_major_input or getattr(inputs, "flat_perm", None) is not None:
+    return None
+  if not (isinstance(inputs, ops.PackedSpikes)
+          or (isinstance(inputs, torch.Tensor) and inputs.dtype == torch.uint8)):
+    return None
+  x = inputs
+  if x.ndim != 3:
+    return None
+  tm = not block1.batch_major_input
+  T = x.shape[0] if tm else x.shape[1]
+  c1, c2 = block1.connection_fn, block2.connection_fn
+  K, N1, N2 = x.shape[-1], c1.features, c2.features
+  if not (1 <= T <= 64 and 128 < N1 <= 512 and N2 <= 128 and N2 % group == 0):
+    return None
+  if isinstance(x, torch.Tensor) and K % 16:
+    return None
+  pk1 = c1.packed_kernel(K)
+  w1 = pk1.int_weight_mfma((N1 + 31) // 32 * 32)
+  nrn1 = block1.neural_dynamics.neuron(N1)
+  pk2 = c2.packed_kernel(N1)
+  w2 = pk2.int_weight_mfma((N2 + 31) // 32 * 32)
+  nrn2 = block2.neural_dynamics.neuron(N2)
+  if w1 is None or w2 is None or w1.wt is None or w2.wt is None or w1.col_sum is None:
+    return None
+  try:
+    return ops.dense_head_forward(x, w1, K, N1, nrn1, w2, N2, nrn2, group=group, want_s1=want_s1,
+                                  want_s2=want_s2, time_major=tm)
+  except L.SnnqpError as e:
+    if e.code != L.EUNSUPPORTED:
+      raise
+    return None
+
+
 class SpikingBlock(nn.Module):
   """connection -> [norm] -> neuron over the leading (time) axis.
 

@@ -2500,3 +2500,149 @@ def test_zz_captured_launches_beyond_the_capture_slots_walk_statically(dev, orac
     torch.cuda.synchronize()
     got = _np(outs).view(np.uint32)
     assert (got == e["pooled_bits"][None]).all()
+
+
+# ---------------------------------------------------------------------------
+# round 4: the wide dense kernel (a workgroup per 256 / 512-column block, the neuron from the
+# accumulator registers) and the dense head as one launch
+# ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("shape", [(20, 37, 2048, 512), (1, 9, 64, 129), (3, 70, 160, 256),
+                                   (64, 3, 96, 300), (17, 11, 1040, 700), (33, 6, 48, 512),
+                                   (5, 300, 272, 384)],
+                         ids=["c2_layer1", "one_step", "ct1_full", "longest_t", "two_col_blocks",
+                              "t_over_32", "many_samples"])
+@pytest.mark.parametrize("fmt", ["u8", "bits"])
+def test_dense_wide_kernel(dev, oracle, shape, fmt):
+  """Dense blocks with more than 128 features (dense_wide.hip): uint8 rows (binary, counts, every
+  value up to 255) and bit-packed rows, time-major and batch-major, with a carried-in state, all
+  row-tile counts the launcher may pick: rasters and potentials equal the oracle's."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, K, N = shape
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  rng = np.random.Generator(np.random.PCG64(K + N))
+  u0 = _t(c["u0"], dev)
+  before = ops.fallback_counts()["dense_blocks"]
+  inputs = [("binary", c["x"])]
+  if fmt == "u8":
+    wide = np.minimum(rng.poisson(0.15, (T, B, K)), 255).astype(np.uint8)
+    wide[rng.random(wide.shape) < 0.002] = 255
+    wide[0, 0, :3] = (128, 127, 200)
+    inputs.append(("to_255", wide))
+  for name, x in inputs:
+    eu, es = oracle.dense_block(x, qw, None, "int", u0=c["u0"])
+    xd = _t(x, dev) if fmt == "u8" else ops.pack_bits(_t(x, dev))
+    u, s = ops.dense_lif_forward(xd, w, K, N, _mslif(), u0=u0, packed_out=True, impl=L.IMPL_MFMA)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg=name)
+    np.testing.assert_array_equal(_np(u), eu, err_msg=name)
+    xb = np.ascontiguousarray(np.swapaxes(x, 0, 1))
+    xbd = _t(xb, dev) if fmt == "u8" else ops.pack_bits(_t(xb, dev))
+    ub, sb = ops.dense_lif_forward(xbd, w, K, N, _mslif(), u0=None, packed_out=True,
+                                   impl=L.IMPL_AUTO, time_major=False)
+    eu0, es0 = oracle.dense_block(x, qw, None, "int")
+    np.testing.assert_array_equal(_np(sb), packbits_lastaxis(es0), err_msg=name + " batch-major")
+    np.testing.assert_array_equal(_np(ub), eu0, err_msg=name + " batch-major")
+  assert ops.fallback_counts()["dense_blocks"] == before
+
+
+@pytest.mark.parametrize("kind", ["plif", "lif", "mslif_tau3", "mslif_vreset"])
+def test_dense_wide_kernel_neurons_and_batchnorm(dev, oracle, kind):
+  """The neuron variants of spiking_learning.py:357-438 and a BatchNorm in front of them on the
+  wide dense kernel (the fast form u += (x - u) m and the general one)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  T, B, K, N = 11, 13, 320, 200
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  rng = np.random.Generator(np.random.PCG64(77))
+  bn = {"mean": rng.normal(0, 0.1, N).astype(F32), "var": (0.5 + rng.random(N)).astype(F32),
+        "scale": (0.8 + 0.4 * rng.random(N)).astype(F32), "bias": rng.normal(0, 0.1, N).astype(F32)}
+  sig = lambda v: (1.0 / (1.0 + np.exp(-np.asarray(v, np.float64)))).astype(F32)
+  vth, vr = 1.0, 0.0
+  if kind == "plif":
+    tau_param = F32(-0.35)
+    nrn = ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, float(sig(tau_param)), vth, vr)
+    ocfg = {"kind": "parametric_leaky_IF", "tau_param": tau_param}
+  elif kind == "lif":
+    tau_vec = rng.uniform(-1.0, 2.0, N).astype(F32)
+    nrn = ops.Neuron(L.NEURON_LIF, 1.0, vth, vr, decay=_t(sig(tau_vec), dev))
+    ocfg = {"kind": "LIF", "tau_vec": tau_vec}
+  elif kind == "mslif_tau3":
+    nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, vth, vr)
+    ocfg = {"kind": "multi_step_LIF", "tau": 3.0}
+  else:
+    vth, vr = 0.8, 0.1
+    nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, vth, vr)
+    ocfg = {"kind": "multi_step_LIF", "tau": 2.0}
+  ocfg.update(v_threshold=vth, v_reset=vr)
+  for use_bn in (False, True):
+    norm = (lambda y: oracle.batchnorm_eval(y, bn["mean"], bn["var"], bn["scale"], bn["bias"], 1e-5)) \
+        if use_bn else None
+    eu, es = oracle.spiking_block(c["u0"], c["x"], lambda xx: oracle.quant_dense(xx, qw, "int"),
+                                  oracle._neuron(ocfg), norm)
+    assert 0.005 < es.mean() < 0.7, es.mean()
+    u, s = ops.dense_lif_forward(_t(c["x"], dev), w, K, N, nrn, bn=_bn(bn, dev) if use_bn else None,
+                                 u0=_t(c["u0"], dev), packed_out=True, impl=L.IMPL_MFMA)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="%s bn=%s" % (kind, use_bn))
+    np.testing.assert_array_equal(_np(u), eu, err_msg="%s bn=%s" % (kind, use_bn))
+
+
+@pytest.mark.parametrize("shape", [(20, 256, 2048, 512, 110), (6, 5, 208, 200, 70), (64, 3, 96, 300, 30),
+                                   (1, 40, 64, 512, 120), (9, 131, 1040, 384, 110), (3, 77, 320, 160, 50)],
+                         ids=["c2", "small", "longest_t", "one_step", "ragged_batch", "many_per_group"])
+@pytest.mark.parametrize("fmt", ["u8", "bits"])
+def test_dense_head_as_one_launch(dev, oracle, shape, fmt):
+  """snnqp_dense_head_forward -- QuantDense + LIF -> QuantDense + LIF -> vote
+  (examples/tcja/models.py:200-255) in one launch -- against the oracle's two blocks and vote:
+  both rasters and the logits bit-exact, on uint8 rows (counts up to 255) and bit-packed rows."""
+  from snnquantprune_amd import ops
+  T, B, K, N1, N2 = shape
+  c = cases.dense_net_case(True, T=T, B=B, K=K, hidden=N1, out=N2)
+  p = c["vars"]["params"]
+  x = np.ascontiguousarray(np.swapaxes(c["x"], 0, 1))                # [T, B, K]
+  if fmt == "u8":
+    rng = np.random.Generator(np.random.PCG64(K))
+    x = x.copy()
+    x[rng.random(x.shape) < 0.003] = 3
+    x[0, 0, :2] = (255, 128)
+  q1, q2 = qweight_of(oracle, p["QuantDense_0"], 8), qweight_of(oracle, p["QuantDense_1"], 8)
+  e = oracle.dense2_forward(x, q1, q2, mode="int")
+  w1 = _weight(p["QuantDense_0"], 8, dev, transposed=True)
+  w2 = _weight(p["QuantDense_1"], 8, dev, transposed=True)
+  xd = _t(x, dev) if fmt == "u8" else ops.pack_bits(_t(x, dev))
+  logits, s1, s2 = ops.dense_head_forward(xd, w1, K, N1, _mslif(), w2, N2, _mslif(), group=10,
+                                          want_s1=True, want_s2=True)
+  np.testing.assert_array_equal(_np(s1), packbits_lastaxis(e["s1"].astype(np.uint8)))
+  np.testing.assert_array_equal(_np(s2), packbits_lastaxis(e["s2"].astype(np.uint8)))
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+  # without the rasters (what a step asks for), batch-major rows
+  xb = np.ascontiguousarray(np.swapaxes(x, 0, 1))
+  xbd = _t(xb, dev) if fmt == "u8" else ops.pack_bits(_t(xb, dev))
+  l2, n1, n2 = ops.dense_head_forward(xbd, w1, K, N1, _mslif(), w2, N2, _mslif(), time_major=False)
+  assert n1 is None and n2 is None
+  np.testing.assert_array_equal(_np(l2), e["logits"])
+
+
+def test_dense_snn_model_takes_the_fused_head(dev, oracle):
+  """DenseSNN (config C2) calls the fused head when it fits and the two blocks + vote when it
+  does not (hidden > 512): same logits as the oracle either way, and the fused path is ONE
+  dense launch per step."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  for hidden, fused in ((512, True), (544, False)):
+    c = cases.dense_net_case(True, T=20, B=24, K=512, hidden=hidden)
+    e = cases.dense_net_expected(oracle, c)
+    model = models.DenseSNN(num_classes=11, config=syn.make_config(bits=8, prune_percentage=0.5, hidden=hidden))
+    variables = nn.tree_from_numpy(c["vars"], dev)
+    model.apply(variables, _t(c["x"], dev), trgt=None, train=False, rng=None)   # packs the weights
+    ops.profile_start()
+    (logits, _) = model.apply(variables, _t(c["x"], dev), trgt=None, train=False, rng=None)
+    prof = ops.profile_stop()
+    np.testing.assert_array_equal(_np(logits), e["logits"])
+    tags = sorted(prof)
+    assert (tags == ["dense_head[512->512->110]"]) == fused, tags
