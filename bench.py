@@ -636,6 +636,8 @@ def main(argv=None):
                         ) if collective else "none (one process, no process group)"
   if ops is not None:
     line["fallbacks"] = ops.fallback_counts()      # blocks on the direct-form kernel (should be 0)
+    line["fallbacks"].update(ops.workqueue_stats())   # static patch walks, arithmetic instead of table dequantisation
+    line["device_status"] = ops.device_status()       # 0: no kernel reported a broken invariant
   if args.graph:
     line["config"]["launch"] = "hipGraph replay of model.apply (kernel times from the eager warm-up)"
   if build_flags or os.environ.get("SNNQP_DIAG_LIB"):

@@ -16,8 +16,9 @@
  *    right before its launch and guarded by an event; a launch that finds its slot still in
  *    flight (more than 64 conv launches outstanding on the device) walks its patches
  *    statically instead: same results, no queue -- and 960 slots that launches captured into
- *    a graph take one each, for good (the pool must exist before the capture: one eager
- *    launch on the device);
+ *    a graph take one each until snnqp_workqueue_capture_release hands them back (the pool
+ *    must exist before the capture: one eager launch on the device); 64 bytes of page-locked
+ *    host memory per device hold the status word (snnqp_device_status);
  *  - descriptor structs (snnqp_*_t) are HOST structs read during the call;
  *  - all work is enqueued on `stream` (a hipStream_t); no call synchronises;
  *  - return value: 0 on success, <0 on error (SNNQP_E*); the message is
@@ -164,7 +165,8 @@ typedef struct {
 /* ABI version of this header: bumped whenever a struct or a signature below changes
  * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
  * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
- * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward).  A binding compares snnqp_version() with the SNNQP_VERSION it was
+ * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward, snnqp_device_status,
+ * snnqp_workqueue_*).  A binding compares snnqp_version() with the SNNQP_VERSION it was
  * written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 400
 int snnqp_version(void);
@@ -295,6 +297,33 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
  * new reason is also printed to stderr.  No reference counterpart (diagnostic). */
 int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *reason,
                           int32_t reason_len, int reset);
+
+/* ---- device status, work-queue bookkeeping (no reference counterpart: diagnostics) ----------
+ * The conv kernels walk their patches through per-launch work queues and the split-K dense
+ * kernel hands partial sums over through tickets; both rely on counters that are zero when a
+ * launch begins.  A launch that ends with its bookkeeping not adding up (its results may be
+ * wrong) stores a code in the device's status word -- page-locked host memory, read without any
+ * synchronisation -- and every later snnqp_conv_lif_forward / snnqp_dense_lif_forward /
+ * snnqp_dense_head_forward on that device returns SNNQP_EHIP until the word is reset. */
+#define SNNQP_STATUS_QUEUE_CORRUPT 1u /* a conv launch's patches did not add up */
+#define SNNQP_STATUS_TICKET 2u        /* a split-K dense launch drew a ticket out of range */
+int snnqp_device_status(int device, uint32_t *codes, int reset);
+/* Launches captured into a graph take a work-queue slot of their own (see the top of this file).
+ * mark: the number of capture slots handed out on `device` so far.  release: the slots handed out
+ * between two marks go back to the pool -- call it when the graph that was captured between the
+ * marks has been destroyed and its last replay has completed. */
+int snnqp_workqueue_capture_mark(int device, int64_t *mark);
+int snnqp_workqueue_capture_release(int device, int64_t mark_begin, int64_t mark_end);
+/* Since the library was loaded (or the last reset): conv launches that walked their patches
+ * statically because no capture slot was left / because their eager slot was still in flight
+ * (same results, worse balance), and bit-input conv launches that ran the arithmetic
+ * dequantisation because the device failed (or, under capture, had not yet run) the probe of the
+ * matrix pipe's float32-denormal arithmetic that SNNQP_DQ_TABLE rests on (same results). */
+int snnqp_workqueue_stats(int64_t *captured_static, int64_t *busy_static,
+                          int64_t *dequant_fallbacks, int reset);
+/* test hook: writes `value` into word `word` of the capture slot that was handed out at `mark`
+ * (synchronous) */
+int snnqp_debug_workqueue_poke(int device, int64_t mark, int word, uint32_t value);
 
 /* How the bit-input 3x3 MFMA kernels of snnqp_conv_lif_forward turn the integer accumulator
  * into the current fl(fl(acc / L) * m) for these weights and this neuron (host-side query, no

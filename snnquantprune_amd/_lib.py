@@ -27,6 +27,7 @@ IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA = 0, 1, 2
 FLAG_CODE_OVERFLOW, FLAG_MASK_NOT_BINARY = 1, 2
 FLAG_NOT_INTEGER, FLAG_GT_ONE, FLAG_GT_127, FLAG_GT_15 = 4, 8, 16, 32
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
+STATUS_QUEUE_CORRUPT, STATUS_TICKET = 1, 2
 
 
 class WeightT(Structure):
@@ -90,6 +91,11 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(WeightT),
         c_void_p, POINTER(NeuronT), c_int32, POINTER(WeightT), c_void_p, POINTER(NeuronT), c_int32,
         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snnqp_device_status": (c_int, [c_int, POINTER(c_uint32), c_int]),
+    "snnqp_workqueue_capture_mark": (c_int, [c_int, POINTER(c_int64)]),
+    "snnqp_workqueue_capture_release": (c_int, [c_int, c_int64, c_int64]),
+    "snnqp_workqueue_stats": (c_int, [POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int]),
+    "snnqp_debug_workqueue_poke": (c_int, [c_int, c_int64, c_int, c_uint32]),
     "snnqp_fallback_counts": (c_int, [POINTER(c_int64), POINTER(c_int64), c_char_p, c_int32, c_int]),
     "snnqp_conv_dequant_form": (c_int, [POINTER(WeightT), POINTER(NeuronT)]),
     "snnqp_current_min": (c_int, [POINTER(WeightT), POINTER(BnT), c_int32, c_int32, c_void_p, c_void_p]),

@@ -31,6 +31,17 @@ void note_fallback(bool dense, const char *why) {
 }
 }  // namespace
 
+// a kernel on the device of `st` reported a broken invariant (runtime.hip): refuse to go on
+static int refuse_after_device_report(hipStream_t st, const char *who) {
+  const uint32_t code = device_status_read(stream_device(st));
+  if (code) {
+    set_error("%s: device status 0x%x: %s (snnqp_device_status(..., reset = 1) clears it)", who,
+              (unsigned)code, device_status_text(code));
+    return SNNQP_EHIP;
+  }
+  return SNNQP_OK;
+}
+
 extern "C" {
 
 int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *reason,
@@ -65,6 +76,7 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int s_type, int pool, int impl, int x_max, int32_t *x_seen,
                            snnqp_stream_t stream) {
   SNNQP_REQUIRE(g && w && nrn, SNNQP_EINVAL, "conv_lif_forward: null descriptor");
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "conv_lif_forward")) return rc;
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
                     nrn->kind <= SNNQP_NEURON_LIF,
                 SNNQP_EINVAL, "conv_lif_forward: unknown neuron kind %d", nrn->kind);
@@ -100,6 +112,7 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream) {
   SNNQP_REQUIRE(w && nrn, SNNQP_EINVAL, "dense_lif_forward: null descriptor");
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "dense_lif_forward")) return rc;
   SNNQP_REQUIRE(K > 0 && N > 0, SNNQP_EINVAL, "dense_lif_forward: bad K/N");
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
                     nrn->kind <= SNNQP_NEURON_LIF,

@@ -241,7 +241,9 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   // patch indices (+ one grid stride) stay below 2^31 (run_conv3x3_mfma refuses launches of
   // 2^30 patches or more) and are workgroup-uniform: scalar registers
   int r = __builtin_amdgcn_readfirstlane((int)pw.first);
+  uint32_t processed = 0;                       // patches of this workgroup (scalar)
   while (r < (int)pw.count) {
+    ++processed;
     int claimed = 0;
     if (pw.queue && tid == 0) claimed = (int)pw.claim();   // next patch, a patch ahead
     int b, y0, x0;
@@ -576,7 +578,7 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
     if (pw.queue) r_next = __builtin_amdgcn_readfirstlane((int)nxt[0]);
     r = r_next;
   }
-  if (pw.queue && tid == 0) pw.finish();
+  if (pw.queue && tid == 0) pw.finish(processed, a.npatch, a.status);
 }
 
 template <int FMT, int CIN, int NF, int DQ, bool FMA, bool BNF>

@@ -10,11 +10,14 @@
 // dequant / BatchNorm constants are per-lane registers, the membrane potentials of a
 // tile stay in 16 VGPRs for all T, and the v_cmp that thresholds a register *is* the
 // packed spike word of two pixels (64-bit lane mask); pooling is an OR of those masks.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
 #include <type_traits>
 #include <utility>
+
+#include <vector>
 
 #include "conv_tile.h"
 
@@ -212,7 +215,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   // patch indices (+ one grid stride) stay below 2^31 (run_conv3x3_mfma refuses launches of
   // 2^30 patches or more) and are workgroup-uniform: scalar registers
   int r = __builtin_amdgcn_readfirstlane((int)pw.first);
+  uint32_t processed = 0;                       // patches of this workgroup (scalar)
   while (r < (int)pw.count) {
+    ++processed;
     int claimed = 0;
     if (pw.queue && tid == 0) claimed = (int)pw.claim();   // next patch, a patch ahead
     int b, y0, x0;
@@ -388,7 +393,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     for (int k = 0; k < 5; ++k)
       if (hist[k] != 0) atomicAdd((uint32_t *)a.x_seen + 1 + k, hist[k]);
   }
-  if (pw.queue && tid == 0) pw.finish();
+  if (pw.queue && tid == 0) pw.finish(processed, a.npatch, a.status);
 }
 
 // ---------------------------------------------------------------------------
@@ -426,7 +431,10 @@ struct SchedPool {
   bool retired[SCHED_SLOTS] = {};      // no event could be made: never handed out again
   unsigned next = 0;
   unsigned next_capture = 0;           // slots SCHED_SLOTS + i: one per captured launch
+  std::vector<int> capture_log;        // capture slots in the order they were handed out
+  std::vector<int> capture_free;       // ... and the ones handed back (snnqp_workqueue_capture_release)
 };
+std::atomic<int64_t> g_static_captured{0}, g_static_busy{0};
 std::mutex g_sched_mu;
 SchedPool g_sched[64];
 
@@ -462,8 +470,18 @@ uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
   if (capturing) {
     // a slot of its own, zero since the pool was allocated and zero again after every launch
     // that walked it (conv_tile.h)
-    if (!p.words || p.next_capture >= (unsigned)SCHED_CAPTURE_SLOTS) return nullptr;
-    const int slot = SCHED_SLOTS + (int)p.next_capture++;
+    if (!p.words) { g_static_captured.fetch_add(1, std::memory_order_relaxed); return nullptr; }
+    int slot;
+    if (!p.capture_free.empty()) {
+      slot = p.capture_free.back();
+      p.capture_free.pop_back();
+    } else if (p.next_capture < (unsigned)SCHED_CAPTURE_SLOTS) {
+      slot = SCHED_SLOTS + (int)p.next_capture++;
+    } else {
+      g_static_captured.fetch_add(1, std::memory_order_relaxed);     // every capture slot is taken
+      return nullptr;
+    }
+    p.capture_log.push_back(slot);
     *dev_out = dev;
     *slot_out = slot;
     return p.words + (size_t)slot * SCHED_WORDS;
@@ -500,6 +518,7 @@ uint32_t *sched_acquire(hipStream_t st, int *dev_out, int *slot_out) {
     p.has_event[slot] = true;
   } else if (hipEventQuery(p.busy[slot]) != hipSuccess) {
     (void)hipGetLastError();            // hipErrorNotReady: the slot's last launch is in flight
+    g_static_busy.fetch_add(1, std::memory_order_relaxed);
     return nullptr;
   }
   uint32_t *words = p.words + (size_t)slot * SCHED_WORDS;
@@ -698,7 +717,10 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     // three-instruction form; BatchNorm is the multiply alone when the caller knows every mean
     // and bias is zero
     const bool i8 = !(w->code_max > 0 && w->code_max <= 7);
-    const int dq = conv3x3_bits_dequant_form(w, nrn);
+    // (the table form rests on the matrix pipe adding float32 denormals exactly: probed once
+    // per device, runtime.hip; a device that does not gets the arithmetic form, same results)
+    int dq = conv3x3_bits_dequant_form(w, nrn);
+    if (dq == DQ_TABLE && !dq_table_trusted(stream_device(st), st)) dq = DQ_ARITH;
     const bool tab = dq == DQ_TABLE;
     const bool bnf = (a.bn.flags & (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO)) ==
                      (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO);
@@ -735,3 +757,51 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
 }
 
 }  // namespace snnqp
+
+// ---- work-queue bookkeeping visible to the binding -----------------------------------------
+extern "C" int snnqp_workqueue_capture_mark(int device, int64_t *mark) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(device >= 0 && device < 64 && mark, SNNQP_EINVAL, "workqueue_capture_mark: bad argument");
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  *mark = (int64_t)g_sched[device].capture_log.size();
+  return SNNQP_OK;
+}
+
+extern "C" int snnqp_workqueue_capture_release(int device, int64_t mark_begin, int64_t mark_end) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(device >= 0 && device < 64, SNNQP_EINVAL, "workqueue_capture_release: bad device");
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  SchedPool &p = g_sched[device];
+  SNNQP_REQUIRE(0 <= mark_begin && mark_begin <= mark_end && mark_end <= (int64_t)p.capture_log.size(),
+                SNNQP_EINVAL, "workqueue_capture_release: marks out of range");
+  for (int64_t i = mark_begin; i < mark_end; ++i) {
+    const int slot = p.capture_log[(size_t)i];
+    if (slot < 0) continue;                        // handed back already
+    p.capture_free.push_back(slot);
+    p.capture_log[(size_t)i] = -1;
+  }
+  return SNNQP_OK;
+}
+
+extern "C" int snnqp_workqueue_stats(int64_t *captured_static, int64_t *busy_static,
+                                     int64_t *dequant_fallbacks, int reset) {
+  using namespace snnqp;
+  if (captured_static) *captured_static = g_static_captured.load(std::memory_order_relaxed);
+  if (busy_static) *busy_static = g_static_busy.load(std::memory_order_relaxed);
+  if (dequant_fallbacks) *dequant_fallbacks = dq_table_fallbacks(reset != 0);
+  if (reset) { g_static_captured = 0; g_static_busy = 0; }
+  return SNNQP_OK;
+}
+
+extern "C" int snnqp_debug_workqueue_poke(int device, int64_t mark, int word, uint32_t value) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(device >= 0 && device < 64 && word >= 0 && word < SCHED_WORDS, SNNQP_EINVAL,
+                "debug_workqueue_poke: bad argument");
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  SchedPool &p = g_sched[device];
+  SNNQP_REQUIRE(p.words && mark >= 0 && mark < (int64_t)p.capture_log.size() && p.capture_log[(size_t)mark] >= 0,
+                SNNQP_EINVAL, "debug_workqueue_poke: no live capture slot at mark %lld", (long long)mark);
+  SNNQP_HIP(hipMemcpy(p.words + (size_t)p.capture_log[(size_t)mark] * SCHED_WORDS + word, &value, 4,
+                      hipMemcpyHostToDevice));
+  return SNNQP_OK;
+}

@@ -81,6 +81,7 @@ struct ConvMfmaArgs {
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (<= 32)
   uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk
+  uint32_t *status;   // the device's status word (runtime.hip), or null
   int32_t patch_h;    // rows of a patch: 8 (two 4x8 tiles), or 4 (conv3x3_bits.hip, one tile)
 };
 
@@ -138,18 +139,29 @@ struct PatchWalk {
   // of its static share left: 4.75 against 7.44 ms measured inside conv0).  One thread
   // claims, a patch ahead so that the atomic's round trip hides behind the patch.
   // (never beyond `count`, whatever the counter holds: a word that was not zero at the start
-  // of the launch costs patches, it must not cost an out-of-range patch index)
+  // of the launch must not cost an out-of-range patch index -- it costs patches, and finish()
+  // reports that)
   __device__ __forceinline__ int64_t claim() const {
     const int64_t r = stride + (int64_t)atomicAdd(queue, 1u);
     return r < count ? r : count;
   }
-  // after the last claim of the workgroup (one thread): count it; the last of the launch
-  // zeroes the slot
-  __device__ __forceinline__ void finish() const {
+  // After the last claim of the workgroup (one thread): add the patches this workgroup processed
+  // to the launch's tally and count the workgroup; the last one of the launch checks the tally
+  // against the number of patches the launch had -- a queue word that was not zero when the
+  // launch began (an aborted launch, a graph replayed concurrently with itself) makes
+  // workgroups skip patches, which must not pass silently: the device's status word gets
+  // SNNQP_STATUS_QUEUE_CORRUPT and the next call into the library fails (runtime.hip) -- and
+  // zeroes the slot for its next user.
+  __device__ __forceinline__ void finish(uint32_t processed, int64_t npatch, uint32_t *status) const {
+    atomicAdd(done + 1, processed);
     __threadfence();
     const uint32_t total = gridDim.x;
     if (atomicAdd(done, 1u) + 1u == total) {
+      __threadfence();
+      const uint32_t tally = atomicAdd(done + 1, 0u);
+      if (tally != (uint32_t)npatch && status) *(volatile uint32_t *)status = SNNQP_STATUS_QUEUE_CORRUPT;
       for (int i = 0; i < 8; ++i) done[i - 8] = 0u;
+      done[1] = 0u;
       __threadfence();
       *done = 0u;
     }
@@ -530,18 +542,23 @@ __device__ __forceinline__ v16i splat16(int v) {
 //    nullptr), which is always correct, only less well balanced (C3 under a graph without
 //    queues: 13.6 ms against 12.3).
 // A launch that is being CAPTURED into a graph (events cannot be queried there) gets a slot of
-// its own out of SCHED_CAPTURE_SLOTS further ones, never handed out again.  Nothing is added to
+// its own out of SCHED_CAPTURE_SLOTS further ones, handed back when the caller says the graph is
+// gone (snnqp_workqueue_capture_release; linen.CapturedApply does).  Nothing is added to
 // the graph for it: the pool is zeroed when it is allocated, the last workgroup of every launch
 // leaves the slot's words zero again (PatchWalk::finish), and a graph does not run concurrently
 // with itself -- every replay finds zeroed words.  (A memset node in front of the kernel node,
-// the obvious way, faulted on the second graph captured in a process: ROCm 7.2.)  The pool must
+// the obvious way, aborted on the replay of the second graph captured in a process; DESIGN.md
+// 4.6 has what is known about it.)  A word that is NOT zero at a replay makes workgroups skip
+// patches: finish() tallies the patches and reports a mismatch through the device's status word
+// (runtime.hip).  The pool must
 // exist by then -- nothing may be allocated during a capture: one eager launch on the device,
-// the usual warm-up.  After 960 captured launches, or without the pool, a captured launch takes
-// the static walk.
+// the usual warm-up.  With all 960 capture slots taken, or without the pool, a captured launch
+// takes the static walk (counted: snnqp_workqueue_stats).
 // sched_acquire returns the slot's words (or nullptr) and its index; sched_release records
 // the event.  The device comes from the stream, not from the calling thread's current device.
 uint32_t *sched_acquire(hipStream_t st, int *dev, int *slot);
 void sched_release(int dev, int slot, hipStream_t st);
+uint32_t *device_status_word(int dev);            // runtime.hip
 
 // CUs of device `dev` and the workgroups of `kernel` one CU holds (threads, dynamic LDS):
 // asked from the runtime once per (kernel, threads, LDS bytes, device) and remembered -- the
@@ -555,6 +572,7 @@ static inline void launch_persistent(K kernel, ConvMfmaArgs a, unsigned gy, hipS
   int dev = 0, cus = 256, occ = 2, slot = -1;
   a.sched = gy <= (unsigned)SCHED_Y ? sched_acquire(st, &dev, &slot) : nullptr;   // npatch < 2^30: run_conv3x3_mfma
   if (!a.sched) dev = stream_device(st);
+  a.status = a.sched ? device_status_word(dev) : nullptr;
   persistent_limits((const void *)kernel, threads, dyn_lds, dev, &cus, &occ);
   const int64_t gmax = (int64_t)cus * occ;
   unsigned gx = (unsigned)(a.npatch < gmax ? a.npatch : gmax);

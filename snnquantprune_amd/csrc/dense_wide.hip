@@ -683,6 +683,11 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
                                         snnqp_stream_t stream) {
   using namespace snnqp;
   SNNQP_REQUIRE(x && w1 && w2 && nrn1 && nrn2 && logits, SNNQP_EINVAL, "dense_head_forward: null argument");
+  if (const uint32_t code = device_status_read(stream_device((hipStream_t)stream))) {
+    set_error("dense_head_forward: device status 0x%x: %s (snnqp_device_status(..., reset = 1) clears it)",
+              (unsigned)code, device_status_text(code));
+    return SNNQP_EHIP;
+  }
   SNNQP_REQUIRE(T >= 0 && B >= 0 && K > 0 && N1 > 0 && N2 > 0 && group > 0, SNNQP_EINVAL,
                 "dense_head_forward: bad sizes");
   SNNQP_REQUIRE(N2 % group == 0, SNNQP_EINVAL, "dense_head_forward: N2=%d not divisible by group=%d", N2, group);

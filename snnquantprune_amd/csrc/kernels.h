@@ -24,6 +24,15 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
                      int x_max, int32_t *x_seen, hipStream_t st);
 
+// per-device state (runtime.hip): the status word kernels report broken invariants into, the
+// probe of the matrix pipe's denormal arithmetic behind DQ_TABLE
+uint32_t *device_status_word(int dev);
+uint32_t device_status_read(int dev);
+const char *device_status_text(uint32_t code);
+bool dq_table_trusted(int dev, hipStream_t st);
+int64_t dq_table_fallbacks(bool reset);
+int stream_device(hipStream_t st);
+
 // float32 x float32 connection on the f32 MFMA (fseq_gemm.hip)
 const char *fseq_gemm_unsupported(int in_type, const snnqp_conv_geom_t *g,
                                   const snnqp_weight_t *w);

@@ -489,13 +489,38 @@ class CapturedApply:
     self._graph = torch.cuda.CUDAGraph()
     cur = torch.cuda.current_stream(dev)
     self._stream.wait_stream(cur)
+    self._device = torch.device(dev)
+    self._slots = None
     with torch.cuda.stream(self._stream):
       for _ in range(2):               # packs, caches and the allocator's pools, outside the capture
         module.apply(variables, self.static_input, **kwargs)
       self._stream.synchronize()
-      with torch.cuda.graph(self._graph, stream=self._stream):
-        self.static_output = module.apply(variables, self.static_input, **kwargs)
+      # the conv launches recorded below take a work-queue slot each (snnqp.h): remember which,
+      # so that they go back to the pool with this object
+      mark = ops.workqueue_capture_mark(self._device)
+      try:
+        with torch.cuda.graph(self._graph, stream=self._stream):
+          self.static_output = module.apply(variables, self.static_input, **kwargs)
+      finally:
+        self._slots = (mark, ops.workqueue_capture_mark(self._device))
     cur.wait_stream(self._stream)
+
+  def close(self):
+    """Destroys the graph and hands its work-queue slots back (after its last replay has
+    completed).  Called by the destructor; idempotent."""
+    slots, self._slots = self._slots, None
+    if slots is None or slots[0] == slots[1]:
+      self._graph = None
+      return
+    try:
+      torch.cuda.synchronize(self._device)
+      self._graph = None
+      self._ops.workqueue_capture_release(self._device, slots[0], slots[1])
+    except Exception:                   # interpreter shutdown: the pool dies with the process
+      pass
+
+  def __del__(self):
+    self.close()
 
   def _clone(self, x):
     ops = self._ops
@@ -516,6 +541,8 @@ class CapturedApply:
         raise ValueError("captured for inputs %s %s, got %s %s"
                          % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
       dst.copy_(src, non_blocking=True)
+    if self._graph is None:
+      raise RuntimeError("this CapturedApply has been closed")
     self._graph.replay()
     return self.static_output
 

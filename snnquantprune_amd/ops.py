@@ -807,6 +807,35 @@ def fallback_counts(reset: bool = False) -> dict:
           "last_reason": buf.value.decode("utf-8", "replace")}
 
 
+def device_status(device=None, reset: bool = False) -> int:
+  """Codes the kernels of `device` have reported into its status word (_lib.STATUS_*; 0: none) --
+  a launch whose bookkeeping did not add up.  While it is not zero the fused block calls raise
+  SnnqpError(EHIP); reset=True clears it (after the caller has dealt with the suspect results)."""
+  dev = torch.cuda.current_device() if device is None else torch.device(device).index
+  code = ctypes.c_uint32()
+  L.check(L.lib().snnqp_device_status(int(dev or 0), ctypes.byref(code), 1 if reset else 0))
+  return int(code.value)
+
+
+def workqueue_stats(reset: bool = False) -> dict:
+  """Conv launches that walked their patches statically (no capture slot left / eager slot still
+  in flight) and bit-input conv launches that ran the arithmetic dequantisation because the
+  device did not pass (or, under capture, had not yet run) the denormal probe of the table form."""
+  a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+  L.check(L.lib().snnqp_workqueue_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), 1 if reset else 0))
+  return {"captured_static_walks": a.value, "busy_static_walks": b.value, "dequant_table_fallbacks": c.value}
+
+
+def workqueue_capture_mark(device) -> int:
+  m = ctypes.c_int64()
+  L.check(L.lib().snnqp_workqueue_capture_mark(int(torch.device(device).index or 0), ctypes.byref(m)))
+  return int(m.value)
+
+
+def workqueue_capture_release(device, begin: int, end: int):
+  L.check(L.lib().snnqp_workqueue_capture_release(int(torch.device(device).index or 0), int(begin), int(end)))
+
+
 DQ_FORMS = {1: "arith", 2: "one", 3: "table"}
 
 

@@ -384,8 +384,14 @@ def test_bench_metric_label_follows_the_arguments():
   # the roofline block of the C2 line: the first dense block is the dense layer the metric names
   r = bench.rooflines_of(c2, {"dense[2048->512]": (10, 0.2), "dense[512->110]": (10, 0.2)}, 256, 20, [8] * 4)
   assert r["roofline_dense"]["kernel"] == "dense[2048->512]" and r["roofline"]["kernel"] == "dense kernel"
-  nbytes = 256 * 20 * (256 + 64) + 2048 * 512
+  # (the bytes of the format the kernel really reads: uint8 rows in place, 2048 B per sample-step)
+  nbytes = 256 * 20 * (2048 + 64) + 2048 * 512
   assert abs(r["roofline_dense"]["achieved"] - nbytes / 0.02e-3 / 1e9) < 1e-6
+  # ... and as one launch (snnqp_dense_head_forward), which is what the model runs when it fits
+  r = bench.rooflines_of(c2, {"dense_head[2048->512->110]": (10, 0.3)}, 256, 20, [8] * 4)
+  assert r["roofline_dense"]["kernel"] == "dense_head[2048->512->110]"
+  nbytes = 256 * 20 * 2048 + 2048 * 512 + 512 * 128 + 256 * 4 * 11
+  assert abs(r["roofline_dense"]["achieved"] - nbytes / 0.03e-3 / 1e9) < 1e-6
 
 
 def _flax_blob_module():

@@ -2484,11 +2484,13 @@ def test_zz_captured_launches_beyond_the_capture_slots_walk_statically(dev, orac
   cap = torch.cuda.Stream(device=dev)
   graph = torch.cuda.CUDAGraph()
   n = 1000
+  static0 = ops.workqueue_stats()["captured_static_walks"]
   with torch.cuda.stream(cap):
     _, s0 = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
                                  impl=L.IMPL_MFMA, x_max=1)
     outs = torch.zeros((n,) + tuple(s0.bits.shape), dtype=s0.bits.dtype, device=dev)
     cap.synchronize()
+    mark0 = ops.workqueue_capture_mark(dev)
     with torch.cuda.graph(graph, stream=cap):
       for i in range(n):
         _, s = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
@@ -2500,6 +2502,26 @@ def test_zz_captured_launches_beyond_the_capture_slots_walk_statically(dev, orac
     torch.cuda.synchronize()
     got = _np(outs).view(np.uint32)
     assert (got == e["pooled_bits"][None]).all()
+  # the launches that found no slot were counted, and the slots come back with the graph
+  assert ops.workqueue_stats()["captured_static_walks"] - static0 >= n - 960
+  mark1 = ops.workqueue_capture_mark(dev)
+  assert 0 < mark1 - mark0 <= 960
+  del graph
+  torch.cuda.synchronize()
+  ops.workqueue_capture_release(dev, mark0, mark1)
+  static1 = ops.workqueue_stats()["captured_static_walks"]
+  graph2 = torch.cuda.CUDAGraph()
+  with torch.cuda.stream(cap):
+    with torch.cuda.graph(graph2, stream=cap):
+      _, s = ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                                  impl=L.IMPL_MFMA, x_max=1)
+  graph2.replay()
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(_np(s), e["pooled_bits"])
+  assert ops.workqueue_stats()["captured_static_walks"] == static1      # it got a slot again
+  mark2 = ops.workqueue_capture_mark(dev)
+  del graph2
+  ops.workqueue_capture_release(dev, mark1, mark2)
 
 
 # ---------------------------------------------------------------------------
@@ -2646,3 +2668,117 @@ def test_dense_snn_model_takes_the_fused_head(dev, oracle):
     np.testing.assert_array_equal(_np(logits), e["logits"])
     tags = sorted(prof)
     assert (tags == ["dense_head[512->512->110]"]) == fused, tags
+
+
+def test_a_dirty_work_queue_is_reported_not_skipped_silently(dev, oracle):
+  """A captured conv launch relies on its work-queue words being zero at every replay (the last
+  workgroup of a launch leaves them so).  A word that is not -- here poked into the slot between
+  two replays; in the field an aborted launch, or a graph replayed concurrently with itself --
+  makes workgroups skip patches.  That must not pass as a result: the launch's patch tally does
+  not add up, the device's status word says so, the next call into the library raises, and after
+  the reset (the launch has left its slot clean again) replays are the oracle's once more.
+  (1280 patches for at most 512 workgroups: the queue is really walked.)"""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=2, B=40, hw=32)
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  bn, nrn = _bn(c["bn"], dev), _mslif()
+  g = ops.ConvGeom(32, 32, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+
+  def launch():
+    return ops.conv_lif_forward(xin, g, w, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                                impl=L.IMPL_MFMA, x_max=1)[1]
+  assert ops.device_status() == 0
+  cap = torch.cuda.Stream(device=dev)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.stream(cap):
+    launch()
+    cap.synchronize()
+    mark = ops.workqueue_capture_mark(dev)
+    with torch.cuda.graph(graph, stream=cap):
+      s = launch()
+  assert ops.workqueue_capture_mark(dev) - mark == 1
+  graph.replay()
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(_np(s), e["pooled_bits"])
+  assert ops.device_status() == 0
+  # the queue of XCD 0 (blockIdx.y = 0: word 0) claims to be five patches in
+  L.check(L.lib().snnqp_debug_workqueue_poke(0, mark, 0, 5))
+  graph.replay()
+  torch.cuda.synchronize()
+  assert ops.device_status() == L.STATUS_QUEUE_CORRUPT
+  with pytest.raises(L.SnnqpError) as err:
+    launch()
+  assert err.value.code == L.EHIP and "work queue" in str(err.value)
+  assert ops.device_status(reset=True) == L.STATUS_QUEUE_CORRUPT and ops.device_status() == 0
+  graph.replay()                                                       # the slot is clean again
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(_np(s), e["pooled_bits"])
+  np.testing.assert_array_equal(_np(launch()), e["pooled_bits"])
+  assert ops.device_status() == 0
+  del graph
+  ops.workqueue_capture_release(dev, mark, mark + 1)
+
+
+def test_captured_apply_hands_its_slots_back(dev, oracle):
+  """nn.capture of a conv model takes a work-queue slot per conv launch; destroying the
+  CapturedApply gives them back, so a process that re-captures (new weights, new shapes) never
+  runs out: 400 capture / destroy cycles of a three-block model (1200 slots' worth against a pool
+  of 960) and not one captured launch falls to the static walk."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.conv_net_case(T=2, B=1)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+  (want, _) = model.apply(variables, x, trgt=None, train=False, rng=None)
+  before = ops.workqueue_stats()["captured_static_walks"]
+  for i in range(400):
+    step = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
+    if i % 100 == 0:
+      logits, _ = step(x)
+      assert torch.equal(logits, want)
+    del step
+  assert ops.workqueue_stats()["captured_static_walks"] == before
+
+
+def test_table_dequantisation_is_probed_per_device(dev, oracle, monkeypatch):
+  """DQ_TABLE rests on the f8f6f4 MFMA adding float32 denormals exactly; the library probes that
+  once per device before the first table launch (runtime.hip).  Here: the probe has run on this
+  device by now and passed (no arithmetic fallback was counted for conv1's headline weights), and
+  a process in which the probe is made to fail (SNNQP_FORCE_DENORM_PROBE_FAIL) gives the same
+  rasters from the arithmetic form and counts the fallback."""
+  import subprocess, sys, json
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=3, B=2, hw=8)
+  e = cases.conv_block_expected(oracle, c)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert ops.conv_dequant_form(w, _mslif()) == "table"
+  g = ops.ConvGeom(8, 8, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  before = ops.workqueue_stats()["dequant_table_fallbacks"]
+  _, s = ops.conv_lif_forward(ops.pack_bits(_t(c["x"], dev)), g, w, _mslif(), bn=_bn(c["bn"], dev),
+                              want_u=False, packed_out=True, pool=2, impl=L.IMPL_MFMA, x_max=1)
+  np.testing.assert_array_equal(_np(s), e["pooled_bits"])
+  assert ops.workqueue_stats()["dequant_table_fallbacks"] == before
+  code = (
+      "import numpy as np, torch, json, sys\n"
+      "from tests import cases\n"
+      "from tests.test_parity_gpu import _weight, _bn, _mslif, _t, _np\n"
+      "from snnquantprune_amd import _lib as L, ops\n"
+      "dev = torch.device('cuda:0')\n"
+      "c = cases.conv_block_case(T=3, B=2, hw=8)\n"
+      "w = _weight(c['leaf'], c['bits'], dev, transposed=True)\n"
+      "g = ops.ConvGeom(8, 8, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))\n"
+      "_, s = ops.conv_lif_forward(ops.pack_bits(_t(c['x'], dev)), g, w, _mslif(), bn=_bn(c['bn'], dev),"
+      " want_u=False, packed_out=True, pool=2, impl=L.IMPL_MFMA, x_max=1)\n"
+      "print(json.dumps({'bits': _np(s).ravel().tolist(), 'fallbacks': ops.workqueue_stats()['dequant_table_fallbacks']}))\n")
+  env = dict(os.environ, SNNQP_FORCE_DENORM_PROBE_FAIL="1")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0, out.stderr[-2000:]
+  got = json.loads(out.stdout.strip().splitlines()[-1])
+  assert got["fallbacks"] >= 1
+  np.testing.assert_array_equal(np.asarray(got["bits"], np.uint32), e["pooled_bits"].ravel())
