@@ -48,7 +48,9 @@ PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json
 PMC_SUMMARY = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_summary.json",
                                                            "r02_pmc_summary.json")]
 # int-vs-float deviation of the numeric contract (tools/int_vs_float.py, CPU), committed
-PARITY_VS_FLOAT = os.path.join(ROOT, "profiles", "r02_int_vs_float.json")
+PARITY_VS_FLOAT = next((p for p in (os.path.join(ROOT, "profiles", n) for n in
+                                    ("r04_int_vs_float.json", "r02_int_vs_float.json"))
+                        if os.path.exists(p)), os.path.join(ROOT, "profiles", "r02_int_vs_float.json"))
 
 
 def parse(argv=None):
@@ -243,6 +245,46 @@ def fed_leg(args, frames_u8, apply_fn, parallel, fence, dev, steps, warmup):
           "samples_per_s_per_gpu": B * steps / dt, "ms_per_step": dt / steps * 1e3,
           "bytes_per_sample": pf.data[0].numel() * 4, "h2d_GBps": nbytes / dt / 1e9,
           "prefetch_depth": 2, "source": "page-locked host memory, hipMemcpyAsync on a copy stream"}
+
+
+def general_leg(args, model, dev, B, T, parallel, fence, steps, warmup):
+  """The same C3 topology WITHOUT the three specialisations the headline takes: event COUNT
+  frames (Poisson(lam) per pixel and polarity, what examples/input_pipeline.py:195-218 produces)
+  instead of binary ones, a trained-looking BatchNorm (random running statistics, scale and
+  bias: all three instructions of the epilogue) instead of the freshly initialised one, and
+  every batch arriving from page-locked host memory in the nibble-packed wire format (EV4)
+  instead of resident in HBM.  Timed like the headline, with its own per-kernel HIP events."""
+  import numpy as np
+  import torch
+  from snnquantprune_amd import _lib as L_, linen as nn, ops, synthetic as syn
+  vnp = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10, random_bn=True)
+  variables = nn.tree_from_numpy(vnp, dev)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(8627170)
+  x = torch.poisson(torch.full((B, T, 128, 128, 2), float(args.lam), device=dev),
+                    generator=gen).clamp_(max=15).to(torch.uint8)
+  feeder = make_feeder(ops.pack_frames(x, L_.EV4), dev)
+  del x
+
+  def step():
+    ops.forget_inputs()
+    (logits, _) = model.apply(variables, next(feeder)["dvs_matrix"], trgt=None, train=False, rng=None)
+    return parallel.all_gather_rows(logits)
+  for _ in range(max(3, warmup)):          # the count hint settles within two batches
+    step()
+  fence()
+  ops.profile_start()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  fence()
+  dt = time.perf_counter() - t0
+  prof = ops.profile_stop()
+  return {"what": "event-count frames (Poisson(%g), EV4 wire format) fed from host memory, BatchNorm "
+                  "with random running statistics / scale / bias; same topology, bits and pruning" % args.lam,
+          "steps": steps, "ms_per_step": dt / steps * 1e3, "samples_per_s_per_gpu": B * steps / dt,
+          "kernels": {tag: {"launches": n, "avg_ms": ms / max(n, 1)} for tag, (n, ms) in prof.items()},
+          "dequant_form": {t: v.get("dequant") for t, v in ops.PROFILE_NOTES.items()}}
 
 
 def cpu_baseline(args, variables_np):
@@ -593,6 +635,19 @@ def main(argv=None):
     fed["ms_per_step"] = float(tf.item())
     fed["samples_per_s_per_gpu"] = B / (fed["ms_per_step"] * 1e-3)
 
+  # the general case beside the headline's best case (every rank runs it: the step holds a collective)
+  general = None
+  notes_main = dict(ops.PROFILE_NOTES) if ops is not None else {}
+  if (gpu and ops is not None and args.model == "c3" and args.feed == "resident" and not args.no_fed_leg
+      and not args.counts and not args.random_bn and not args.graph and args.input == "ev1"):
+    general = general_leg(args, model, dev, B, T, parallel, fence, args.steps, min(args.warmup, 3))
+    tg = torch.tensor([general["ms_per_step"]], device=dev, dtype=torch.float64)
+    if collective:
+      torch.distributed.all_reduce(tg, op=torch.distributed.ReduceOp.MAX)
+    general["ms_per_step"] = float(tg.item())
+    general["samples_per_s_per_gpu"] = B / (general["ms_per_step"] * 1e-3)
+    general["vs_headline"] = general["samples_per_s_per_gpu"] / (B * args.steps / dt)
+
   if rank != 0:
     return
   value = world * B * args.steps / dt
@@ -659,7 +714,19 @@ def main(argv=None):
     line["resident_u8"] = alt
   if cap_leg is not None:
     line["captured"] = cap_leg
-  line.update(rooflines_of(args, prof, B, T, lb, dict(ops.PROFILE_NOTES) if ops is not None else {}))
+  if general is not None:
+    line["general"] = general
+  if args.model != "dense":
+    # which specialisations this line's `value` took: the `general` leg takes none
+    line["config"]["specialisations"] = {
+        "input": {"ev1": "binary frames, bit-packed (EV1), resident in HBM", "ev4": "count frames <= 15, "
+                  "nibble-packed (EV4)", "u8": "uint8 frames", "f32": "float32 frames"}[args.input]
+                 + (", event counts" if args.counts else ", binary events")
+                 + (", fed from host memory" if args.feed == "host" else ""),
+        "bn_flags": "random statistics: sub, mul, add" if args.random_bn else
+                    "mean 0 / bias 0 (as initialised): the multiply alone",
+        "dequant_form": {t: v.get("dequant") for t, v in notes_main.items()}}
+  line.update(rooflines_of(args, prof, B, T, lb, notes_main))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:
       line["parity_vs_float"] = dict(json.load(f).get("summary") or {},

@@ -307,6 +307,10 @@ int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *rea
  * snnqp_dense_head_forward on that device returns SNNQP_EHIP until the word is reset. */
 #define SNNQP_STATUS_QUEUE_CORRUPT 1u /* a conv launch's patches did not add up */
 #define SNNQP_STATUS_TICKET 2u        /* a split-K dense launch drew a ticket out of range */
+#define SNNQP_STATUS_BOUND 4u         /* snnqp_weight_t.abs_sum_max below a one-sided code sum of its
+                                       * weights (checked once per weights on the device, after the
+                                       * first launch that used them: the conv kernels size their
+                                       * dequantisation tables by it) */
 int snnqp_device_status(int device, uint32_t *codes, int reset);
 /* Launches captured into a graph take a work-queue slot of their own (see the top of this file).
  * mark: the number of capture slots handed out on `device` so far.  release: the slots handed out

@@ -27,7 +27,7 @@ IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA = 0, 1, 2
 FLAG_CODE_OVERFLOW, FLAG_MASK_NOT_BINARY = 1, 2
 FLAG_NOT_INTEGER, FLAG_GT_ONE, FLAG_GT_127, FLAG_GT_15 = 4, 8, 16, 32
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
-STATUS_QUEUE_CORRUPT, STATUS_TICKET = 1, 2
+STATUS_QUEUE_CORRUPT, STATUS_TICKET, STATUS_BOUND = 1, 2, 4
 
 
 class WeightT(Structure):

@@ -122,6 +122,7 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
   // codes that fit fp6, packed as fp6 tiles, over bit-packed rows: the f8f6f4 kernel
   if (impl != SNNQP_IMPL_GENERIC && in_type == SNNQP_BITS && s_type == SNNQP_BITS &&
       w->wtype == SNNQP_W_I8 && w->wt_fp6 && w->code_max > 0 && w->code_max <= 7 && T <= 160 &&
+      (int64_t)7 * K < ((int64_t)1 << 24) &&      // every partial sum an integer float32 holds exactly
       !(nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) && x_stride_t >= 0 && x_stride_b >= 0 &&
       (int64_t)(T > 0 ? T - 1 : 0) * x_stride_t + 160 * x_stride_b + (K + 31) / 32 < ((int64_t)1 << 31))
     return run_dense_fp6(x, x_stride_t, x_stride_b, T, B, K, N, w, bn, nrn, u0, u_out,

@@ -725,9 +725,13 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     const bool bnf = (a.bn.flags & (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO)) ==
                      (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO);
     a.lut_bound = tab ? (int32_t)w->abs_sum_max : 0;
+    if (tab) check_code_bound_once(stream_device(st), (const int8_t *)w->w, (int64_t)9 * g->Cin, g->Cout,
+                                   w->abs_sum_max, st);
     launch_conv3x3_bits(a, i8, nf, pl, dq, fma, bnf, gy, st);
   } else {
     const int lm = lutc ? LUT_CHANNEL : lut ? LUT_SHARED : LUT_NONE;
+    if (lut) check_code_bound_once(stream_device(st), (const int8_t *)w->w, (int64_t)9 * g->Cin, g->Cout,
+                                   w->abs_sum_max, st);
     // LDS decides how many workgroups share a CU (every variant needs < 128 VGPRs: up to four
     // waves per SIMD): stage fewer timesteps per pass rather than lose a workgroup to LDS --
     // four per CU measured 7.1 ms on the headline shape, three 7.8, two 11.2.  Any chunk length

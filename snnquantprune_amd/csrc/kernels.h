@@ -30,6 +30,7 @@ uint32_t *device_status_word(int dev);
 uint32_t device_status_read(int dev);
 const char *device_status_text(uint32_t code);
 bool dq_table_trusted(int dev, hipStream_t st);
+void check_code_bound_once(int dev, const int8_t *w, int64_t K, int32_t N, int32_t bound, hipStream_t st);
 int64_t dq_table_fallbacks(bool reset);
 int stream_device(hipStream_t st);
 

@@ -128,6 +128,26 @@ bool run_denorm_probe() {
 
 DeviceState *state_of(int dev) { return dev >= 0 && dev < 64 ? &g_rt[dev] : nullptr; }
 
+// one thread per output column: the two one-sided code sums against the caller's bound
+__global__ void __launch_bounds__(256)
+check_code_bound_kernel(const int8_t *__restrict__ w, int64_t K, int32_t N, int32_t bound,
+                        uint32_t *status) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int64_t pos = 0, neg = 0;
+  for (int64_t k = 0; k < K; ++k) {
+    const int c = w[k * N + n];
+    pos += c > 0 ? c : 0;
+    neg += c < 0 ? -c : 0;
+  }
+  if ((pos > bound || neg > bound) && status) *(volatile uint32_t *)status = SNNQP_STATUS_BOUND;
+}
+
+// (codes pointer, K, N, bound) tuples already checked on a device: a small ring
+struct Checked { const void *w; int64_t K; int32_t N, bound; };
+Checked g_checked[64][32];
+unsigned g_checked_next[64];
+
 }  // namespace
 
 // Device pointer of the status word of `dev` (made on first use), or nullptr: the kernels then
@@ -170,6 +190,10 @@ const char *device_status_text(uint32_t code) {
     return "a conv launch finished with a patch count that does not match its work queue (a queue "
            "word was not zero when the launch began: an aborted launch or a graph replayed "
            "concurrently with itself): spike rasters since then may be wrong";
+  if (code & SNNQP_STATUS_BOUND)
+    return "snnqp_weight_t.abs_sum_max is smaller than a one-sided code sum of the weights it came "
+           "with: the dequantisation tables of the conv kernels were read outside their range, "
+           "spike rasters of that layer are wrong";
   if (code & SNNQP_STATUS_TICKET)
     return "a split-K dense launch drew a ticket outside its range (its counters were not zero "
            "when the launch began): spike rasters since then may be wrong";
@@ -203,6 +227,31 @@ bool dq_table_trusted(int dev, hipStream_t st) {
   s->denorm = ok ? 1 : -1;
   if (!ok) g_dq_fallbacks.fetch_add(1, std::memory_order_relaxed);
   return ok;
+}
+
+// The LDS tables of the conv kernels are sized by the caller's snnqp_weight_t.abs_sum_max, and
+// the accumulator addresses them as it is: a bound that is too small reads outside the table.
+// The first launch that sees a (codes, shape, bound) tuple on a device also launches a check of
+// the bound against the codes (one thread per output channel, a few microseconds); a violation
+// goes to the status word, i.e. the NEXT call fails.  The tuple is remembered (a ring of 32 per
+// device): codes rewritten in place under an unchanged bound are not checked again.
+void check_code_bound_once(int dev, const int8_t *w, int64_t K, int32_t N, int32_t bound, hipStream_t st) {
+  if (dev < 0 || dev >= 64 || !w || bound <= 0) return;
+  {
+    std::lock_guard<std::mutex> lock(g_rt_mu);
+    for (const Checked &c : g_checked[dev])
+      if (c.w == w && c.K == K && c.N == N && c.bound == bound) return;
+  }
+  uint32_t *status = device_status_word(dev);
+  if (!status) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (cap != hipStreamCaptureStatusNone) return;      // not into a graph: the next eager launch checks
+  hipLaunchKernelGGL(check_code_bound_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, w, K, N,
+                     bound, status);
+  if (hipGetLastError() != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_rt_mu);
+  g_checked[dev][g_checked_next[dev]++ % 32] = Checked{w, K, N, bound};
 }
 
 int64_t dq_table_fallbacks(bool reset) {

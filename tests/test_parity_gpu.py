@@ -2782,3 +2782,89 @@ def test_table_dequantisation_is_probed_per_device(dev, oracle, monkeypatch):
   got = json.loads(out.stdout.strip().splitlines()[-1])
   assert got["fallbacks"] >= 1
   np.testing.assert_array_equal(np.asarray(got["bits"], np.uint32), e["pooled_bits"].ravel())
+
+
+def test_an_abs_sum_max_below_the_codes_is_reported(dev, oracle):
+  """snnqp_weight_t.abs_sum_max sizes the LDS tables the conv kernels dequantise through, and the
+  accumulator addresses them as it is: a caller that understates it gets wrong currents.  The
+  library checks the bound against the codes once per weights (a column-sum pass after the first
+  launch that used them) and reports a violation through the device status word."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=2, B=2, hw=8)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  g = ops.ConvGeom(8, 8, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+  assert ops.device_status() == 0
+  ops.conv_lif_forward(xin, g, w, _mslif(), bn=_bn(c["bn"], dev), want_u=False, packed_out=True,
+                       impl=L.IMPL_MFMA, x_max=1)
+  torch.cuda.synchronize()
+  assert ops.device_status() == 0                       # the honest bound passes
+  bad = dataclasses.replace(w, abs_sum_max=max(1, w.abs_sum_max // 4))
+  ops.conv_lif_forward(xin, g, bad, _mslif(), bn=_bn(c["bn"], dev), want_u=False, packed_out=True,
+                       impl=L.IMPL_MFMA, x_max=1)
+  torch.cuda.synchronize()
+  assert ops.device_status() == L.STATUS_BOUND
+  with pytest.raises(L.SnnqpError) as err:
+    ops.conv_lif_forward(xin, g, w, _mslif(), bn=_bn(c["bn"], dev), want_u=False, packed_out=True,
+                         impl=L.IMPL_MFMA, x_max=1)
+  assert "abs_sum_max" in str(err.value)
+  assert ops.device_status(reset=True) == L.STATUS_BOUND
+
+
+def test_hip_against_the_reference_literal_float_arithmetic(dev, oracle):
+  """BASELINE.json: "bit-exact for spike rasters and integer accumulators, within 1e-5 relative
+  for float membrane potentials" -- against the reference's own float32 arithmetic, which the
+  oracle restates as its `float` mode (float32 fake-quantised weights x float32 spikes summed in
+  float32, BLAS order standing in for XLA's: flax_qconv.py:158-168, flax_qdense.py:87-89), not
+  the `int` mode the kernels are bit-exact against.  Config C3's layers at their own geometry
+  (128 x 128 x 2, T = 20, 4-bit, 90 % pruned), B = 16, each layer on the same input raster:
+  the HIP rasters may differ from the float-mode rasters only where a potential sat within
+  rounding of the threshold (asserted: fewer than one spike in a million), and the final
+  membrane potentials of all neurons whose rasters agree differ by at most 1e-5 relative to
+  max(|u|, v_th) (asserted; the measured figure is ~5e-7)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops, synthetic as syn
+  B, T = 16, 20
+  v = syn.conv_net_variables(prune_p=0.9, out=110)
+  p = v["params"]
+  x = np.swapaxes(syn.poisson_spikes((B, T, 128, 128, 2), 0.1, seed=4711), 0, 1)   # [T, B, ...]
+  nrn = _mslif()
+  report = {}
+  cur = x
+  for i, hw in enumerate((128, 64, 32)):
+    leaf = p["QuantConv_%d" % i]
+    qw = qweight_of(oracle, leaf, 4)
+    bn = bn_of(v, i)
+    uf, sf = oracle.conv_block(cur, qw, bn, None, "float")
+    w = _weight(leaf, 4, dev, transposed=True)
+    g = ops.ConvGeom(hw, hw, cur.shape[-1], 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+    xin = _t(cur.astype(np.uint8), dev) if i == 0 else ops.pack_bits(_t(cur.astype(np.uint8), dev))
+    u, s = ops.conv_lif_forward(xin, g, w, nrn, bn=_bn(bn, dev), want_u=True, packed_out=True, pool=1,
+                                impl=L.IMPL_MFMA, x_max=1)
+    sh = _np(s.to_dense()).astype(np.uint8)
+    report["conv%d" % i] = _float_deviation(_np(u), uf, sh, sf.astype(np.uint8))
+    cur = oracle.max_pool_2x2(sh.astype(F32))            # the HIP raster feeds the next layer
+  xf = oracle.flatten_channel_major(cur)
+  qd = qweight_of(oracle, p["QuantDense_0"], 4)
+  uf, sf = oracle.dense_block(xf, qd, None, "float")
+  wd = _weight(p["QuantDense_0"], 4, dev, transposed=True)
+  u, s = ops.dense_lif_forward(ops.pack_bits(_t(xf.astype(np.uint8), dev)), wd, xf.shape[-1], 110, nrn,
+                               want_u=True, packed_out=True, impl=L.IMPL_MFMA)
+  report["readout"] = _float_deviation(_np(u), uf, _np(s.to_dense()).astype(np.uint8), sf.astype(np.uint8))
+  print("HIP vs reference-literal float arithmetic:", report)
+  for name, r in report.items():
+    assert r["flip_rate"] < 1e-6, (name, r)
+    assert r["max_rel_to_max_u_vth"] <= 1e-5, (name, r)
+
+
+def _float_deviation(u_hip, u_flt, s_hip, s_flt):
+  flips = int((s_hip != s_flt).sum())
+  same = np.all(s_hip == s_flt, axis=0)
+  a, b = u_hip[same].astype(np.float64), u_flt[same].astype(np.float64)
+  d = np.abs(a - b)
+  scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1.0)        # v_th = 1
+  return {"neuron_steps": int(s_hip.size), "flips": flips, "flip_rate": flips / max(s_hip.size, 1),
+          "max_abs_u": float(d.max()) if d.size else 0.0,
+          "max_rel_to_max_u_vth": float((d / scale).max()) if d.size else 0.0}
