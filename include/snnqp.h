@@ -166,7 +166,7 @@ typedef struct {
  * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
  * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
  * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward, snnqp_device_status,
- * snnqp_workqueue_*).  A binding compares snnqp_version() with the SNNQP_VERSION it was
+ * snnqp_workqueue_*, snnqp_dense_lif_forward_ws).  A binding compares snnqp_version() with the SNNQP_VERSION it was
  * written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 400
 int snnqp_version(void);
@@ -365,6 +365,24 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             const snnqp_neuron_t *nrn, const float *u0,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream);
+
+/* The same with a workspace: the fp4 x fp6 kernel then may split K over several workgroups per
+ * tile of rows (the read-out of config C3: 32768 -> 110 gives 256 workgroups of 80 rows too few
+ * rows to amortise the 3 MB of codes each of them streams; two workgroups of 160 rows per tile
+ * stream half each), handing partial sums over through `ws`.  ws: device memory, 256-byte
+ * aligned, at least snnqp_dense_workspace_bytes(...) bytes, ZERO when first used and used by one
+ * launch at a time (the kernel leaves it reusable: its tickets are zero again at the end of a
+ * launch).  ws = NULL or too small: no split, as snnqp_dense_lif_forward.
+ * snnqp_dense_workspace_bytes returns 0 when the split would not be used. */
+int64_t snnqp_dense_workspace_bytes(int in_type, int32_t T, int32_t B, int32_t K, int32_t N,
+                                    const snnqp_weight_t *w);
+int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
+                               int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
+                               int32_t N, const snnqp_weight_t *w,
+                               const int8_t *wt, const snnqp_bn_t *bn,
+                               const snnqp_neuron_t *nrn, const float *u0,
+                               float *u_out, void *s_out, int s_type, int impl,
+                               void *ws, int64_t ws_bytes, snnqp_stream_t stream);
 
 /* ---- the dense head as one launch -----------------------------------------------
  * replaces: the two dense SpikingBlocks and the vote that end CextNet,

@@ -87,6 +87,11 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
         c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "snnqp_dense_workspace_bytes": (c_int64, [c_int, c_int32, c_int32, c_int32, c_int32, POINTER(WeightT)]),
+    "snnqp_dense_lif_forward_ws": (c_int, [
+        c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
+        POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
+        c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "snnqp_dense_head_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(WeightT),
         c_void_p, POINTER(NeuronT), c_int32, POINTER(WeightT), c_void_p, POINTER(NeuronT), c_int32,

@@ -104,6 +104,14 @@ int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bou
   return run_current_min(w, bn, bound, Cout, out_bits, (hipStream_t)stream);
 }
 
+int64_t snnqp_dense_workspace_bytes(int in_type, int32_t T, int32_t B, int32_t K, int32_t N,
+                                    const snnqp_weight_t *w) {
+  if (!w || in_type != SNNQP_BITS || w->wtype != SNNQP_W_I8 || !w->wt_fp6 || w->code_max <= 0 ||
+      w->code_max > 7 || K <= 0 || N <= 0)
+    return 0;
+  return dense_fp6_workspace_bytes(T, B, K, N);
+}
+
 int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                             int32_t N, const snnqp_weight_t *w,
@@ -111,6 +119,17 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             const snnqp_neuron_t *nrn, const float *u0,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream) {
+  return snnqp_dense_lif_forward_ws(x, in_type, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn, u0,
+                                    u_out, s_out, s_type, impl, nullptr, 0, stream);
+}
+
+int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
+                               int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
+                               int32_t N, const snnqp_weight_t *w,
+                               const int8_t *wt, const snnqp_bn_t *bn,
+                               const snnqp_neuron_t *nrn, const float *u0,
+                               float *u_out, void *s_out, int s_type, int impl,
+                               void *ws, int64_t ws_bytes, snnqp_stream_t stream) {
   SNNQP_REQUIRE(w && nrn, SNNQP_EINVAL, "dense_lif_forward: null descriptor");
   if (int rc = refuse_after_device_report((hipStream_t)stream, "dense_lif_forward")) return rc;
   SNNQP_REQUIRE(K > 0 && N > 0, SNNQP_EINVAL, "dense_lif_forward: bad K/N");
@@ -126,7 +145,7 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
       !(nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) && x_stride_t >= 0 && x_stride_b >= 0 &&
       (int64_t)(T > 0 ? T - 1 : 0) * x_stride_t + 160 * x_stride_b + (K + 31) / 32 < ((int64_t)1 << 31))
     return run_dense_fp6(x, x_stride_t, x_stride_b, T, B, K, N, w, bn, nrn, u0, u_out,
-                         (uint32_t *)s_out, 0, (hipStream_t)stream);
+                         (uint32_t *)s_out, 0, ws, ws_bytes, (hipStream_t)stream);
   // more than 128 features: a workgroup per 256 / 512-column block, every row read once
   if (impl != SNNQP_IMPL_GENERIC &&
       !dense_wide_unsupported(in_type, T, K, N, x_stride_t, x_stride_b, x, w, wt, nrn, s_type))

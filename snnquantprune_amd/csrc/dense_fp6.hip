@@ -53,6 +53,11 @@ struct DenseFp6Args {
   const float *u0;
   float *u_out;
   uint32_t *s_out;
+  // K split over workgroups (blockIdx.z): partial tiles and tickets in a caller-owned workspace
+  int32_t ksplit, gcz;           // workgroups per tile; group-chunks of one of them
+  uint32_t *tickets;             // [tiles] zero between launches (the last arriver resets its own)
+  float *slabs;                  // [tiles][ksplit][ROWS * 128]
+  uint32_t *status;              // the device's status word (runtime.hip), or null
 };
 
 __device__ __forceinline__ void lds_barrier6() {
@@ -149,7 +154,10 @@ dense_fp6_kernel(DenseFp6Args a) {
   const int nb = blockIdx.y * 4 + wave;           // 32-column block of this wave
   const bool wave_on = nb * 32 < a.N;
   const int nchunks = (a.KS + F6_KSC - 1) / F6_KSC;   // chunk j of this group = 2 j + grp
-  const int ngc = (nchunks + F6_KGROUPS - 1) / F6_KGROUPS;     // chunks per group
+  const int ngc_all = (nchunks + F6_KGROUPS - 1) / F6_KGROUPS;  // chunks per group over all of K
+  // K split over workgroups: this one walks the group-chunks [gc0, gc0 + ngc)
+  const int gc0 = a.ksplit > 1 ? (int)blockIdx.z * a.gcz : 0;
+  const int ngc = a.ksplit > 1 ? max(0, min(a.gcz, ngc_all - gc0)) : ngc_all;
   // Every workgroup streams the same code tiles.  Walking K in the same order, all of them ask
   // for the same lines at the same time; the sums are exact integers, so the walk may start
   // anywhere: step `lc` of the loop is chunk (lc + rot) mod ngc, with one `rot` per XCD
@@ -161,7 +169,7 @@ dense_fp6_kernel(DenseFp6Args a) {
   const int rot = (int)(((blockIdx.x & 7u) * (unsigned)ngc) >> 3);
   auto phys = [&](int lc) -> int {     // loop step -> this group's chunk; steps beyond ngc: a dead chunk
     const int pc = lc + rot >= ngc ? lc + rot - ngc : lc + rot;
-    return lc < ngc ? pc : nchunks;
+    return lc < ngc ? gc0 + pc : nchunks;
   };
 
   // table: byte -> 8 nibbles (bit i set -> 1.0 = 0x2 in nibble i), 32 copies: entry e of copy c
@@ -342,6 +350,46 @@ dense_fp6_kernel(DenseFp6Args a) {
     lds_barrier6();
   }
 
+  // K split over workgroups: every workgroup of a tile leaves its partial tile (exact integers
+  // in float32) in its slab and draws a ticket; the one that draws the last adds the others'
+  // slabs to its own tile and goes on to the neuron, the others are done.  One agent-scope
+  // release before the ticket, one acquire after it (cdna_hip_programming.md, in-launch split-K).
+  if (a.ksplit > 1) {
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float *mine = a.slabs + ((int64_t)tile * a.ksplit + blockIdx.z) * (ROWS * 128);
+    for (int i = threadIdx.x * 4; i < ROWS * 128; i += 256 * F6_KGROUPS * 4)
+      *(float4 *)(mine + i) = *(const float4 *)(et + i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t *flag = (uint32_t *)lds;               // (the byte -> nibble table is no longer needed)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket >= (uint32_t)a.ksplit && a.status) *(volatile uint32_t *)a.status = SNNQP_STATUS_TICKET;
+      const bool last = ticket + 1u == (uint32_t)a.ksplit;
+      if (last) {
+        __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    for (int z = 0; z < a.ksplit; ++z) {
+      if (z == (int)blockIdx.z) continue;
+      const float *other = a.slabs + ((int64_t)tile * a.ksplit + z) * (ROWS * 128);
+      for (int i = threadIdx.x * 4; i < ROWS * 128; i += 256 * F6_KGROUPS * 4) {
+        const float4 o = *(const float4 *)(other + i);
+        float4 m = *(const float4 *)(et + i);
+        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+        *(float4 *)(et + i) = m;
+      }
+    }
+    __syncthreads();
+  }
+
   const int CW = (a.N + 31) >> 5;
   for (int p = threadIdx.x; p < a.SB * 128; p += 256 * F6_KGROUPS) {
     const int bl = p >> 7, col = p & 127;
@@ -374,39 +422,72 @@ dense_fp6_kernel(DenseFp6Args a) {
 
 template <int RT>
 static void launch_dense_fp6(const DenseFp6Args &a, unsigned gx, unsigned gy, hipStream_t st) {
-  hipLaunchKernelGGL((dense_fp6_kernel<RT>), dim3(gx, gy), dim3(256 * F6_KGROUPS), 0, st, a);
+  hipLaunchKernelGGL((dense_fp6_kernel<RT>), dim3(gx, gy, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)),
+                     dim3(256 * F6_KGROUPS), 0, st, a);
 }
 
-// Rows of a workgroup.  A workgroup streams the whole code matrix through its CU's vector L1
-// (64 B / clk), which is what bounds this kernel: 48 KiB per pair of chunks against 4 RT x 2
-// MFMAs of 32 cycles per SIMD.  More row tiles amortise that stream, but only while the grid
-// still covers the chip: the cost of a choice is (rounds of workgroups over the 256 CUs) x RT,
-// ties go to the larger tile.  (Measured on the read-out, B = 1024, T = 20: RT 2 / 3 / 4 / 5 =
-// 0.109 / 0.071 / 0.089 / 0.098 ms.)
-static int pick_row_tiles(int T, int B, unsigned gy) {
-  int best = 0;
-  int64_t best_cost = 0;
-  for (int rt = 1; rt <= 5; ++rt) {
-    const int sb = rt * 32 / T;
-    if (sb < 1) continue;
-    const int64_t wgs = (int64_t)((B + sb - 1) / sb) * gy;
-    const int64_t cost = ((wgs + 255) / 256) * rt;
-    if (best == 0 || cost <= best_cost) { best = rt; best_cost = cost; }
+// Rows of a workgroup and workgroups per tile along K.  A workgroup streams the code matrix of
+// its K range through its CU's vector L1, which is what bounds this kernel: more row tiles
+// amortise that stream, but only while the grid still covers the chip; a split of K over `ks`
+// workgroups per tile (partial tiles and tickets in a caller workspace, the last arriver of a
+// tile runs the neuron) fills the chip when the batch alone does not.  The model behind the
+// choice, in microseconds at K = 32768, fitted to the read-out (T = 20): a launch takes (rounds of
+// workgroups over the 256 CUs) x (11 + (9.5 + 15.5 RT) / ks) -- B = 1024 unsplit: RT 3 / 5 =
+// 0.067 / 0.098 ms -- plus, when split, the hand-over 6 + 0.09 per KB of slab moved (RT x 16 KB out,
+// (ks - 1) x that in; an agent-scope release / acquire pair, which on this part writes back /
+// invalidates an L2): B = 64 as RT 1, ks 4 takes 0.029 ms against 0.043 unsplit; B = 1024 as
+// RT 5, ks 2 takes 0.075 against 0.066, so the headline stays unsplit.
+// workspace = F6_TICKET_BYTES of tickets (a fixed head, whatever the plan: a workspace that
+// served another shape before still has zeros there), then the slabs
+constexpr int64_t F6_TICKET_BYTES = 4096;
+struct Fp6Plan { int rt, ks; };
+static Fp6Plan pick_fp6_plan(int T, int B, int K, unsigned gy, bool may_split) {
+  const int nchunks = ((K + 63) / 64 + F6_KSC - 1) / F6_KSC;
+  Fp6Plan best = {0, 1};
+  double best_cost = 0;
+  for (int ks = 1; ks <= (may_split ? 4 : 1); ks *= 2) {
+    if (ks > 1 && (K < 8192 || nchunks < 8 * ks)) break;
+    for (int rt = 1; rt <= 5; ++rt) {
+      const int sb = rt * 32 / T;
+      if (sb < 1) continue;
+      const int64_t wgs = (int64_t)((B + sb - 1) / sb) * gy * ks;
+      if (ks > 1 && wgs / ks > F6_TICKET_BYTES / 4) continue;      // a ticket per tile
+      const double kscale = (double)K / 32768.0;
+      const double cost = (double)((wgs + 255) / 256) * (11.0 + kscale * (9.5 + 15.5 * rt) / ks) +
+                          (ks > 1 ? 6.0 + 0.09 * (rt * 16 * ks) : 0.0);
+      if (best.rt == 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && ks == best.ks)) {
+        best = Fp6Plan{rt, ks};
+        best_cost = cost;
+      }
+    }
   }
   return best;
+}
+
+static int64_t fp6_workspace_bytes(const Fp6Plan &p, int T, int B, unsigned gy) {
+  if (p.ks <= 1) return 0;
+  const int sb = p.rt * 32 / T;
+  const int64_t tiles = (int64_t)((B + sb - 1) / sb) * gy;
+  return F6_TICKET_BYTES + tiles * p.ks * (int64_t)(p.rt * 32 * 128) * 4;
+}
+
+int64_t dense_fp6_workspace_bytes(int32_t T, int32_t B, int32_t K, int32_t N) {
+  if (T <= 0 || B <= 0 || T > 160) return 0;
+  const unsigned gy = (unsigned)((N + 127) / 128);
+  return fp6_workspace_bytes(pick_fp6_plan(T, B, K, gy, true), T, B, gy);
 }
 
 int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B, int32_t K,
                   int32_t N, const snnqp_weight_t *w, const snnqp_bn_t *bn,
                   const snnqp_neuron_t *nrn, const float *u0, float *u_out, uint32_t *s_out,
-                  int row_tiles, hipStream_t st) {
+                  int row_tiles, void *ws, int64_t ws_bytes, hipStream_t st) {
   SNNQP_REQUIRE(x && s_out && w->wt_fp6, SNNQP_EINVAL, "dense fp6: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense fp6: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   SNNQP_CHECK_BN(bn);
   if (T == 0 || B == 0) return SNNQP_OK;
   SNNQP_REQUIRE(T <= 160, SNNQP_EUNSUPPORTED, "dense fp6: T > 160");
-  DenseFp6Args a;
+  DenseFp6Args a = {};
   a.x = (const uint32_t *)x; a.xs_t = xs_t; a.xs_b = xs_b;
   a.T = T; a.B = B; a.K = K; a.N = N; a.KW = (K + 31) / 32; a.KS = (K + 63) / 64;
   a.wt6 = (const uint8_t *)w->wt_fp6;
@@ -414,10 +495,27 @@ int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t 
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out;
   const unsigned gy = (unsigned)((N + 127) / 128);
-  int rt = row_tiles >= 1 && row_tiles <= 5 && row_tiles * 32 >= T ? row_tiles : pick_row_tiles(T, B, gy);
+  // the workspace decides: the plan with a K split when the caller brought enough of it
+  // (snnqp_dense_workspace_bytes, zero-filled once), else the best plan without
+  Fp6Plan plan = pick_fp6_plan(T, B, K, gy, ws != nullptr);
+  if (plan.ks > 1 && (fp6_workspace_bytes(plan, T, B, gy) > ws_bytes || ((uintptr_t)ws & 255) != 0))
+    plan = pick_fp6_plan(T, B, K, gy, false);
+  if (row_tiles >= 1 && row_tiles <= 5 && row_tiles * 32 >= T) plan = Fp6Plan{row_tiles, 1};
+  const int rt = plan.rt;
   SNNQP_REQUIRE(rt > 0, SNNQP_EUNSUPPORTED, "dense fp6: T too large");
   a.SB = rt * 32 / T;
   const unsigned gx = (unsigned)((B + a.SB - 1) / a.SB);
+  a.ksplit = plan.ks;
+  if (plan.ks > 1) {
+    const int nchunks = (a.KS + F6_KSC - 1) / F6_KSC;
+    const int ngc_all = (nchunks + F6_KGROUPS - 1) / F6_KGROUPS;
+    a.gcz = (ngc_all + plan.ks - 1) / plan.ks;
+    const int64_t tiles = (int64_t)gx * gy;
+    a.tickets = (uint32_t *)ws;
+    a.slabs = (float *)((uint8_t *)ws + F6_TICKET_BYTES);
+    (void)tiles;
+    a.status = device_status_word(stream_device(st));
+  }
   switch (rt) {
     case 5: launch_dense_fp6<5>(a, gx, gy, st); break;
     case 4: launch_dense_fp6<4>(a, gx, gy, st); break;

@@ -59,9 +59,11 @@ int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
                    float *u_out, uint32_t *s_out, hipStream_t st);
 
 // codes of magnitude <= 7 on the f8f6f4 MFMA (dense_fp6.hip); row_tiles 0 = choose
+// (ws / ws_bytes: optional workspace for a K split over workgroups, dense_fp6_workspace_bytes)
 int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B, int32_t K,
                   int32_t N, const snnqp_weight_t *w, const snnqp_bn_t *bn,
                   const snnqp_neuron_t *nrn, const float *u0, float *u_out, uint32_t *s_out,
-                  int row_tiles, hipStream_t st);
+                  int row_tiles, void *ws, int64_t ws_bytes, hipStream_t st);
+int64_t dense_fp6_workspace_bytes(int32_t T, int32_t B, int32_t K, int32_t N);
 
 }  // namespace snnqp

@@ -760,12 +760,33 @@ def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
     s = torch.empty((T, B, N), dtype=torch.float32, device=dev)
   w, n = weight.struct(), neuron.struct()
   b = bn.struct() if bn is not None else None
+  # a long contraction over few rows (the read-out) splits K over workgroups through a workspace
+  ws = _dense_workspace(dev, int(L.lib().snnqp_dense_workspace_bytes(in_type, T, B, K, N, ctypes.byref(w)))) \
+      if (packed_out and impl != L.IMPL_GENERIC) else None
   with _timed("dense[%d->%d]" % (K, N)):
-    L.check(L.lib().snnqp_dense_lif_forward(
+    L.check(L.lib().snnqp_dense_lif_forward_ws(
         _ptr(xt), in_type, xs_t, xs_b, T, B, K, N, ctypes.byref(w), _ptr(weight.wt),
         ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0),
-        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl, _stream()))
+        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl,
+        _ptr(ws), 0 if ws is None else ws.numel(), _stream()))
   return u_out, (PackedSpikes(s, N) if packed_out else s)
+
+
+_dense_ws = {}
+
+
+def _dense_workspace(dev, nbytes: int):
+  """The zero-filled workspace of the split-K dense kernel on `dev` and the current stream
+  (snnqp.h: one launch at a time; launches of one stream are), grown as needed, or None."""
+  if nbytes <= 0:
+    return None
+  key = (torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream)
+  ws = _dense_ws.get(key)
+  if ws is None or ws.numel() < nbytes:
+    if torch.cuda.is_current_stream_capturing():
+      return None                       # nothing may be allocated inside a capture: no split
+    ws = _dense_ws[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+  return ws
 
 
 def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight, N2: int,

@@ -2868,3 +2868,33 @@ def _float_deviation(u_hip, u_flt, s_hip, s_flt):
   return {"neuron_steps": int(s_hip.size), "flips": flips, "flip_rate": flips / max(s_hip.size, 1),
           "max_abs_u": float(d.max()) if d.size else 0.0,
           "max_rel_to_max_u_vth": float((d / scale).max()) if d.size else 0.0}
+
+
+@pytest.mark.parametrize("shape", [(20, 64, 32768, 110), (20, 100, 32768, 110), (7, 20, 32768, 200),
+                                   (33, 9, 40000, 70)],
+                         ids=["readout_small_batch", "readout_100", "two_col_blocks", "ragged_k"])
+def test_dense_fp6_splits_k_over_workgroups(dev, oracle, shape):
+  """The fp4 x fp6 dense kernel with a workspace: long contractions over too few rows to fill the
+  chip (the read-out of config C3 at small batches) split K over two or four workgroups per tile,
+  partial tiles and tickets in the workspace, the last arriver runs the neuron.  Rasters and potentials equal the oracle's and the
+  unsplit launch's, twice in a row (the tickets are zero again after a launch), with a carried-in
+  state."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  import ctypes
+  T, B, K, N = shape
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N, bits=4, p=0.9)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert w.wt6 is not None and 0 < w.code_max <= 7
+  ws_bytes = int(L.lib().snnqp_dense_workspace_bytes(L.BITS, T, B, K, N, ctypes.byref(w.struct())))
+  assert ws_bytes > 0, "this shape is meant to split"
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  xin = ops.pack_bits(_t(c["x"], dev))
+  u0 = _t(c["u0"], dev)
+  eu, es = oracle.dense_block(c["x"], qw, None, "int", u0=c["u0"])
+  assert ops.device_status() == 0
+  for rep in range(2):
+    u, s = ops.dense_lif_forward(xin, w, K, N, _mslif(), u0=u0, packed_out=True, impl=L.IMPL_AUTO)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="rep %d" % rep)
+    np.testing.assert_array_equal(_np(u), eu, err_msg="rep %d" % rep)
+  assert ops.device_status() == 0
