@@ -604,11 +604,10 @@ def main(argv=None):
   # process only: a capture that failed on some rank of a multi-GPU job would take the whole
   # line with it, and the figure is a per-GPU one anyway (--graph runs it on every rank).
   cap_leg = None
-  # Only what can be captured: integer frames into the C3 / dense models (float32 frames and
-  # CextNet's real-valued activations are inspected on the host -- a read-back no capture allows).
+  # Only what can be captured: integer frames (float32 frames are inspected on the host before they
+  # are narrowed -- a read-back no capture allows).
   if (gpu and ops is not None and not args.stand_in and not args.graph and args.feed == "resident"
-      and not args.no_fed_leg and world == 1 and args.model in ("c3", "dense")
-      and args.input in ("u8", "ev1", "ev4")):
+      and not args.no_fed_leg and world == 1 and args.input in ("u8", "ev1", "ev4")):
     captured = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
     for _ in range(2):
       parallel.all_gather_rows(captured()[0])

@@ -247,12 +247,12 @@ class CextNet(nn.Module):
           pool=pool, return_state=False, batch_major_input=first, packed=packed)
       return layer(None, x)[1]
 
-    def dense_block(x, features):
+    def dense_block(x, features, packed=None):
       layer = SpikingBlock(
           connection_fn=QuantDense(features, use_bias=False, dtype=self.dtype,
                                    config=cfg.quant, bits=cfg.quant.bits,
                                    g_scale=cfg.quant.g_scale),
-          neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype), return_state=False)
+          neural_dynamics=cfg.neuron_dynamics(dtype=self.dtype), return_state=False, packed=packed)
       return layer(None, x)[1]
 
     x = _as_input(inputs)
@@ -280,7 +280,9 @@ class CextNet(nn.Module):
     if probe:
       _sow_density(self, "dense1_inpt", x)
     with packing.integer_inputs(False):
-      x = dense_block(x, cfg.channels * 2 * 2)          # models.py:200-216
+      # real-valued inputs, but what comes out are spikes: bit-packed, so that dense2 runs on the
+      # integer kernels without anybody having to look at the values first
+      x = dense_block(x, cfg.channels * 2 * 2, packed=True)          # models.py:200-216
     self.sow("intermediates", "dense1_out", x)
     if probe:
       _sow_density(self, "dense1_out", x)

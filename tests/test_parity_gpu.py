@@ -2898,3 +2898,35 @@ def test_dense_fp6_splits_k_over_workgroups(dev, oracle, shape):
     np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="rep %d" % rep)
     np.testing.assert_array_equal(_np(u), eu, err_msg="rep %d" % rep)
   assert ops.device_status() == 0
+
+
+def test_cextnet_steps_without_a_host_synchronisation_and_captures(dev, oracle, golden_dir, monkeypatch):
+  """The reference's full TCJA model (examples/tcja/models.py:31-257) on integer frames: a step
+  never waits for the device (Tensor.item / tolist and the inspection helpers raise during it:
+  dense1 hands its spikes on bit-packed, so nothing downstream has to look at float values), and
+  nn.capture records it -- the replay gives the golden logits."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.cextnet_case()
+  g = _golden(golden_dir, "cextnet_tiny")
+  model = models.CextNet(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+  (logits, _) = model.apply(variables, x, trgt=None, train=False, rng=None)       # packs the weights
+  np.testing.assert_array_equal(_np(logits), g["logits"])
+
+  def boom(*a, **k):
+    raise AssertionError("host synchronisation inside a CextNet step")
+  with monkeypatch.context() as m:
+    m.setattr(torch.Tensor, "item", boom)
+    m.setattr(torch.Tensor, "tolist", boom)
+    m.setattr(ops, "inspect_f32", boom)
+    m.setattr(ops, "narrow_f32", boom)
+    m.setattr(ops, "input_max_bound", boom)
+    ops.forget_inputs()
+    (l2, _) = model.apply(variables, torch.roll(x, 1, 0), trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(l2), np.roll(g["logits"], 1, 0))
+  step = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
+  np.testing.assert_array_equal(_np(step(x)[0]), g["logits"])
+  np.testing.assert_array_equal(_np(step(torch.roll(x, 1, 0))[0]), np.roll(g["logits"], 1, 0))
+  del step
