@@ -570,6 +570,19 @@ def main(argv=None):
       xr = (torch.rand((B, T, hw, hw, 2), device=dev, generator=g) < p_spike).to(torch.uint8)
       assert torch.equal(out[r * B:(r + 1) * B], apply_fn(xr)), "gathered rows of rank %d" % r
 
+  # every rank's own account of the timed region: seconds, per-layer launch times (HIP events on
+  # its own stream) and fallback counters -- a straggler or a rank that fell off the fast kernels
+  # shows in rank 0's line, not only in the maximum
+  mine = {"rank": rank, "seconds": dt,
+          "kernels": {tag: round(ms / max(n, 1), 5) for tag, (n, ms) in (prof or {}).items()}}
+  if ops is not None:
+    mine["fallbacks"] = dict(ops.fallback_counts(), **ops.workqueue_stats())
+    mine["device_status"] = ops.device_status(dev)
+  if collective:
+    rank_detail = [None] * world
+    torch.distributed.all_gather_object(rank_detail, mine)
+  else:
+    rank_detail = [mine]
   tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
   rank_dt = [dt]
   if collective:
@@ -685,6 +698,7 @@ def main(argv=None):
   line["ranks_seen"] = len({(i.get("pci"), i.get("device"), i["rank"]) for i in ids})
   line["ranks"] = [{k: i.get(k) for k in ("rank", "device", "pci", "rccl", "pid") if k in i} for i in ids]
   line["rank_seconds"] = rank_dt
+  line["rank_detail"] = rank_detail
   line["collective"] = ("%s process group of %d rank(s): all-gather of the logits every step, "
                         "barrier + all-reduce(MAX) around the timed region" % (args.backend, world)
                         ) if collective else "none (one process, no process group)"

@@ -230,12 +230,17 @@ def fused_dense_head(block1, block2, inputs, group: int = 10, want_s1: bool = Fa
   if w1 is None or w2 is None or w1.wt is None or w2.wt is None or w1.col_sum is None:
     return None
   try:
-    return ops.dense_head_forward(x, w1, K, N1, nrn1, w2, N2, nrn2, group=group, want_s1=want_s1,
-                                  want_s2=want_s2, time_major=tm)
+    out = ops.dense_head_forward(x, w1, K, N1, nrn1, w2, N2, nrn2, group=group, want_s1=want_s1,
+                                 want_s2=want_s2, time_major=tm)
   except L.SnnqpError as e:
     if e.code != L.EUNSUPPORTED:
       raise
     return None
+  fused_dense_head.last_plan = (w1, K, N1, nrn1, w2, N2, nrn2, group, tm)    # models.DenseSNN caches it
+  return out
+
+
+fused_dense_head.last_plan = None
 
 
 class SpikingBlock(nn.Module):

@@ -315,6 +315,11 @@ def test_bench_gpus_2_starts_its_own_ranks_on_gloo():
   assert d["ranks_seen"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1]
   assert len({r["pid"] for r in d["ranks"]}) == 2
   assert len(d["rank_seconds"]) == 2 and max(d["rank_seconds"]) == pytest.approx(d["ms_per_step"] * 3e-3)
+  # ... and each rank's own account (seconds, per-layer kernel times, fallback counters: the
+  # stand-in launches no kernel), gathered into rank 0's line in rank order
+  assert [r["rank"] for r in d["rank_detail"]] == [0, 1]
+  assert [r["seconds"] for r in d["rank_detail"]] == d["rank_seconds"]
+  assert all(r["kernels"] == {} for r in d["rank_detail"])
   # every rank announced itself on stderr
   assert err.count("bench.py rank {") >= 1
 

@@ -232,14 +232,14 @@ def test_int_contract_against_reference_literal_float_at_baseline_size(oracle):
   float32 arithmetic (flax_qconv.py:158-168, flax_qdense.py:87-89) at BASELINE size: spike
   rasters equal, membrane potentials within 1e-5 of the threshold scale.  One full-size C3
   sample (T = 20, 128x128x2: 55 M neuron-steps) and C2 at B = 64 here; the committed report
-  (python -m oracle.int_vs_float --samples 16 -> profiles/r02_int_vs_float.json) covers 16
+  (python -m oracle.int_vs_float --samples 16 -> profiles/r04_int_vs_float.json) covers 16
   samples and B = 256 and must satisfy the same bounds."""
   import json
   from oracle import int_vs_float as ivf
   c3 = ivf.c3_report(samples=1)
   c2 = ivf.c2_report(B=64)
   live = ivf.summarize(c3, c2)
-  with open(os.path.join(ROOT, "profiles", "r02_int_vs_float.json")) as f:
+  with open(os.path.join(ROOT, "profiles", "r04_int_vs_float.json")) as f:
     committed = json.load(f)
   assert committed["c3"]["samples"] >= 8
   assert committed["c3"]["layers"]["conv0"]["neuron_steps"] == committed["c3"]["samples"] * 20 * 128 * 128 * 128

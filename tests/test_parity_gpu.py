@@ -1702,14 +1702,17 @@ def test_conv_block_random_shapes(dev):
   """40 random geometries (image sizes 3..40, Cin 2..128, Cout 32..300, T, B, pool, 3/4/5/8-bit
   codes, binary / count / large-count events, carried-in potentials): the MFMA kernels --
   work-queue schedule, clipped edge patches, masked channel words, padded Cin, fp6 and int8
-  formats, every conv0 table mode -- equal the direct-form kernel bit for bit."""
+  formats, every conv0 table mode -- equal the direct-form kernel bit for bit.
+  A PROPERTY test (two implementations of this package agree), not parity evidence: the oracle
+  comparisons of the same shapes are test_random_blocks_against_the_oracle and the layer tests."""
   from tests.stress import conv_block_random
   assert conv_block_random(dev, 40, 20261004) == []
 
 
 def test_dense_block_random_shapes(dev):
   """40 random dense blocks (any K and N, T up to 60, every neuron form, carried-in potentials):
-  the MFMA kernel equals the direct-form kernel bit for bit."""
+  the MFMA kernels (128-column, wide, fp6) equal the direct-form kernel bit for bit.  A PROPERTY
+  test (two implementations of this package agree), not parity evidence."""
   from tests.stress import dense_block_random
   assert dense_block_random(dev, 40, 20261005) == []
 
