@@ -58,6 +58,8 @@ if "--traffic" in sys.argv:
       tag = "conv3x3[128x128x2->128]"
     elif "conv3x3_bits_kernel" in k or "conv3x3_fp6_kernel" in k:
       tag = "conv3x3[64x64x128->128]" if k.endswith("#0") else "conv3x3[32x32x128->128]"
+    elif "dense_wide_kernel" in k:
+      tag = "dense_head[2048->512->110]"
     elif "dense_mfma_kernel" in k or "dense_fp6_kernel" in k:
       tag = "dense[32768->110]"
     if tag:

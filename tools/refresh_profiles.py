@@ -1,4 +1,4 @@
-"""Copies one tools/r03_measure.sh result directory into profiles/ under the round's prefix:
+"""Copies one tools/r0N_measure.sh result directory into profiles/ under the round's prefix:
   python tools/refresh_profiles.py gpurun_out/s3x r03
 (gpurun_out/ is scratch; profiles/ is what the record cites)."""
 import glob
@@ -11,6 +11,8 @@ src, pre = sys.argv[1], sys.argv[2]
 names = {"bench.json": "bench.json", "bench_under_rocprof.json": "bench_under_rocprof.json",
          "kernel_stats.csv": "kernel_stats.csv", "pmc_summary.json": "pmc_summary.json",
          "pmc_traffic.json": "pmc_traffic.json", "pmc_product_summary.json": "pmc_lds_summary.json"}
+names.update({n: n for n in ("kernel_stats_c2.csv", "pmc_c2_summary.json", "pmc_c2_b4096_summary.json", "pmc_c2_traffic.json")
+              if os.path.exists(os.path.join(src, n))})
 for a, b in names.items():
   shutil.copy(os.path.join(src, a), os.path.join("profiles", "%s_%s" % (pre, b)))
 lines = []
