@@ -2933,3 +2933,84 @@ def test_cextnet_steps_without_a_host_synchronisation_and_captures(dev, oracle, 
   np.testing.assert_array_equal(_np(step(x)[0]), g["logits"])
   np.testing.assert_array_equal(_np(step(torch.roll(x, 1, 0))[0]), np.roll(g["logits"], 1, 0))
   del step
+
+
+@pytest.mark.parametrize("kind", ["plif", "lif", "mslif_tau3", "mslif_vreset"])
+def test_dense_head_neuron_variants(dev, oracle, kind):
+  """The fused dense head with every neuron of spiking_learning.py:357-438 in both blocks (the
+  straight-line walk for u += (x - u) m with v_reset = 0, the general walk for the rest), a hidden
+  width that takes one column tile per wave (N1 = 200) and one that takes two (N1 = 400)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  sig = lambda v: (1.0 / (1.0 + np.exp(-np.asarray(v, np.float64)))).astype(F32)
+  for N1 in (200, 400):
+    T, B, K, N2 = 13, 21, 320, 60
+    c = cases.dense_net_case(True, T=T, B=B, K=K, hidden=N1, out=N2)
+    p = c["vars"]["params"]
+    x = np.ascontiguousarray(np.swapaxes(c["x"], 0, 1))
+    rng = np.random.Generator(np.random.PCG64(N1))
+    vth, vr = 1.0, 0.0
+    def neuron(n):
+      if kind == "plif":
+        tp = F32(-0.35)
+        return ops.Neuron(L.NEURON_PARAMETRIC_LEAKY_IF, float(sig(tp)), vth, vr), \
+            {"kind": "parametric_leaky_IF", "tau_param": tp, "v_threshold": vth, "v_reset": vr}
+      if kind == "lif":
+        tv = rng.uniform(-1.0, 2.0, n).astype(F32)
+        return ops.Neuron(L.NEURON_LIF, 1.0, vth, vr, decay=_t(sig(tv), dev)), \
+            {"kind": "LIF", "tau_vec": tv, "v_threshold": vth, "v_reset": vr}
+      if kind == "mslif_tau3":
+        return ops.Neuron(L.NEURON_MULTI_STEP_LIF, 3.0, vth, vr), \
+            {"kind": "multi_step_LIF", "tau": 3.0, "v_threshold": vth, "v_reset": vr}
+      return ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, 0.8, 0.1), \
+          {"kind": "multi_step_LIF", "tau": 2.0, "v_threshold": 0.8, "v_reset": 0.1}
+    n1, o1 = neuron(N1)
+    n2, o2 = neuron(N2)
+    q1, q2 = qweight_of(oracle, p["QuantDense_0"], 8), qweight_of(oracle, p["QuantDense_1"], 8)
+    _, s1 = oracle.dense_block(x, q1, o1, "int")
+    _, s2 = oracle.dense_block(s1, q2, o2, "int")
+    want = oracle.vote(s2, 10)
+    assert 0.005 < s1.mean() < 0.7, s1.mean()
+    w1 = _weight(p["QuantDense_0"], 8, dev, transposed=True)
+    w2 = _weight(p["QuantDense_1"], 8, dev, transposed=True)
+    logits, g1, g2 = ops.dense_head_forward(_t(x, dev), w1, K, N1, n1, w2, N2, n2, group=10,
+                                            want_s1=True, want_s2=True)
+    np.testing.assert_array_equal(_np(g1), packbits_lastaxis(s1.astype(np.uint8)), err_msg="%s N1 %d" % (kind, N1))
+    np.testing.assert_array_equal(_np(g2), packbits_lastaxis(s2.astype(np.uint8)), err_msg="%s N1 %d" % (kind, N1))
+    np.testing.assert_array_equal(_np(logits), want)
+
+
+def test_dense_snn_prepared_head_follows_its_parameters(dev, oracle):
+  """models.DenseSNN keeps the prepared launch of the dense head per parameter set (identity and
+  version of the eight leaves, the config's factories, the input's shape).  Changing a leaf in
+  place, swapping the tree, another batch size or another config object must each give the
+  oracle's logits for THAT state -- never the cached launch of another."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  c = cases.dense_net_case(True, T=20, B=12, K=512, hidden=512)
+  e = cases.dense_net_expected(oracle, c)
+  cfg = syn.make_config(bits=8, prune_percentage=0.5, hidden=512)
+  model = models.DenseSNN(num_classes=11, config=cfg)
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  x = _t(c["x"], dev)
+  for _ in range(3):                                   # generic path, then the cached plan twice
+    np.testing.assert_array_equal(_np(model.apply(variables, x, trgt=None, train=False, rng=None)[0]), e["logits"])
+  # a leaf rewritten in place (a training step would): new codes, new logits
+  import copy
+  v2 = copy.deepcopy(c["vars"])
+  k = v2["params"]["QuantDense_1"]["kernel"]
+  k[:] = np.roll(k, 7, axis=1)
+  e2 = cases.dense_net_expected(oracle, dict(c, vars=v2))
+  assert not np.array_equal(e2["logits"], e["logits"])
+  variables["params"]["QuantDense_1"]["kernel"].copy_(_t(k, dev))
+  np.testing.assert_array_equal(_np(model.apply(variables, x, trgt=None, train=False, rng=None)[0]), e2["logits"])
+  # another tree, another batch size
+  variables3 = nn.tree_from_numpy(c["vars"], dev)
+  np.testing.assert_array_equal(_np(model.apply(variables3, x, trgt=None, train=False, rng=None)[0]), e["logits"])
+  np.testing.assert_array_equal(_np(model.apply(variables3, x[:5], trgt=None, train=False, rng=None)[0]), e["logits"][:5])
+  # another config (4-bit codes from the same leaves): its own logits
+  cfg4 = syn.make_config(bits=4, prune_percentage=0.5, hidden=512)
+  m4 = models.DenseSNN(num_classes=11, config=cfg4)
+  e4 = cases.dense_net_expected(oracle, dict(c, bits=4))
+  np.testing.assert_array_equal(_np(m4.apply(variables3, x, trgt=None, train=False, rng=None)[0]), e4["logits"])
+  np.testing.assert_array_equal(_np(model.apply(variables3, x, trgt=None, train=False, rng=None)[0]), e["logits"])
