@@ -76,7 +76,7 @@ def parse(argv=None):
   ap.add_argument("--model", choices=("c3", "cextnet", "dense"), default="c3",
                   help="c3: BASELINE config 3 (the headline workload); cextnet: the reference's "
                        "full TCJA model (5 conv blocks + 2 gates + 2 dense), same input")
-  ap.add_argument("--input", choices=("u8", "f32", "ev1", "ev4"), default=None,
+  ap.add_argument("--input", choices=("u8", "f32", "ev1", "ev4", "bits"), default=None,
                   help="format of the resident input batch.  ev1 (default for binary frames): the "
                        "bit-packed wire format of include/snnqp.h, 81 920 B per sample -- what the "
                        "host feed can deliver (uint8 frames need 50 GB/s per GPU at this rate) and "
@@ -121,6 +121,8 @@ def parse(argv=None):
   args = ap.parse_args(argv)
   if args.input is None:
     args.input = "u8" if (args.counts or args.model == "dense" or args.stand_in) else "ev1"
+  if args.input == "bits" and args.model != "dense":
+    ap.error("--input bits (bit-packed [B, T, K] rows, ops.PackedSpikes) is for --model dense")
   if args.input == "ev1" and args.counts:
     ap.error("--input ev1 holds binary frames; count frames travel as ev4 or u8")
   if args.layer_bits:
@@ -483,7 +485,10 @@ def main(argv=None):
   else:
     x = (torch.rand((B, T, hw, hw, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
   frames_u8 = x if (args.model != "dense" and not args.stand_in) else None
-  if args.input == "f32":
+  if args.input == "bits":
+    x = ops.pack_bits(x)
+    torch.cuda.synchronize()
+  elif args.input == "f32":
     x = x.to(torch.float32)
   elif args.input in ("ev1", "ev4") and ops is not None and args.model != "dense":
     from snnquantprune_amd import _lib as L_
@@ -620,7 +625,7 @@ def main(argv=None):
   # Only what can be captured: integer frames (float32 frames are inspected on the host before they
   # are narrowed -- a read-back no capture allows).
   if (gpu and ops is not None and not args.stand_in and not args.graph and args.feed == "resident"
-      and not args.no_fed_leg and world == 1 and args.input in ("u8", "ev1", "ev4")):
+      and not args.no_fed_leg and world == 1 and args.input in ("u8", "ev1", "ev4", "bits")):
     captured = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
     for _ in range(2):
       parallel.all_gather_rows(captured()[0])
@@ -676,7 +681,8 @@ def main(argv=None):
                       "membrane potentials f32",
       "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
               % args.lam + {"ev1": " as bit-packed frames (EV1, include/snnqp.h)", "ev4": " as nibble-packed "
-                            "frames (EV4)", "u8": " as uint8 frames", "f32": " as float32 frames"}[args.input] +
+                            "frames (EV4)", "u8": " as uint8 frames", "f32": " as float32 frames",
+                            "bits": " as bit-packed rows"}[args.input] +
               ", N(0,1/fan_in) weights, " +
               ("random BatchNorm statistics" if args.random_bn else "BatchNorm as initialised") +
               ", random seeds fixed",
@@ -764,7 +770,7 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
   #       really read / write, matrix peak of the instruction the kernel issues)
   # bytes of one input frame as conv0 reads it (ev4 frames are unpacked to uint8 first)
   in_bytes = {"f32": 128 * 128 * 2 * 4, "u8": 128 * 128 * 2, "ev4": 128 * 128 * 2,
-              "ev1": 128 * 128 * 2 // 8}[args.input]
+              "ev1": 128 * 128 * 2 // 8, "bits": 0}[args.input]
   spec = {
       "conv3x3[128x128x2->128]": (B * T * 128 * 128 * 128 * 18,
                                   B * T * (in_bytes + 64 * 64 * 16), INT8_MFMA_PEAK_TOPS),

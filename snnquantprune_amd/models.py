@@ -105,8 +105,11 @@ def _head_key(mod, cfg, x, hidden, nout):
   root = mod._root
   if root.initializing or root.mutable or mod._path != ():
     return None
-  if not (isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda and x.ndim == 3
-          and x.is_contiguous()):
+  if isinstance(x, ops.PackedSpikes):
+    if not (x.bits.is_cuda and x.ndim == 3 and x.flat_perm is None):
+      return None
+  elif not (isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda and x.ndim == 3
+            and x.is_contiguous()):
     return None
   p = root.variables.get("params")
   try:
@@ -116,7 +119,7 @@ def _head_key(mod, cfg, x, hidden, nout):
   except (KeyError, TypeError):
     return None
   q = cfg.quant
-  extra = (tuple(x.shape), hidden, nout, _layer_bits(cfg, 0), _layer_bits(cfg, 1), id(q.get("weight")),
+  extra = (type(x).__name__, tuple(x.shape), hidden, nout, _layer_bits(cfg, 0), _layer_bits(cfg, 1), id(q.get("weight")),
            float(q.prune_percentage) >= 0.0, id(cfg.neuron_dynamics))
   return ts, extra
 
