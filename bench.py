@@ -814,7 +814,7 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
         pmc_src = "committed %s (not measured in this run)" % os.path.relpath(path, ROOT)
         break
 
-  if args.model == "dense" and B == 256 and T == 20 and args.bits == 8:
+  if args.model == "dense" and B == 256 and T == 20 and args.bits == 8 and args.input == "u8":
     path = os.path.join(ROOT, "profiles", "r04_pmc_c2_traffic.json")
     if os.path.exists(path):
       with open(path) as f:
