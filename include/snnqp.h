@@ -400,8 +400,15 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
  *       snnqp_dense_lif_forward writes them (the hidden raster otherwise never leaves the CU).
  * Membrane potentials start from zero (initialize_carry, spiking_learning.py:464-472) and are
  * not returned: a caller that carries state uses snnqp_dense_lif_forward per block.
+ * ws / ws_bytes  nullable workspace (device memory, 256-byte aligned, ZERO when first used, one
+ *       launch at a time; snnqp_dense_head_workspace_bytes says how much, 0 = it would not be
+ *       used).  With it a batch that fills at most half the chip (config C2: B = 256) runs as two
+ *       workgroups per tile of samples, each with half of the hidden columns -- half of the first
+ *       block's codes through a CU's L1, the bound of the launch -- which hand their halves of the
+ *       hidden raster over through `ws`; the last arriver runs the second block and the vote.
  * SNNQP_EUNSUPPORTED (nothing enqueued) unless N1 <= 512, N2 <= 128, 1 <= T <= 64 and both
  * weights are W_I8 with tiles: the caller then runs the blocks one by one. */
+int64_t snnqp_dense_head_workspace_bytes(int32_t T, int32_t B, int32_t N1);
 int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_stride_t,
                              int64_t x_stride_b, int32_t T, int32_t B, int32_t K,
                              int32_t N1, const snnqp_weight_t *w1, const int8_t *wt1,
@@ -409,7 +416,7 @@ int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_stride_t,
                              const snnqp_weight_t *w2, const int8_t *wt2,
                              const snnqp_neuron_t *nrn2, int32_t group,
                              uint32_t *s1_out, uint32_t *s2_out, float *logits,
-                             snnqp_stream_t stream);
+                             void *ws, int64_t ws_bytes, snnqp_stream_t stream);
 
 /* ---- element-wise pieces ----------------------------------------------------
  * replaces: neural_dynamics(u, x) scanned over T, spiking_learning.py:460

@@ -92,10 +92,11 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
         c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "snnqp_dense_head_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "snnqp_dense_head_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(WeightT),
         c_void_p, POINTER(NeuronT), c_int32, POINTER(WeightT), c_void_p, POINTER(NeuronT), c_int32,
-        c_void_p, c_void_p, c_void_p, c_void_p]),
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "snnqp_device_status": (c_int, [c_int, POINTER(c_uint32), c_int]),
     "snnqp_workqueue_capture_mark": (c_int, [c_int, POINTER(c_int64)]),
     "snnqp_workqueue_capture_release": (c_int, [c_int, c_int64, c_int64]),

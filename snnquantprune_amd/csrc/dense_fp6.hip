@@ -23,6 +23,8 @@
 // it retires the chunk's LDS writes, not the fragments in flight).  Spike words are requested
 // four chunks ahead, B fragments two (register rings of three), and every wave interleaves its
 // MFMAs with its share of the loads and of the expansion, slot by slot.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace snnqp {
@@ -352,39 +354,37 @@ dense_fp6_kernel(DenseFp6Args a) {
 
   // K split over workgroups: every workgroup of a tile leaves its partial tile (exact integers
   // in float32) in its slab and draws a ticket; the one that draws the last adds the others'
-  // slabs to its own tile and goes on to the neuron, the others are done.  One agent-scope
-  // release before the ticket, one acquire after it (cdna_hip_programming.md, in-launch split-K).
+  // slabs to its own tile and goes on to the neuron, the others are done.  The hand-off recipe of
+  // cdna_hip_programming.md (R1): the slab by agent-scope relaxed stores (write-through), every
+  // storing wave drains, one relaxed agent-scope ticket, the last arriver reads with agent-scope
+  // loads -- no release / acquire fence: on this part a fence pair writes back / invalidates an
+  // L2 and cost ~ 20 us per launch (round 4's first version: 0.075 ms against 0.066 unsplit).
   if (a.ksplit > 1) {
+    typedef unsigned long long u64;
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    float *mine = a.slabs + ((int64_t)tile * a.ksplit + blockIdx.z) * (ROWS * 128);
-    for (int i = threadIdx.x * 4; i < ROWS * 128; i += 256 * F6_KGROUPS * 4)
-      *(float4 *)(mine + i) = *(const float4 *)(et + i);
+    u64 *mine = (u64 *)(a.slabs + ((int64_t)tile * a.ksplit + blockIdx.z) * (ROWS * 128));
+    const u64 *et64 = (const u64 *)et;
+    for (int i = threadIdx.x; i < ROWS * 64; i += 256 * F6_KGROUPS)
+      __hip_atomic_store(mine + i, et64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t *flag = (uint32_t *)lds;               // (the byte -> nibble table is no longer needed)
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const uint32_t ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ticket >= (uint32_t)a.ksplit && a.status) *(volatile uint32_t *)a.status = SNNQP_STATUS_TICKET;
       const bool last = ticket + 1u == (uint32_t)a.ksplit;
-      if (last) {
-        __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
       *flag = last ? 1u : 0u;
     }
     __syncthreads();
     if (*flag == 0u) return;
     for (int z = 0; z < a.ksplit; ++z) {
       if (z == (int)blockIdx.z) continue;
-      const float *other = a.slabs + ((int64_t)tile * a.ksplit + z) * (ROWS * 128);
-      for (int i = threadIdx.x * 4; i < ROWS * 128; i += 256 * F6_KGROUPS * 4) {
-        const float4 o = *(const float4 *)(other + i);
-        float4 m = *(const float4 *)(et + i);
-        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-        *(float4 *)(et + i) = m;
+      const u64 *other = (const u64 *)(a.slabs + ((int64_t)tile * a.ksplit + z) * (ROWS * 128));
+      for (int i = threadIdx.x; i < ROWS * 64; i += 256 * F6_KGROUPS) {
+        const u64 o = __hip_atomic_load(other + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        et[2 * i] += __uint_as_float((uint32_t)o);
+        et[2 * i + 1] += __uint_as_float((uint32_t)(o >> 32));
       }
     }
     __syncthreads();
@@ -432,11 +432,13 @@ static void launch_dense_fp6(const DenseFp6Args &a, unsigned gx, unsigned gy, hi
 // workgroups per tile (partial tiles and tickets in a caller workspace, the last arriver of a
 // tile runs the neuron) fills the chip when the batch alone does not.  The model behind the
 // choice, in microseconds at K = 32768, fitted to the read-out (T = 20): a launch takes (rounds of
-// workgroups over the 256 CUs) x (11 + (9.5 + 15.5 RT) / ks) -- B = 1024 unsplit: RT 3 / 5 =
-// 0.067 / 0.098 ms -- plus, when split, the hand-over 6 + 0.09 per KB of slab moved (RT x 16 KB out,
-// (ks - 1) x that in; an agent-scope release / acquire pair, which on this part writes back /
-// invalidates an L2): B = 64 as RT 1, ks 4 takes 0.029 ms against 0.043 unsplit; B = 1024 as
-// RT 5, ks 2 takes 0.075 against 0.066, so the headline stays unsplit.
+// workgroups over the 256 CUs) x (11 + (9.5 + 15.5 RT) / ks) -- B = 1024 unsplit: RT 3 / 4 / 5 =
+// 0.067 / 0.084 / 0.098 ms -- plus, when split, the hand-over, 6 + 0.09 per KB of slab moved.
+// Measured (write-through hand-over): B = 16 / 64 / 100 split (RT 1, ks 4) 0.025 / 0.027 / 0.031 ms
+// against 0.042 / 0.043 / 0.044 unsplit; B = 1024 forced to (RT 5, ks 2) 0.071, (3, 2) 0.080,
+// (5, 4) 0.096 against 0.066 unsplit -- with more rows per workgroup the per-k cost of a workgroup
+// (fragment reads, expansion, MFMAs per row tile) grows as fast as the stream shrinks -- so the
+// headline stays unsplit.  (SNNQP_DENSE_FP6_PLAN="rt,ks" forces a plan: a measurement knob.)
 // workspace = F6_TICKET_BYTES of tickets (a fixed head, whatever the plan: a workspace that
 // served another shape before still has zeros there), then the slabs
 constexpr int64_t F6_TICKET_BYTES = 4096;
@@ -498,6 +500,11 @@ int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t 
   // the workspace decides: the plan with a K split when the caller brought enough of it
   // (snnqp_dense_workspace_bytes, zero-filled once), else the best plan without
   Fp6Plan plan = pick_fp6_plan(T, B, K, gy, ws != nullptr);
+  if (const char *e = ws ? std::getenv("SNNQP_DENSE_FP6_PLAN") : nullptr) {     // "rt,ks": measurement knob
+    int r = 0, k = 0;
+    if (std::sscanf(e, "%d,%d", &r, &k) == 2 && r >= 1 && r <= 5 && r * 32 >= T && (k == 1 || k == 2 || k == 4))
+      plan = Fp6Plan{r, k};
+  }
   if (plan.ks > 1 && (fp6_workspace_bytes(plan, T, B, gy) > ws_bytes || ((uintptr_t)ws & 255) != 0))
     plan = pick_fp6_plan(T, B, K, gy, false);
   if (row_tiles >= 1 && row_tiles <= 5 && row_tiles * 32 >= T) plan = Fp6Plan{row_tiles, 1};

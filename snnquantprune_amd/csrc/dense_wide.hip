@@ -74,6 +74,12 @@ struct DenseWideArgs {
   NeuronP nrn2;
   uint32_t *s2_out;               // nullable
   float *logits;
+  // fused head with the hidden columns split over two workgroups per tile (blockIdx.y): each
+  // leaves its half of the hidden raster in the workspace, the last arriver runs the rest
+  int32_t csplit;
+  uint32_t *hs_tickets;           // [tiles], zero between launches
+  uint32_t *hs_raster;            // [tiles][2][ROWS][8 words]
+  uint32_t *status;               // the device's status word (runtime.hip), or null
 };
 
 __device__ __forceinline__ void wide_barrier() {
@@ -268,7 +274,9 @@ dense_wide_kernel(DenseWideArgs a) {
   constexpr int NSLOT = NFRAG * CT;               // MFMAs of a chunk
   constexpr int RB = RT * CT >= 6 ? 6 : 12;       // B ring, k-steps (the unrolled body is 12 long)
   constexpr int NW = (16 * RT * CT * 2 + 63) / 64;
-  constexpr int LDSB = W_NBUF * ABYTES > 2176 + W_VOTE_SB * 512 ? W_NBUF * ABYTES : 2176 + W_VOTE_SB * 512;
+  // (the fused head overlays the dead A images: raster | count / T per (sample, feature) | a flag)
+  constexpr int LDSB = W_NBUF * ABYTES > ROWS * W_S1P * 4 + W_VOTE_SB * 512 + 16 ? W_NBUF * ABYTES
+                                                                                : ROWS * W_S1P * 4 + W_VOTE_SB * 512 + 16;
   __shared__ __attribute__((aligned(128))) uint8_t lds[LDSB];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -441,6 +449,7 @@ dense_wide_kernel(DenseWideArgs a) {
   }
   // ---- neuron of the first block, from the accumulator registers ----------------------------
   uint32_t *s1 = (uint32_t *)lds;                   // hidden raster [ROWS][W_S1P] words
+  const int wofs = (FUSE && a.csplit) ? (int)blockIdx.y * 8 : 0;   // this block's words within a row
   float *vbuf = (float *)(lds + ROWS * W_S1P * 4);  // fused head: spike count / T  [SB][128]
   const bool fast1 = a.nrn.kind != SNNQP_NEURON_LIF && a.nrn.inv_k != 0.0f;
   {
@@ -473,7 +482,7 @@ dense_wide_kernel(DenseWideArgs a) {
       const int idx = v * 64 + lane;
       if (idx < 16 * RT * CT * 2) {
         const int hh = idx & 1, ct = (idx >> 1) % CT, k = idx / (2 * CT);
-        s1[rho_of(k, hh) * W_S1P + wl + ct] = words[v];
+        s1[rho_of(k, hh) * W_S1P + wofs + wl + ct] = words[v];
       }
     }
   }
@@ -487,7 +496,37 @@ dense_wide_kernel(DenseWideArgs a) {
       const int jj = kk / a.T, tt = kk - jj * a.T, ss = 2 * jj + hh;
       const int gw = blockIdx.y * 8 * CT + w;
       if (w < 8 * CT && jj < a.SPH && ss < nsamp && gw < CW)
-        a.s_out[((int64_t)tt * a.B + (b0 + ss)) * CW + gw] = s1[rho * W_S1P + w];
+        a.s_out[((int64_t)tt * a.B + (b0 + ss)) * CW + gw] = s1[rho * W_S1P + wofs + w];
+    }
+  }
+  // ---- column split: hand the half raster over, the last arriver of the tile goes on ----------
+  // (cdna_hip_programming.md, hand-off recipe R1: the payload by agent-scope relaxed stores --
+  // write-through --, every storing wave drains, one relaxed agent-scope ticket; the last
+  // arriver reads the other half with agent-scope loads: no release / acquire fence, which on
+  // this part would write back / invalidate an L2)
+  if constexpr (FUSE) {
+    if (a.csplit) {
+      const int tile = blockIdx.x, half = blockIdx.y;
+      uint32_t *mine = a.hs_raster + ((int64_t)(tile * 2 + half) * ROWS) * 8;
+      for (int q = tid; q < ROWS * 8; q += W_THREADS)
+        __hip_atomic_store(mine + q, s1[(q >> 3) * W_S1P + wofs + (q & 7)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      uint32_t *flag = (uint32_t *)(lds + ROWS * W_S1P * 4 + W_VOTE_SB * 512);
+      if (tid == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(a.hs_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket >= 2u && a.status) *(volatile uint32_t *)a.status = SNNQP_STATUS_TICKET;
+        const bool last = ticket == 1u;
+        if (last) __hip_atomic_store(a.hs_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last ? 1u : 0u;
+      }
+      __syncthreads();
+      if (*flag == 0u) return;
+      const uint32_t *other = a.hs_raster + ((int64_t)(tile * 2 + (1 - half)) * ROWS) * 8;
+      for (int q = tid; q < ROWS * 8; q += W_THREADS)
+        s1[(q >> 3) * W_S1P + (8 - wofs) + (q & 7)] =
+            __hip_atomic_load(other + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wide_barrier();
     }
   }
   // ---- second block + vote --------------------------------------------------------------------
@@ -627,26 +666,61 @@ static int wide_row_tiles_override() {
   return v;
 }
 
-static int fill_and_launch(DenseWideArgs &a, int in_type, bool fuse, hipStream_t st) {
-  const int CT = a.N > 256 ? 2 : 1;
-  const unsigned gy = fuse ? 1u : (unsigned)((a.N + 256 * CT - 1) / (256 * CT));
-  int sph = 0;
-  int rt = pick_wide_rt(a.T, a.B, CT, gy, fuse ? W_VOTE_SB / 2 : 64, &sph);
+// The fused head with its hidden columns split over two workgroups per tile: when the batch gives
+// the chip at most half a grid (config C2: B = 256 is 128 tiles of two samples), two workgroups of
+// 256 columns each pull half of the first block's codes through their CU's L1 -- the bound of the
+// unsplit launch -- and hand their half of the hidden raster over through the workspace.
+constexpr int64_t W_TICKET_BYTES = 4096;         // a fixed head of the workspace: a ticket per tile
+struct WidePlan { int rt, sph, ct, csplit; unsigned gx, gy; };
+
+static WidePlan plan_wide(const DenseWideArgs &a, bool fuse, bool may_split) {
+  WidePlan p = {};
+  p.ct = a.N > 256 ? 2 : 1;
+  p.gy = fuse ? 1u : (unsigned)((a.N + 256 * p.ct - 1) / (256 * p.ct));
+  const int cap = fuse ? W_VOTE_SB / 2 : 64;
+  p.rt = pick_wide_rt(a.T, a.B, p.ct, p.gy, cap, &p.sph);
   const int forced = wide_row_tiles_override();
   if (forced >= 1 && forced <= 4 && 16 * forced >= a.T) {
-    rt = forced;
-    sph = 16 * rt / a.T;
-    if (fuse && sph > W_VOTE_SB / 2) sph = W_VOTE_SB / 2;
+    p.rt = forced;
+    p.sph = 16 * p.rt / a.T;
+    if (p.sph > cap) p.sph = cap;
   }
-  SNNQP_REQUIRE(rt > 0, SNNQP_EUNSUPPORTED, "dense wide: T too large");
-  a.SPH = sph;
-  const unsigned gx = (unsigned)((a.B + 2 * sph - 1) / (2 * sph));
+  if (p.rt > 0) {
+    p.gx = (unsigned)((a.B + 2 * p.sph - 1) / (2 * p.sph));
+    static const bool no_split = std::getenv("SNNQP_DENSE_HEAD_NOSPLIT") != nullptr;
+    if (fuse && may_split && !no_split && a.N > 256 && p.gx * 2u <= 256u && p.gx <= W_TICKET_BYTES / 4) {
+      p.csplit = 1;
+      p.ct = 1;
+      p.gy = 2;
+    }
+  }
+  return p;
+}
+
+static int64_t wide_workspace_bytes(const WidePlan &p) {
+  return p.csplit ? W_TICKET_BYTES + (int64_t)p.gx * 2 * (p.rt * 32) * 8 * 4 : 0;
+}
+
+static int fill_and_launch(DenseWideArgs &a, int in_type, bool fuse, void *ws, int64_t ws_bytes,
+                           hipStream_t st) {
+  WidePlan p = plan_wide(a, fuse, ws != nullptr);
+  if (p.csplit && (wide_workspace_bytes(p) > ws_bytes || ((uintptr_t)ws & 255) != 0)) p = plan_wide(a, fuse, false);
+  SNNQP_REQUIRE(p.rt > 0, SNNQP_EUNSUPPORTED, "dense wide: T too large");
+  a.SPH = p.sph;
+  a.csplit = p.csplit;
+  if (p.csplit) {
+    a.hs_tickets = (uint32_t *)ws;
+    a.hs_raster = (uint32_t *)((uint8_t *)ws + W_TICKET_BYTES);
+    a.status = device_status_word(stream_device(st));
+  }
+  const int rt = p.rt;
+  const unsigned gx = p.gx, gy = p.gy;
   const bool u8 = in_type == SNNQP_U8;
   if (fuse) {
-    if (CT == 2) { if (u8) launch_wide_rt<2, SNNQP_U8, true>(rt, a, gx, gy, st); else launch_wide_rt<2, SNNQP_BITS, true>(rt, a, gx, gy, st); }
+    if (p.ct == 2) { if (u8) launch_wide_rt<2, SNNQP_U8, true>(rt, a, gx, gy, st); else launch_wide_rt<2, SNNQP_BITS, true>(rt, a, gx, gy, st); }
     else { if (u8) launch_wide_rt<1, SNNQP_U8, true>(rt, a, gx, gy, st); else launch_wide_rt<1, SNNQP_BITS, true>(rt, a, gx, gy, st); }
   } else {
-    if (CT == 2) { if (u8) launch_wide_rt<2, SNNQP_U8, false>(rt, a, gx, gy, st); else launch_wide_rt<2, SNNQP_BITS, false>(rt, a, gx, gy, st); }
+    if (p.ct == 2) { if (u8) launch_wide_rt<2, SNNQP_U8, false>(rt, a, gx, gy, st); else launch_wide_rt<2, SNNQP_BITS, false>(rt, a, gx, gy, st); }
     else { if (u8) launch_wide_rt<1, SNNQP_U8, false>(rt, a, gx, gy, st); else launch_wide_rt<1, SNNQP_BITS, false>(rt, a, gx, gy, st); }
   }
   SNNQP_CHECK_LAUNCH("dense_wide_kernel");
@@ -669,7 +743,7 @@ int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
   a.dq = make_dequant(w->L, w->m);
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out;
-  return fill_and_launch(a, in_type, false, st);
+  return fill_and_launch(a, in_type, false, nullptr, 0, st);
 }
 
 }  // namespace snnqp
@@ -681,7 +755,7 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
                                         const snnqp_weight_t *w2, const int8_t *wt2,
                                         const snnqp_neuron_t *nrn2, int32_t group,
                                         uint32_t *s1_out, uint32_t *s2_out, float *logits,
-                                        snnqp_stream_t stream) {
+                                        void *ws, int64_t ws_bytes, snnqp_stream_t stream) {
   using namespace snnqp;
   SNNQP_REQUIRE(x && w1 && w2 && nrn1 && nrn2 && logits, SNNQP_EINVAL, "dense_head_forward: null argument");
   if (const uint32_t code = device_status_read(stream_device((hipStream_t)stream))) {
@@ -725,5 +799,13 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
   a.N2 = N2; a.KS2 = (N1 + 31) / 32; a.group = group;
   a.wt2 = wt2; a.dq2 = make_dequant(w2->L, w2->m); a.nrn2 = make_neuron(nrn2);
   a.s2_out = s2_out; a.logits = logits;
-  return fill_and_launch(a, in_type, true, (hipStream_t)stream);
+  return fill_and_launch(a, in_type, true, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int64_t snnqp_dense_head_workspace_bytes(int32_t T, int32_t B, int32_t N1) {
+  using namespace snnqp;
+  if (T < 1 || T > 64 || B < 1 || N1 < 1 || N1 > 512) return 0;
+  DenseWideArgs a = {};
+  a.T = T; a.B = B; a.N = N1;
+  return wide_workspace_bytes(plan_wide(a, true, true));
 }

@@ -2618,13 +2618,18 @@ def test_dense_wide_kernel_neurons_and_batchnorm(dev, oracle, kind):
 
 
 @pytest.mark.parametrize("shape", [(20, 256, 2048, 512, 110), (6, 5, 208, 200, 70), (64, 3, 96, 300, 30),
-                                   (1, 40, 64, 512, 120), (9, 131, 1040, 384, 110), (3, 77, 320, 160, 50)],
-                         ids=["c2", "small", "longest_t", "one_step", "ragged_batch", "many_per_group"])
+                                   (1, 40, 64, 512, 120), (9, 131, 1040, 384, 110), (3, 77, 320, 160, 50),
+                                   (20, 3000, 96, 300, 30)],
+                         ids=["c2", "small", "longest_t", "one_step", "ragged_batch", "many_per_group",
+                              "full_grid_unsplit"])
 @pytest.mark.parametrize("fmt", ["u8", "bits"])
 def test_dense_head_as_one_launch(dev, oracle, shape, fmt):
   """snnqp_dense_head_forward -- QuantDense + LIF -> QuantDense + LIF -> vote
   (examples/tcja/models.py:200-255) in one launch -- against the oracle's two blocks and vote:
-  both rasters and the logits bit-exact, on uint8 rows (counts up to 255) and bit-packed rows."""
+  both rasters and the logits bit-exact, on uint8 rows (counts up to 255) and bit-packed rows.
+  Batches that fill at most half the chip run as two workgroups per tile of samples (the hidden
+  columns split, the halves of the hidden raster handed over through the workspace; every shape
+  here with more than 256 hidden features but the last), larger ones as one."""
   from snnquantprune_amd import ops
   T, B, K, N1, N2 = shape
   c = cases.dense_net_case(True, T=T, B=B, K=K, hidden=N1, out=N2)

@@ -14,7 +14,11 @@ pk = packing.PackedKernel(torch.from_numpy(leaf["kernel"]).to(dev), QuantDesc(L.
 w = pk.int_weight_mfma(128)
 x = ops.pack_bits((torch.rand((T, B, K), device=dev) < 0.1).to(torch.uint8))
 nrn = ops.Neuron(L.NEURON_MULTI_STEP_LIF, 2.0, 1.0, 0.0)
-print("workspace bytes", L.lib().snnqp_dense_workspace_bytes(L.BITS, T, B, K, N, ctypes.byref(w.struct())))
+print("workspace bytes", L.lib().snnqp_dense_workspace_bytes(L.BITS, T, B, K, N, ctypes.byref(w.struct())),
+      "plan override", os.environ.get("SNNQP_DENSE_FP6_PLAN"))
+if os.environ.get("SNNQP_DENSE_FP6_PLAN"):
+  _big = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+  ops._dense_workspace = lambda d, n: _big
 def run(n=20):
   for _ in range(3):
     ops.dense_lif_forward(x, w, K, N, nrn, want_u=False, packed_out=True)
