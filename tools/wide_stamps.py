@@ -22,6 +22,10 @@ assert lib.snnqp_debug_wide_stamps(buf, n) == 0
 s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 16).astype(np.int64)
 live = s[:, 0] > 0
 s = s[live]
+# (workgroups that handed their half raster over and left have no stamps behind the hand-over)
+full = s[:, 10] > s[:, 0]
+print("workgroups", len(s), "of which ran to the vote", int(full.sum()))
+s = s[full]
 print("workgroups", len(s), " (s_memtime ticks = shader cycles)")
 names = ["prologue", "K loop", "barrier", "walk1", "flush words+s_out", "layer2 mfma", "barrier", "walk2", "barrier", "vote"]
 d = np.diff(s[:, :11], axis=1)
