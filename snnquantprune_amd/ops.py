@@ -809,7 +809,10 @@ def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight,
   s2 = torch.empty((T, B, (N2 + 31) // 32), dtype=torch.int32, device=dev) if want_s2 else None
   a, b, n1, n2 = w1.struct(), w2.struct(), nrn1.struct(), nrn2.struct()
   # a batch that fills at most half the chip: two workgroups per tile through a workspace
-  ws = _dense_workspace(dev, int(L.lib().snnqp_dense_head_workspace_bytes(T, B, N1)))
+  nws = _head_ws_bytes.get((T, B, N1))
+  if nws is None:
+    nws = _head_ws_bytes[(T, B, N1)] = int(L.lib().snnqp_dense_head_workspace_bytes(T, B, N1))
+  ws = _dense_workspace(dev, nws)
   with _timed("dense_head[%d->%d->%d]" % (K, N1, N2)):
     L.check(L.lib().snnqp_dense_head_forward(
         _ptr(xt), in_type, xs_t, xs_b, T, B, K, N1, ctypes.byref(a), _ptr(w1.wt), ctypes.byref(n1),
@@ -817,6 +820,9 @@ def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight,
         _ptr(logits), _ptr(ws), 0 if ws is None else ws.numel(), _stream()))
   return (logits, PackedSpikes(s1, N1) if want_s1 else None,
           PackedSpikes(s2, N2) if want_s2 else None)
+
+
+_head_ws_bytes = {}
 
 
 def fallback_counts(reset: bool = False) -> dict:
