@@ -201,6 +201,7 @@ __device__ __forceinline__ void neuron_walk_fast(const v16i (&acc)[RT][CT],
                                                  const unsigned long long (&colmask)[CT],
                                                  const int (&col)[CT], const Dequant &dq,
                                                  const BnP &bn, float inv_k, float vth, int T,
+                                                 int nrows,
                                                  uint32_t (&words)[(16 * RT * CT * 2 + 63) / 64],
                                                  F &&on_end) {
   float bmean[CT], bmul[CT], bbias[CT], u[CT];
@@ -216,6 +217,7 @@ __device__ __forceinline__ void neuron_walk_fast(const v16i (&acc)[RT][CT],
   const int vnotlast = (lane % T == T - 1) ? 0 : -1;      // lane k: row k of a lane half
 #pragma unroll
   for (int k = 0; k < 16 * RT; ++k) {
+    if (k < nrows) {                  // (rows behind the last sample of a half: T = 20, RT 2: 12 of 32)
     const int nl = __builtin_amdgcn_readlane(vnotlast, k);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -235,6 +237,7 @@ __device__ __forceinline__ void neuron_walk_fast(const v16i (&acc)[RT][CT],
     if (COUNT && nl == 0) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) { on_end(ct, cnt[ct], k); cnt[ct] = 0; }
+    }
     }
   }
 }
@@ -465,8 +468,8 @@ dense_wide_kernel(DenseWideArgs a) {
     const bool straight = fast1 && a.nrn.vr == 0.0f && !a.u0 && !a.u_out;
     if (nb0 < NB) {
       if (straight) {
-        if (a.bn.mean) neuron_walk_fast<RT, CT, true, false>(acc, colmask, col, a.dq, a.bn, a.nrn.inv_k, a.nrn.vth, a.T, words, nothing3);
-        else neuron_walk_fast<RT, CT, false, false>(acc, colmask, col, a.dq, a.bn, a.nrn.inv_k, a.nrn.vth, a.T, words, nothing3);
+        if (a.bn.mean) neuron_walk_fast<RT, CT, true, false>(acc, colmask, col, a.dq, a.bn, a.nrn.inv_k, a.nrn.vth, a.T, a.SPH * a.T, words, nothing3);
+        else neuron_walk_fast<RT, CT, false, false>(acc, colmask, col, a.dq, a.bn, a.nrn.inv_k, a.nrn.vth, a.T, a.SPH * a.T, words, nothing3);
         mask_words<RT, CT>(words, colmask, a.T, a.SPH, nsamp);
       } else if (a.bn.mean) {
         if (fast1) neuron_walk<RT, CT, true, true>(acc, off, col_live, col, a.dq, a.bn, a.nrn, a.T, a.SPH, nsamp, b0, a.N, a.u0, a.u_out, h, words, nothing);
@@ -567,7 +570,7 @@ dense_wide_kernel(DenseWideArgs a) {
           if (j < a.SPH && s < nsamp && col2_live[0]) vbuf[s * 128 + col2[0]] = (float)cnt / Tf;
         };
         const unsigned long long colmask2[1] = {__ballot(col2_live[0])};
-        neuron_walk_fast<RT, 1, false, true>(acc2, colmask2, col2, a.dq2, nobn, a.nrn2.inv_k, a.nrn2.vth, a.T, words, sample_done);
+        neuron_walk_fast<RT, 1, false, true>(acc2, colmask2, col2, a.dq2, nobn, a.nrn2.inv_k, a.nrn2.vth, a.T, a.SPH * a.T, words, sample_done);
         mask_words<RT, 1>(words, colmask2, a.T, a.SPH, nsamp);
       } else {
         int cnt = 0;
