@@ -3,7 +3,8 @@
 //   SpikingBlock(QuantDense(K -> N1)) -> SpikingBlock(QuantDense(N1 -> N2)) -> vote
 //                                                                   (the whole head, ONE launch)
 // for int8 codes (flax_qdense.py:74-89 after the pack step) over uint8 rows read in place
-// (x - 128 against the codes, 128 * col_sum added back, see dense_mfma.hip) or bit-packed rows.
+// (x - 128 against the codes; the 128 * col_sum that gives the sum over x back is what the
+// accumulators start from) or bit-packed rows.
 //
 // What differs from dense_mfma.hip (128 columns per workgroup, two K groups, the int32 tile
 // transposed through LDS for the neuron):
@@ -21,7 +22,10 @@
 //    conv kernels: the ballot of a compare is the packed spike word of two samples;
 //  * the hidden raster stays in LDS as bits (2 KiB .. 8 KiB); the second block expands them to
 //    {0, 1} bytes as it reads its A fragments, runs the same neuron walk and leaves spike
-//    counts / T for the vote (models.py:253-255), which the workgroup finishes.
+//    counts / T for the vote (models.py:253-255), which the workgroup finishes;
+//  * batches that fill at most half the chip run TWO workgroups per tile of samples, 256 hidden
+//    columns each, which hand their halves of the hidden raster over through a caller workspace
+//    (write-through stores, a ticket; the last arriver runs the second block and the vote).
 //
 // K loop as in dense_fp6.hip: chunks of 128 k, three LDS images (chunk c computes from image
 // c mod 3 while chunk c + 2 is staged, the barrier waits with a counted lgkmcnt so that the
@@ -126,6 +130,7 @@ __device__ __forceinline__ bool wide_neuron(float &u, float x, const NeuronP &p,
 // The neuron of one wave's column tiles over the rows its lanes own: acc[r][ct] in the MFMA
 // C/D layout, half h walks its rows k = 0 .. 16 RT - 1 in order = (sample j = k / T, t = k % T).
 // words[]: bit-packed spikes, word (k, ct, half) in lane / register (k CT + ct) 2 + half.
+// per_update(ct, spike, t, sample, live): called after every update (the fused head counts with it).
 template <int RT, int CT, bool FASTN, bool HASBN, typename F>
 __device__ __forceinline__ void neuron_walk(const v16i (&acc)[RT][CT], const int (&off)[CT],
                                             const bool (&col_live)[CT], const int (&col)[CT],
@@ -133,7 +138,7 @@ __device__ __forceinline__ void neuron_walk(const v16i (&acc)[RT][CT], const int
                                             int T, int SPH, int nsamp, int b0, int N,
                                             const float *u0, float *u_out, int h,
                                             uint32_t (&words)[(16 * RT * CT * 2 + 63) / 64],
-                                            F &&on_last) {
+                                            F &&per_update) {
   float bmean[CT], bmul[CT], bbias[CT], dec[CT], u[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -163,7 +168,7 @@ __device__ __forceinline__ void neuron_walk(const v16i (&acc)[RT][CT], const int
       words[idx >> 6] = snnqp_writelane_i32((uint32_t)m, (uint32_t)(idx & 63), words[idx >> 6]);
       words[(idx + 1) >> 6] = snnqp_writelane_i32((uint32_t)(m >> 32), (uint32_t)((idx + 1) & 63),
                                                   words[(idx + 1) >> 6]);
-      on_last(ct, sp, t, s, slive);
+      per_update(ct, sp, t, s, slive);
     }
     if (t == T - 1 && u_out) {
 #pragma unroll
@@ -552,7 +557,7 @@ dense_wide_kernel(DenseWideArgs a) {
         }
       }
     }
-    wide_barrier();                                 // the raster has been read: vbuf may overlay nothing of it
+    wide_barrier();
     if (wave < NB2) {
       int off[1] = {0}, col2[1] = {wave * 32 + n};
       bool col2_live[1] = {col2[0] < a.N2};
