@@ -257,7 +257,9 @@ __device__ __forceinline__ void mask_words(uint32_t (&words)[(16 * RT * CT * 2 +
   for (int v = 0; v < (16 * RT * CT * 2 + 63) / 64; ++v) {
     const int idx = v * 64 + lane;
     const int hh = idx & 1, ct = (idx >> 1) % CT, k = idx / (2 * CT);
-    const int j = k / T;
+    // k / T without an integer division: k < 64, T <= 64, so (k + 0.5) / T is at least 1 / 128 away
+    // from an integer and the float quotient truncates to the right one
+    const int j = (int)(((float)k + 0.5f) * (1.0f / (float)T));
     uint32_t cw = (uint32_t)colmask[0];
 #pragma unroll
     for (int c = 1; c < CT; ++c) cw = ct == c ? (uint32_t)colmask[c] : cw;
