@@ -136,6 +136,19 @@ def layer_bits(args):
   return list(args.layer_bits) if args.layer_bits else [args.bits] * 4
 
 
+def issued_dtype(args, lb):
+  """The operand formats of the instruction the dominant kernel issues (not a precision claim:
+  every sum is an exact integer)."""
+  if args.model == "dense":
+    return "int8*int8->int32"
+  conv = [b for b in lb[1:3]]
+  if all(0 < b <= 4 for b in conv):
+    return "fp6*fp4->f32 (integer-exact)"
+  if all(not (0 < b <= 4) for b in conv):
+    return "int8*int8->int32"
+  return "fp6*fp4->f32 (integer-exact) / int8*int8->int32"
+
+
 def metric_name(args):
   if args.model == "dense":
     return "samples/sec/node (2-layer qdense 2048-512-%d, T=%d, %d-bit/%.4g%%-pruned)" % (
@@ -202,6 +215,106 @@ def launch_ranks(args, argv):
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
   return 0
+
+
+def build_model(args, dev):
+  """(model, variables on `dev`, variables as numpy) of the configuration `args` names."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune)
+  if args.layer_bits:
+    cfg.quant.layer_bits = tuple(args.layer_bits)
+  if args.model == "cextnet":
+    model = models.CextNet(num_classes=args.classes, config=cfg)
+    variables_np = syn.cextnet_variables(prune_p=args.prune, out=args.classes * 10,
+                                         random_bn=args.random_bn)
+  elif args.model == "dense":     # BASELINE config C2: the head of CextNet on its own
+    cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune, hidden=512)
+    model = models.DenseSNN(num_classes=args.classes, config=cfg)
+    variables_np = syn.dense_net_variables(2048, 512, args.classes * 10, True, args.prune)
+  else:
+    model = models.ConvDenseSNN(num_classes=args.classes, config=cfg)
+    variables_np = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10,
+                                          random_bn=args.random_bn)
+  return model, nn.tree_from_numpy(variables_np, dev), variables_np
+
+
+def build_input(args, dev, rank, B, T, hw, ops):
+  """(the resident batch in the format --input names, the same frames as uint8 | None)."""
+  import numpy as np
+  import torch
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(8627169 + rank)
+  p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
+  if args.model == "dense":                      # [B, T, 2048] binary spikes
+    x = (torch.rand((B, T, 2048), device=dev, generator=gen) < p_spike).to(torch.uint8)
+  elif args.counts:
+    x = torch.poisson(torch.full((B, T, hw, hw, 2), float(args.lam), device=dev),
+                      generator=gen).clamp_(max=255).to(torch.uint8)
+  else:
+    x = (torch.rand((B, T, hw, hw, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
+  frames_u8 = x if (args.model != "dense" and not args.stand_in) else None
+  if args.input == "bits":
+    x = ops.pack_bits(x)
+    torch.cuda.synchronize()
+  elif args.input == "f32":
+    x = x.to(torch.float32)
+  elif args.input in ("ev1", "ev4") and ops is not None and args.model != "dense":
+    from snnquantprune_amd import _lib as L_
+    x = ops.pack_frames(x, L_.EV1 if args.input == "ev1" else L_.EV4)
+    torch.cuda.synchronize()
+  return x, frames_u8
+
+
+def config_leg(base_args, overrides, dev, steps, warmup, capture):
+  """Another BASELINE configuration timed inside the default run (one GPU): the model and a
+  resident batch of its own, `warmup` + `steps` eager steps, optionally the same steps as a
+  hipGraph (nn.capture), then a pass with a HIP event pair around every launch for its rooflines."""
+  import copy
+  import torch
+  from snnquantprune_amd import linen as nn, ops
+  a = copy.copy(base_args)
+  for k, v in overrides.items():
+    setattr(a, k, v)
+  B, T = a.batch, a.frames
+  model, variables, _ = build_model(a, dev)
+  x, _ = build_input(a, dev, 0, B, T, 128, ops)
+
+  def step():
+    ops.forget_inputs()
+    return model.apply(variables, x, trgt=None, train=False, rng=None)[0]
+
+  def timed(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+      fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+  for _ in range(max(2, warmup)):
+    step()
+  dt = timed(step, steps)
+  leg = {"metric": metric_name(a), "dtype": issued_dtype(a, layer_bits(a)),
+         "config": {"batch_per_gpu": B, "frames": T, "bits": "/".join(str(b) for b in layer_bits(a)),
+                    "prune": a.prune, "classes": a.classes, "input": a.input, "model": a.model},
+         "steps": steps, "ms_per_step": dt * 1e3, "samples_per_s": B / dt,
+         "launch": "eager (one C call per block from Python)"}
+  if capture:
+    cap = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
+    for _ in range(3):
+      cap()
+    dtc = timed(cap, steps)
+    leg["captured"] = {"api": "nn.capture (one hipGraph launch per step)", "steps": steps,
+                       "ms_per_step": dtc * 1e3, "samples_per_s": B / dtc}
+    del cap
+  ops.profile_start()
+  for _ in range(min(steps, 50)):
+    step()
+  prof = ops.profile_stop()
+  leg.update(rooflines_of(a, prof, B, T, layer_bits(a), dict(ops.PROFILE_NOTES)))
+  leg["fallbacks"] = ops.fallback_counts()
+  leg["device_status"] = ops.device_status()
+  return leg
 
 
 def make_feeder(x_dev, dev, nbatches=4):
@@ -447,26 +560,11 @@ def main(argv=None):
     hw = 4
   else:
     from snnquantprune_amd import _lib, linen as nn
-    from snnquantprune_amd import models, ops, synthetic as syn
+    from snnquantprune_amd import ops
     build_flags = _lib.build_flags()
     if not args.allow_diag:
       _lib.require_product_build()
-    cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune)
-    if args.layer_bits:
-      cfg.quant.layer_bits = tuple(args.layer_bits)
-    if args.model == "cextnet":
-      model = models.CextNet(num_classes=args.classes, config=cfg)
-      variables_np = syn.cextnet_variables(prune_p=args.prune, out=args.classes * 10,
-                                           random_bn=args.random_bn)
-    elif args.model == "dense":     # BASELINE config C2: the head of CextNet on its own
-      cfg = syn.make_config(bits=args.bits, prune_percentage=args.prune, hidden=512)
-      model = models.DenseSNN(num_classes=args.classes, config=cfg)
-      variables_np = syn.dense_net_variables(2048, 512, args.classes * 10, True, args.prune)
-    else:
-      model = models.ConvDenseSNN(num_classes=args.classes, config=cfg)
-      variables_np = syn.conv_net_variables(prune_p=args.prune, out=args.classes * 10,
-                                            random_bn=args.random_bn)
-    variables = nn.tree_from_numpy(variables_np, dev)
+    model, variables, variables_np = build_model(args, dev)
 
     def apply_fn(xb):
       (logits, _) = model.apply(variables, xb, trgt=None, train=False, rng=None)
@@ -474,26 +572,8 @@ def main(argv=None):
     hw = 128
 
   # synthetic Poisson-spike DVS frames, resident in HBM before the timed region
-  gen = torch.Generator(device=dev)
-  gen.manual_seed(8627169 + rank)
   p_spike = 1.0 - float(np.exp(-args.lam))       # P(Poisson(lam) > 0)
-  if args.model == "dense":                      # [B, T, 2048] binary spikes
-    x = (torch.rand((B, T, 2048), device=dev, generator=gen) < p_spike).to(torch.uint8)
-  elif args.counts:
-    x = torch.poisson(torch.full((B, T, hw, hw, 2), float(args.lam), device=dev),
-                      generator=gen).clamp_(max=255).to(torch.uint8)
-  else:
-    x = (torch.rand((B, T, hw, hw, 2), device=dev, generator=gen) < p_spike).to(torch.uint8)
-  frames_u8 = x if (args.model != "dense" and not args.stand_in) else None
-  if args.input == "bits":
-    x = ops.pack_bits(x)
-    torch.cuda.synchronize()
-  elif args.input == "f32":
-    x = x.to(torch.float32)
-  elif args.input in ("ev1", "ev4") and ops is not None and args.model != "dense":
-    from snnquantprune_amd import _lib as L_
-    x = ops.pack_frames(x, L_.EV1 if args.input == "ev1" else L_.EV4)
-    torch.cuda.synchronize()
+  x, frames_u8 = build_input(args, dev, rank, B, T, hw, ops)
 
   feeder = None
   if args.feed == "host":
@@ -522,22 +602,19 @@ def main(argv=None):
   import gc
   gc.collect()
   gc.freeze()
-  # the per-kernel HIP events are part of the timed steps: create them in the warm-up steps as
-  # well (the first timing event of a process costs tens of milliseconds on a cold box)
+  # The per-kernel HIP events stay OUT of the timed steps (they cost 0.8 % there, round 4): the
+  # warm-up creates them once (the first timing event of a process costs tens of milliseconds on
+  # a cold box), the timed region runs bare, and a second pass of the same K steps right after it
+  # carries the events the rooflines are computed from.
   if ops is not None:
     ops.profile_start()
   out = None
   for i in range(args.warmup):
-    if args.graph and ops is not None and i > 0 and i == (args.warmup + 1) // 2:
-      ops.profile_stop()          # --graph: kernel times from the second half of the warm-up
-      ops.profile_start()
     out = step()
   fence()
-  prof_warm = None
   if ops is not None:
-    prof_warm = ops.profile_stop()
-    if not args.graph:
-      ops.profile_start()
+    ops.profile_stop()
+  eager_step = step
   if args.graph:
     assert gpu and ops is not None and args.warmup > 0, "--graph needs a GPU and a warm-up step"
     # the product API: nn.capture records model.apply once (linen.CapturedApply)
@@ -563,8 +640,15 @@ def main(argv=None):
   if trace and rank == 0:
     print("enqueue done at (ms):", [round(m * 1e3, 2) for m in marks], "all done", round(dt * 1e3, 2),
           file=sys.stderr)
-  # {tag: (launches, total ms)}: from the timed steps, or from the eager warm-up under --graph
-  prof = (prof_warm if args.graph else ops.profile_stop()) if ops is not None else {}
+  # {tag: (launches, total ms)}: a second pass of the same steps, launched eagerly with a HIP event
+  # pair around every block's launch on its stream
+  prof = {}
+  if ops is not None:
+    ops.profile_start()
+    for _ in range(args.steps):
+      eager_step()
+    fence()
+    prof = ops.profile_stop()
   assert out.shape == (world * B, args.classes), out.shape
   if args.stand_in:
     # every rank's rows arrived, in rank order: row r*B of the gathered logits is rank r's first
@@ -674,11 +758,13 @@ def main(argv=None):
       "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
       "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-      "dtype": "int8",
-      "dtype_detail": "integer codes x integer inputs, exact sums: conv0/dense int8 x u8/binary -> "
-                      "int32 (i8 MFMA); conv1-2 the same integers as fp6 codes x fp4 spikes -> f32 "
-                      "(f8f6f4 MFMA, sums < 2^24 exact) when the codes fit (<= 4 bits), else int8; "
-                      "membrane potentials f32",
+      "dtype": issued_dtype(args, lb),
+      "dtype_detail": "the operand formats the dominant kernel issues; the arithmetic is integer and "
+                      "exact throughout: codes of magnitude <= 7 (DuQ up to 4 bits) as fp6 (e2m3) x "
+                      "spikes as fp4 (e2m1) on v_mfma_scale_f32_32x32x64_f8f6f4, sums < 2^24 exact in the "
+                      "f32 accumulator (conv1, conv2, read-out); wider codes and conv0 / the C2 head as "
+                      "int8 x int8 (u8 counts as x - 128) -> int32 on v_mfma_i32_32x32x32_i8; membrane "
+                      "potentials f32",
       "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
               % args.lam + {"ev1": " as bit-packed frames (EV1, include/snnqp.h)", "ev4": " as nibble-packed "
                             "frames (EV4)", "u8": " as uint8 frames", "f32": " as float32 frames",
@@ -713,7 +799,7 @@ def main(argv=None):
     line["fallbacks"].update(ops.workqueue_stats())   # static patch walks, arithmetic instead of table dequantisation
     line["device_status"] = ops.device_status()       # 0: no kernel reported a broken invariant
   if args.graph:
-    line["config"]["launch"] = "hipGraph replay of model.apply (kernel times from the eager warm-up)"
+    line["config"]["launch"] = "hipGraph replay of model.apply (kernel times from an eager pass)"
   if build_flags or os.environ.get("SNNQP_DIAG_LIB"):
     line["DIAGNOSTIC_BUILD"] = build_flags or os.environ.get("SNNQP_DIAG_LIB")
   if args.stand_in:
@@ -751,6 +837,23 @@ def main(argv=None):
       line["parity_vs_float"] = dict(json.load(f).get("summary") or {},
                                      source="committed %s (CPU, oracle int vs float mode; not "
                                             "measured in this run)" % os.path.relpath(PARITY_VS_FLOAT, ROOT))
+  # the other single-GPU BASELINE configurations, timed in the same run: C2 as
+  # BASELINE.json configs[1] names it (B = 256, T = 20, 8-bit, 50 % pruned; uint8 rows) and C5's
+  # per-GPU share (B = 512, T = 50, mixed 2/4-bit, 95 % pruned, 10 classes; EV1 frames)
+  default_headline = (world == 1 and args.model == "c3" and args.input == "ev1" and B == 1024 and T == 20
+                      and not args.layer_bits and args.bits == 4 and not args.counts and not args.random_bn
+                      and args.feed == "resident" and not args.no_fed_leg and not args.graph)
+  if default_headline:
+    del x, frames_u8
+    torch.cuda.empty_cache()
+    line["legs"] = {
+        "c2": config_leg(args, dict(model="dense", batch=256, frames=20, bits=8, prune=0.5, input="u8",
+                                    layer_bits=None, classes=11), dev, 200, 20, True),
+        "c2_b4096": config_leg(args, dict(model="dense", batch=4096, frames=20, bits=8, prune=0.5,
+                                          input="u8", layer_bits=None, classes=11), dev, 50, 5, False),
+        "c5": config_leg(args, dict(model="c3", batch=512, frames=50, bits=4, prune=0.95, input="ev1",
+                                    layer_bits=[2, 4, 2, 4], classes=10), dev, args.steps, 3, False),
+    }
   if world == 1 and not args.no_cpu_baseline and args.model == "c3":
     line["cpu_baseline"] = cpu_baseline(args, variables_np)
   print(json.dumps(line))
