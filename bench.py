@@ -49,7 +49,7 @@ PMC_SUMMARY = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_summary.json
                                                            "r02_pmc_summary.json")]
 # int-vs-float deviation of the numeric contract (tools/int_vs_float.py, CPU), committed
 PARITY_VS_FLOAT = next((p for p in (os.path.join(ROOT, "profiles", n) for n in
-                                    ("r04_int_vs_float.json", "r02_int_vs_float.json"))
+                                    ("r05_int_vs_float.json", "r04_int_vs_float.json", "r02_int_vs_float.json"))
                         if os.path.exists(p)), os.path.join(ROOT, "profiles", "r02_int_vs_float.json"))
 
 

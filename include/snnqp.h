@@ -173,7 +173,7 @@ int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build
  * (snnquantprune_amd/csrc/build.py); diagnostic builds (tools/diag_build.py, written
- * under build/diag/, never in-tree) report their -D switches here.  Tests and bench.py
+ * under diag_build/, never in-tree) report their -D switches here.  Tests and bench.py
  * refuse a library whose string is not empty. */
 const char *snnqp_build_flags(void);
 
@@ -370,9 +370,11 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
  * tile of rows (the read-out of config C3: 32768 -> 110 gives 256 workgroups of 80 rows too few
  * rows to amortise the 3 MB of codes each of them streams; two workgroups of 160 rows per tile
  * stream half each), handing partial sums over through `ws`.  ws: device memory, 256-byte
- * aligned, at least snnqp_dense_workspace_bytes(...) bytes, ZERO when first used and used by one
- * launch at a time (the kernel leaves it reusable: its tickets are zero again at the end of a
- * launch).  ws = NULL or too small: no split, as snnqp_dense_lif_forward.
+ * aligned, at least snnqp_dense_workspace_bytes(...) bytes, used by one launch at a time (its
+ * content need not survive between launches: the call zeroes the tickets at its head on `stream`
+ * in front of the kernel -- a kernel node when the stream is being captured -- so that nothing an
+ * earlier launch, an aborted replay or a stray store left there can reach this one).
+ * ws = NULL or too small: no split, as snnqp_dense_lif_forward.
  * snnqp_dense_workspace_bytes returns 0 when the split would not be used. */
 int64_t snnqp_dense_workspace_bytes(int in_type, int32_t T, int32_t B, int32_t K, int32_t N,
                                     const snnqp_weight_t *w);
@@ -400,9 +402,9 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
  *       snnqp_dense_lif_forward writes them (the hidden raster otherwise never leaves the CU).
  * Membrane potentials start from zero (initialize_carry, spiking_learning.py:464-472) and are
  * not returned: a caller that carries state uses snnqp_dense_lif_forward per block.
- * ws / ws_bytes  nullable workspace (device memory, 256-byte aligned, ZERO when first used, one
- *       launch at a time; snnqp_dense_head_workspace_bytes says how much, 0 = it would not be
- *       used).  With it a batch that fills at most half the chip (config C2: B = 256) runs as two
+ * ws / ws_bytes  nullable workspace (device memory, 256-byte aligned, one launch at a time; its
+ *       tickets are zeroed on `stream` by every call, as for snnqp_dense_lif_forward_ws;
+ *       snnqp_dense_head_workspace_bytes says how much, 0 = it would not be used).  With it a batch that fills at most half the chip (config C2: B = 256) runs as two
  *       workgroups per tile of samples, each with half of the hidden columns -- half of the first
  *       block's codes through a CU's L1, the bound of the launch -- which hand their halves of the
  *       hidden raster over through `ws`; the last arriver runs the second block and the vote.

@@ -14,6 +14,14 @@ current -- BatchNorm, spiking_learning.py:410-414 -- is the same float32 op sequ
 membrane potential can differ by a few ulp of the current and a spike can flip only where the
 potential sits within that distance of the threshold.
 
+One summation order with no flips does not bound another, and XLA's order is
+unknown.  The forced comparison is therefore repeated under a family of float32 accumulation
+orders, installed through snn_oracle.FLOAT_MATMUL: BLAS on the natural K order, BLAS on
+`--perms` random permutations of K (different blockings and SIMD-lane groupings of the same
+products), one strictly sequential chain (k ascending: what a naive loop or an fma chain does)
+and a leaf-1 pairwise tree (the other extreme: the most parallel order).  `summary` reports the
+maxima OVER ALL ORDERS; the expensive orders (sequential, tree) run on fewer samples, stated.
+
 Per layer, at BASELINE size (C3: [B, 20, 128, 128, 2], 4-bit, 90 % pruned; C2: 2048 -> 512
 -> 110, 8-bit, 50 % pruned, B = 256) this reports
   forced   the layer run in both modes on the SAME input raster (the int-mode one):
@@ -37,6 +45,73 @@ if ROOT not in sys.path:
 from oracle import snn_oracle as o  # noqa: E402
 
 F32 = np.float32
+
+
+# ---- float32 accumulation orders (a [M, K] float32, w [K, N] float32 -> [M, N] float32) --------
+
+def order_perm(seed):
+  """BLAS over a random permutation of K."""
+  def f(a, w):
+    p = np.random.Generator(np.random.PCG64(seed * 1000003 + a.shape[1])).permutation(a.shape[1])
+    return np.ascontiguousarray(a[:, p]) @ np.ascontiguousarray(w[p])
+  return f
+
+
+def order_sequential(a, w, budget=96 << 20):
+  """acc = fl(acc + fl(a[:, k] * w[k])), k ascending: one chain per output."""
+  M, K = a.shape
+  N = w.shape[1]
+  out = np.empty((M, N), F32)
+  step = max(1, budget // (4 * N))
+  for r0 in range(0, M, step):
+    ac = a[r0:r0 + step]
+    acc = np.zeros((ac.shape[0], N), F32)
+    live = np.flatnonzero(ac.any(axis=0))        # x + fl(0 * w) = x: columns of zeros change nothing
+    for k in live:
+      acc += ac[:, k, None] * w[k][None, :]
+    out[r0:r0 + step] = acc
+  return out
+
+
+def order_tree(a, w, budget=192 << 20):
+  """Leaf-1 pairwise tree over K (zero-padded to a power of two): (p0 + p1) + (p2 + p3) ..."""
+  M, K = a.shape
+  N = w.shape[1]
+  K2 = 1 << max(0, (K - 1).bit_length())
+  out = np.empty((M, N), F32)
+  step = max(1, budget // (4 * N * K2))
+  for r0 in range(0, M, step):
+    ac = a[r0:r0 + step]
+    prod = np.zeros((ac.shape[0], K2, N), F32)
+    np.multiply(ac[:, :, None], w[None, :, :], out=prod[:, :K])
+    while prod.shape[1] > 1:
+      prod = prod[:, 0::2] + prod[:, 1::2]
+    out[r0:r0 + step] = prod[:, 0]
+  return out
+
+
+def make_orders(perms=8, cheap_samples=16, seq_samples=2, tree_samples=1):
+  """name -> (matmul | None for plain BLAS, C3 samples it runs on)."""
+  orders = {"blas": (None, cheap_samples)}
+  for i in range(perms):
+    orders["blas_perm%d" % i] = (order_perm(i + 1), cheap_samples)
+  if seq_samples > 0:
+    orders["sequential"] = (order_sequential, seq_samples)
+  if tree_samples > 0:
+    orders["pairwise_tree"] = (order_tree, tree_samples)
+  return orders
+
+
+class _float_order:
+  def __init__(self, fn):
+    self.fn = fn
+
+  def __enter__(self):
+    self.old, o.FLOAT_MATMUL = o.FLOAT_MATMUL, self.fn
+
+  def __exit__(self, *exc):
+    o.FLOAT_MATMUL = self.old
+    return False
 
 
 def _u_error(u_int, u_flt, s_int, s_flt):
@@ -63,7 +138,18 @@ def _flip(s_a, s_b):
   return {"flips": k, "of": int(n), "rate": k / n if n else 0.0}
 
 
-def c3_report(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=4, lam=0.1, seed=4242):
+def _merge_order(acc, layer, f, ue):
+  d = acc.setdefault(layer, {"flips": 0, "neuron_steps": 0, "u_max_abs": 0.0, "u_max_rel": 0.0,
+                             "u_max_rel_to_threshold": 0.0, "u_p999_rel": 0.0})
+  d["flips"] += f["flips"]
+  d["neuron_steps"] += f["of"]
+  if ue.get("neurons"):
+    for k_src, k_dst in (("max_abs", "u_max_abs"), ("max_rel", "u_max_rel"),
+                         ("max_rel_to_threshold", "u_max_rel_to_threshold"), ("p999_rel", "u_p999_rel")):
+      d[k_dst] = max(d[k_dst], ue[k_src])
+
+
+def c3_report(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=4, lam=0.1, seed=4242, orders=None):
   from snnquantprune_amd import synthetic as syn
   from tests.helpers import bn_of, qweight_of
   v = syn.conv_net_variables(hw=hw, prune_p=prune) if hw == 128 else \
@@ -78,6 +164,7 @@ def c3_report(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=4, lam=0.1,
   logits_equal = argmax_equal = 0
   logit_max_diff = 0.0
   rates = {n: [] for n in names}
+  by_order = {}
   for b0 in range(0, samples, chunk):
     nb = min(chunk, samples - b0)
     x = syn.poisson_spikes((nb, frames, hw, hw, 2), lam, seed=seed + b0)
@@ -87,7 +174,16 @@ def c3_report(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=4, lam=0.1,
     xi = np.swapaxes(x, 0, 1)
     for i in range(3):
       ui, si = o.conv_block(xi, cq[i], bns[i], None, "int")
+      for oname, (ofn, onum) in (orders or {}).items():
+        if ofn is None or b0 >= onum:
+          continue
+        k = min(nb, onum - b0)                    # the first `onum` samples, in time-major layout
+        with _float_order(ofn):
+          uo, so = o.conv_block(xi[:, :k], cq[i], bns[i], None, "float")
+        _merge_order(by_order.setdefault(oname, {}), names[i], _flip(si[:, :k], so), _u_error(ui[:k], uo, si[:, :k], so))
+        del uo, so
       uf, sf = o.conv_block(xi, cq[i], bns[i], None, "float")
+      _merge_order(by_order.setdefault("blas", {}), names[i], _flip(si, sf), _u_error(ui, uf, si, sf))
       f = _flip(si, sf)
       forced[names[i]]["flips"] += f["flips"]; forced[names[i]]["of"] += f["of"]
       forced[names[i]]["u"].append(_u_error(ui, uf, si, sf))
@@ -98,7 +194,15 @@ def c3_report(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=4, lam=0.1,
       del ui, uf, sf
     xf = o.flatten_channel_major(xi)
     ui, si = o.dense_block(xf, dq, None, "int")
+    for oname, (ofn, onum) in (orders or {}).items():
+      if ofn is None or b0 >= onum:
+        continue
+      k = min(nb, onum - b0)
+      with _float_order(ofn):
+        uo, so = o.dense_block(xf[:, :k], dq, None, "float")
+      _merge_order(by_order.setdefault(oname, {}), "dense", _flip(si[:, :k], so), _u_error(ui[:k], uo, si[:, :k], so))
     uf, sf = o.dense_block(xf, dq, None, "float")
+    _merge_order(by_order.setdefault("blas", {}), "dense", _flip(si, sf), _u_error(ui, uf, si, sf))
     f = _flip(si, sf)
     forced["dense"]["flips"] += f["flips"]; forced["dense"]["of"] += f["of"]
     forced["dense"]["u"].append(_u_error(ui, uf, si, sf))
@@ -127,10 +231,11 @@ def c3_report(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=4, lam=0.1,
   out["logits_bit_equal"] = "%d/%d" % (logits_equal, samples)
   out["argmax_equal"] = "%d/%d" % (argmax_equal, samples)
   out["logits_max_abs_diff"] = logit_max_diff
+  out["forced_by_order"] = by_order
   return out
 
 
-def c2_report(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, seed=4343):
+def c2_report(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, seed=4343, orders=None):
   from snnquantprune_amd import synthetic as syn
   from tests.helpers import qweight_of
   v = syn.dense_net_variables(K, hidden, nout, True, prune)
@@ -140,6 +245,13 @@ def c2_report(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, seed
   ri = o.dense2_forward(x, q1, q2, mode="int")
   rf = o.dense2_forward(x, q1, q2, mode="float")
   u2f, s2f = o.dense_block(ri["s1"], q2, None, "float")      # layer 2 forced onto int input
+  by_order = {}
+  for oname, (ofn, _) in (orders or {"blas": (None, 0)}).items():
+    with _float_order(ofn):
+      u1o, s1o = o.dense_block(x, q1, None, "float")
+      u2o, s2o = o.dense_block(ri["s1"], q2, None, "float")
+    _merge_order(by_order.setdefault(oname, {}), "dense1", _flip(ri["s1"], s1o), _u_error(ri["u1"], u1o, ri["s1"], s1o))
+    _merge_order(by_order.setdefault(oname, {}), "dense2", _flip(ri["s2"], s2o), _u_error(ri["u2"], u2o, ri["s2"], s2o))
   out = {"config": "C2: qdense(%d->%d)+LIF -> qdense(%d->%d)+LIF, T=%d, B=%d, %d-bit, %g%% pruned"
                    % (K, hidden, hidden, nout, T, B, bits, prune * 100),
          "layers": {
@@ -154,15 +266,41 @@ def c2_report(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, seed
          "logits_bit_equal": "%d/%d" % (int(np.count_nonzero(np.all(ri["logits"] == rf["logits"], 1))), B),
          "argmax_equal": "%d/%d" % (int(np.count_nonzero(np.argmax(ri["logits"], 1) ==
                                                          np.argmax(rf["logits"], 1))), B),
-         "logits_max_abs_diff": float(np.abs(ri["logits"] - rf["logits"]).max())}
+         "logits_max_abs_diff": float(np.abs(ri["logits"] - rf["logits"]).max()),
+         "forced_by_order": by_order}
   return out
 
 
 def summarize(c3, c2):
   lay = {**{"C3." + k: v for k, v in c3["layers"].items()},
          **{"C2." + k: v for k, v in c2["layers"].items()}}
+  ob = {}
+  for cfg, rep in (("C3", c3), ("C2", c2)):
+    for oname, layers in (rep.get("forced_by_order") or {}).items():
+      for lname, d in layers.items():
+        ob.setdefault(oname, {})[cfg + "." + lname] = d
+  every = [d for layers in ob.values() for d in layers.values()]
+  over_orders = {}
+  if every:
+    over_orders = {
+        "orders": sorted(ob),
+        "neuron_steps_by_order": {k: int(sum(d["neuron_steps"] for d in v.values())) for k, v in sorted(ob.items())},
+        "max_flip_rate_over_orders": max(d["flips"] / max(d["neuron_steps"], 1) for d in every),
+        "total_flips_over_orders": int(sum(d["flips"] for d in every)),
+        # the two scales, named: error / max(|u|, v_th = 1) -- what decides a spike -- and the pure
+        # relative error error / |u| over potentials with |u| >= 0.01
+        "max_u_err_rel_to_max_absu_vth_over_orders": max(d["u_max_rel_to_threshold"] for d in every),
+        "max_u_err_pure_rel_over_orders": max(d["u_max_rel"] for d in every),
+        "p999_u_err_pure_rel_over_orders": max(d["u_p999_rel"] for d in every),
+        "max_u_err_abs_over_orders": max(d["u_max_abs"] for d in every),
+        "worst_order_by_pure_rel": max(ob, key=lambda k: max(d["u_max_rel"] for d in ob[k].values()))}
   return {"what": "oracle 'int' mode (the kernels' contract, bit-exact on the GPU) against the "
                   "reference-literal float32 mode, CPU, BASELINE sizes; forced = same input raster",
+          "north_star_tolerance": "1e-5 relative for membrane potentials: met on the scale "
+                                  "max(|u|, v_th) (max_u_err_rel_to_max_absu_vth_*); the PURE relative "
+                                  "error |du| / |u| (max_u_err_pure_rel_*) exceeds it on potentials of a "
+                                  "few 1e-2 whose absolute error is below 1e-6",
+          "over_orders": over_orders,
           "samples_c3": c3["samples"],
           "max_forced_flip_rate": max(v["forced_flip_rate"] for v in lay.values()),
           "max_free_flip_rate": max(v["free_flip_rate"] for v in lay.values()),
@@ -176,13 +314,18 @@ def summarize(c3, c2):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--samples", type=int, default=8)
+  ap.add_argument("--perms", type=int, default=8, help="random K permutations under BLAS")
+  ap.add_argument("--seq-samples", type=int, default=2, help="C3 samples under the sequential order")
+  ap.add_argument("--tree-samples", type=int, default=1, help="C3 samples under the pairwise-tree order")
   ap.add_argument("--out", default=None)
   args = ap.parse_args()
   t0 = time.time()
-  c3 = c3_report(args.samples)
-  c2 = c2_report()
+  orders = make_orders(args.perms, args.samples, args.seq_samples, args.tree_samples)
+  c3 = c3_report(args.samples, orders=orders)
+  c2 = c2_report(orders=orders)
   rep = {"summary": summarize(c3, c2), "c3": c3, "c2": c2, "seconds": round(time.time() - t0, 1),
-         "generated_by": "python -m oracle.int_vs_float --samples %d" % args.samples}
+         "generated_by": "python -m oracle.int_vs_float --samples %d --perms %d --seq-samples %d --tree-samples %d"
+                         % (args.samples, args.perms, args.seq_samples, args.tree_samples)}
   txt = json.dumps(rep, indent=1, sort_keys=True)
   print(txt)
   if args.out:

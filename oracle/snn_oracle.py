@@ -388,6 +388,17 @@ def dense_acc(x, qw: QWeight):
   return acc.reshape(lead + (qw.q.shape[-1],))
 
 
+# The summation order of the 'float' mode.  The reference's order is whatever XLA's CPU backend
+# picks (flax_qconv.py:158-168, flax_qdense.py:87-89) and cannot be observed here; the default
+# stand-in is BLAS.  oracle/int_vs_float.py installs other orders (K permuted, strictly sequential,
+# pairwise tree) to bound how much ANY order can move a potential or flip a spike.
+FLOAT_MATMUL = None
+
+
+def float_matmul(a, w):
+  return (a @ w) if FLOAT_MATMUL is None else FLOAT_MATMUL(a, w)
+
+
 def quant_dense(x, qw: QWeight, mode: str = "int"):
   """QuantDense.__call__ without bias, flax_qdense.py:58-89."""
   x = np.asarray(x)
@@ -399,7 +410,7 @@ def quant_dense(x, qw: QWeight, mode: str = "int"):
   elif mode == "fseq":
     y = fseq_matmul(x2.astype(F32), qw.w_fq)
   elif mode == "float":
-    y = x2.astype(F32) @ qw.w_fq
+    y = float_matmul(x2.astype(F32), qw.w_fq)
   else:
     raise ValueError(mode)
   return y.reshape(lead + (qw.w_fq.shape[-1],)).astype(F32)
@@ -509,7 +520,7 @@ def quant_conv(x, qw: QWeight, strides=None, padding="SAME", input_dilation=None
     elif mode == "fseq":
       yg = fseq_matmul(c2.astype(F32), qw.w_fq.reshape(-1, cout)[:, sl])
     elif mode == "float":
-      yg = c2.astype(F32) @ qw.w_fq.reshape(-1, cout)[:, sl]
+      yg = float_matmul(c2.astype(F32), np.ascontiguousarray(qw.w_fq.reshape(-1, cout)[:, sl]))
     else:
       raise ValueError(mode)
     outs.append(yg.reshape(lead + (og,)))

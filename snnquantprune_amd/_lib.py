@@ -139,7 +139,7 @@ def lib():
   """Loads libsnnqp.so once; raises if it is missing (no CPU fallback).
 
   SNNQP_DIAG_LIB=<path> loads a diagnostic build (tools/diag_build.py writes them under
-  build/diag/, never over the in-tree library) instead, and says so on stderr; such a
+  diag_build/, never over the in-tree library) instead, and says so on stderr; such a
   library reports its switches in snnqp_build_flags() and `require_product_build()`
   (tests, bench.py's default run) refuses it."""
   global _lib

@@ -30,7 +30,7 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
   """The product build: fixed flags, in-tree objects.  Diagnostic / A-B builds never come
-  through here (tools/diag_build.py compiles them into build/diag/<name>/)."""
+  through here (tools/diag_build.py compiles them into diag_build/<name>/)."""
   hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
   headers = [os.path.join(HERE, h) for h in ("common.h", "kernels.h", "conv_tile.h")]
   headers.append(os.path.join(HERE, "..", "..", "include", "snnqp.h"))

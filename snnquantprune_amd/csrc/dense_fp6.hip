@@ -57,7 +57,7 @@ struct DenseFp6Args {
   uint32_t *s_out;
   // K split over workgroups (blockIdx.z): partial tiles and tickets in a caller-owned workspace
   int32_t ksplit, gcz;           // workgroups per tile; group-chunks of one of them
-  uint32_t *tickets;             // [tiles] zero between launches (the last arriver resets its own)
+  uint32_t *tickets;             // [tiles], zeroed on the stream in front of every launch (run_dense_fp6)
   float *slabs;                  // [tiles][ksplit][ROWS * 128]
   uint32_t *status;              // the device's status word (runtime.hip), or null
 };
@@ -373,7 +373,6 @@ dense_fp6_kernel(DenseFp6Args a) {
       const uint32_t ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ticket >= (uint32_t)a.ksplit && a.status) *(volatile uint32_t *)a.status = SNNQP_STATUS_TICKET;
       const bool last = ticket + 1u == (uint32_t)a.ksplit;
-      if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
       *flag = last ? 1u : 0u;
     }
     __syncthreads();
@@ -520,8 +519,12 @@ int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t 
     const int64_t tiles = (int64_t)gx * gy;
     a.tickets = (uint32_t *)ws;
     a.slabs = (float *)((uint8_t *)ws + F6_TICKET_BYTES);
-    (void)tiles;
     a.status = device_status_word(stream_device(st));
+    // the tickets are zeroed on the stream in front of EVERY launch (a kernel node when the stream
+    // is being captured: zero_words_async, kernels.h): whatever an earlier launch, an aborted replay or a stray store left in
+    // them, this launch starts from zero (cdna_hip_programming.md, hand-off recipe: "zero the
+    // counter per call; a reset by the last arriver alone fails the first, poisoned launch")
+    if (int rc = zero_words_async((uint32_t *)ws, tiles, st)) return rc;
   }
   switch (rt) {
     case 5: launch_dense_fp6<5>(a, gx, gy, st); break;

@@ -81,7 +81,7 @@ struct DenseWideArgs {
   // fused head with the hidden columns split over two workgroups per tile (blockIdx.y): each
   // leaves its half of the hidden raster in the workspace, the last arriver runs the rest
   int32_t csplit;
-  uint32_t *hs_tickets;           // [tiles], zero between launches
+  uint32_t *hs_tickets;           // [tiles], zeroed on the stream in front of every launch
   uint32_t *hs_raster;            // [tiles][2][ROWS][8 words]
   uint32_t *status;               // the device's status word (runtime.hip), or null
 };
@@ -527,7 +527,6 @@ dense_wide_kernel(DenseWideArgs a) {
         const uint32_t ticket = __hip_atomic_fetch_add(a.hs_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket >= 2u && a.status) *(volatile uint32_t *)a.status = SNNQP_STATUS_TICKET;
         const bool last = ticket == 1u;
-        if (last) __hip_atomic_store(a.hs_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *flag = last ? 1u : 0u;
       }
       __syncthreads();
@@ -722,6 +721,8 @@ static int fill_and_launch(DenseWideArgs &a, int in_type, bool fuse, void *ws, i
     a.hs_tickets = (uint32_t *)ws;
     a.hs_raster = (uint32_t *)((uint8_t *)ws + W_TICKET_BYTES);
     a.status = device_status_word(stream_device(st));
+    // zeroed on the stream in front of every launch (dense_fp6.hip: a kernel node under capture)
+    if (int rc = zero_words_async((uint32_t *)ws, (int64_t)p.gx, st)) return rc;
   }
   const int rt = p.rt;
   const unsigned gx = p.gx, gy = p.gy;

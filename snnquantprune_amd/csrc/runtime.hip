@@ -57,6 +57,22 @@ struct RtDeviceGuard {
   }
 };
 
+}  // namespace
+
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t *p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+
+int zero_words_async(uint32_t *p, int64_t nwords, hipStream_t st) {
+  if (!p || nwords <= 0) return SNNQP_OK;
+  const int64_t blocks = (nwords + 255) / 256;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, p, nwords);
+  SNNQP_CHECK_LAUNCH("zero_words_kernel");
+  return SNNQP_OK;
+}
+
+namespace {
+
 // One wave: A = all 1.0 (fp4), B = fp6 codes of the lane's column, PROBE_CHAIN MFMAs of K = 64
 // with the block scales of DQ_TABLE (2^-63 * 2^-84 = 2^-147 per spike x code unit = 4 denormal
 // steps), the chain started from the bit pattern 4 * off.  out[lane][i] = accumulator bits.

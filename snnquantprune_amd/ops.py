@@ -776,15 +776,21 @@ _dense_ws = {}
 
 
 def _dense_workspace(dev, nbytes: int):
-  """The zero-filled workspace of the split-K dense kernel on `dev` and the current stream
-  (snnqp.h: one launch at a time; launches of one stream are), grown as needed, or None."""
+  """The workspace of a dense launch that hands partial results over between workgroups
+  (snnqp.h: used by one launch at a time; the call zeroes its tickets on the stream), or None.
+
+  Eager launches share one per (device, stream) -- launches of one stream run one after the
+  other -- grown as needed.  A launch that is being captured into a hipGraph gets a workspace of
+  its OWN, allocated inside the capture, i.e. from the graph's private memory pool: the address
+  baked into the graph lives exactly as long as the graph, is never handed to an eager launch and
+  never to another graph (two live captures replayed on two streams cannot meet in one)."""
   if nbytes <= 0:
     return None
+  if torch.cuda.is_current_stream_capturing():
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
   key = (torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream)
   ws = _dense_ws.get(key)
   if ws is None or ws.numel() < nbytes:
-    if torch.cuda.is_current_stream_capturing():
-      return None                       # nothing may be allocated inside a capture: no split
     ws = _dense_ws[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
   return ws
 

@@ -3019,3 +3019,88 @@ def test_dense_snn_prepared_head_follows_its_parameters(dev, oracle):
   e4 = cases.dense_net_expected(oracle, dict(c, bits=4))
   np.testing.assert_array_equal(_np(m4.apply(variables3, x, trgt=None, train=False, rng=None)[0]), e4["logits"])
   np.testing.assert_array_equal(_np(model.apply(variables3, x, trgt=None, train=False, rng=None)[0]), e["logits"])
+
+
+def test_poisoned_tickets_cannot_reach_a_launch(dev, oracle):
+  """The two in-launch hand-overs (the fused head's column split, the read-out's K split) count
+  arrivals in ticket words at the head of a workspace.  A word that is not zero when a launch
+  begins would make a workgroup believe it is the last arriver before the others have stored
+  (value 1: nothing could detect that) or nobody believe it (value 7, 0xFFFFFFFF).  Every call
+  therefore zeroes the tickets on its stream in front of the kernel (snnqp.h):
+  here every ticket of the cached workspace is poisoned between launches, and the next launch is
+  the oracle's, bit for bit, with nothing reported."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  assert ops.device_status() == 0
+  # the fused head, column split (B = 40: 20 tiles of two samples, two workgroups each)
+  T, B, K, N1, N2 = 20, 40, 512, 512, 110
+  c = cases.dense_net_case(True, T=T, B=B, K=K, hidden=N1, out=N2)
+  p = c["vars"]["params"]
+  x = np.ascontiguousarray(np.swapaxes(c["x"], 0, 1))
+  e = oracle.dense2_forward(x, qweight_of(oracle, p["QuantDense_0"], 8), qweight_of(oracle, p["QuantDense_1"], 8),
+                            mode="int")
+  w1 = _weight(p["QuantDense_0"], 8, dev, transposed=True)
+  w2 = _weight(p["QuantDense_1"], 8, dev, transposed=True)
+  xd = _t(x, dev)
+  assert int(L.lib().snnqp_dense_head_workspace_bytes(T, B, N1)) > 0, "this shape is meant to split"
+
+  def head():
+    return _np(ops.dense_head_forward(xd, w1, K, N1, _mslif(), w2, N2, _mslif(), group=10)[0])
+  np.testing.assert_array_equal(head(), e["logits"])
+  ws = ops._dense_ws[(torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream)]
+  for poison in (1, 7, -1):
+    ws[:4096].view(torch.int32).fill_(poison)
+    np.testing.assert_array_equal(head(), e["logits"], err_msg="tickets poisoned with %d" % poison)
+    assert ops.device_status() == 0
+  # the read-out's K split (four workgroups per tile at this batch)
+  T, B, K, N = 20, 64, 32768, 110
+  c = cases.dense_block_case(T=T, B=B, K=K, N=N, bits=4, p=0.9)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  xin = ops.pack_bits(_t(c["x"], dev))
+  eu, es = oracle.dense_block(c["x"], qweight_of(oracle, c["leaf"], c["bits"]), None, "int")
+  for poison in (0, 1, 3, -1):
+    ws = ops._dense_ws.get((torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream))
+    if ws is not None:
+      ws[:4096].view(torch.int32).fill_(poison)
+    u, s = ops.dense_lif_forward(xin, w, K, N, _mslif(), packed_out=True, impl=L.IMPL_AUTO)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg="tickets poisoned with %d" % poison)
+    np.testing.assert_array_equal(_np(u), eu)
+    assert ops.device_status() == 0
+
+
+def test_two_live_captures_on_two_streams_own_their_workspaces(dev, oracle):
+  """Two CapturedApply objects of the split dense head, alive together and replayed on two
+  streams at once, many times: each graph's hand-over workspace was allocated inside its own
+  capture (the graph's private pool), so the two never share tickets or raster slabs, and an
+  eager launch in between uses a third one (the workspace belongs to the
+  capture, not to a (device, stream-handle) table)."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  ca = cases.dense_net_case(True, T=20, B=48, K=512, hidden=512)
+  ea = cases.dense_net_expected(oracle, ca)
+  rng = np.random.Generator(np.random.PCG64(99))
+  xb_np = (rng.random(ca["x"].shape) < 0.12).astype(np.uint8)
+  cb = dict(ca, x=xb_np)
+  eb = cases.dense_net_expected(oracle, cb)
+  assert not np.array_equal(ea["logits"], eb["logits"])
+  model = models.DenseSNN(num_classes=11, config=syn.make_config(bits=8, prune_percentage=0.5, hidden=512))
+  variables = nn.tree_from_numpy(ca["vars"], dev)
+  xa, xb = _t(ca["x"], dev), _t(xb_np, dev)
+  capa = nn.capture(model, variables, xa, trgt=None, train=False, rng=None)
+  capb = nn.capture(model, variables, xb, trgt=None, train=False, rng=None)
+  sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+  torch.cuda.synchronize()
+  for it in range(50):
+    with torch.cuda.stream(sa):
+      la = capa()[0]
+    with torch.cuda.stream(sb):
+      lb = capb()[0]
+    if it % 10 == 3:                   # an eager launch on the default stream in between
+      (le, _) = model.apply(variables, xa, trgt=None, train=False, rng=None)
+      np.testing.assert_array_equal(_np(le), ea["logits"])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(la), ea["logits"], err_msg="replay %d, graph a" % it)
+    np.testing.assert_array_equal(_np(lb), eb["logits"], err_msg="replay %d, graph b" % it)
+  assert ops.device_status() == 0
+  capa.close()
+  capb.close()

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of diagnostic builds under the bench: tools/ab_bench.sh OUT name1 name2 ...   (name = product | build/diag/<name>)
+# A/B of diagnostic builds under the bench: tools/ab_bench.sh OUT name1 name2 ...   (name = product | diag_build/<name>)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
 for n in "$@"; do
-  if [ "$n" = product ]; then lib=""; else lib=$GRAFT_REPO_ROOT/build/diag/$n/libsnnqp.so; fi
+  if [ "$n" = product ]; then lib=""; else lib=$GRAFT_REPO_ROOT/diag_build/$n/libsnnqp.so; fi
   SNNQP_DIAG_LIB=$lib python bench.py --allow-diag --no-cpu-baseline --no-fed-leg --steps 6 --warmup 2 $BENCH_ARGS > $O/$n.json 2> $O/$n.err || { echo "$n failed"; tail -3 $O/$n.err; continue; }
   python - "$n" "$O/$n.json" <<'PY'
 import json,sys

@@ -2,7 +2,7 @@
 faster side by side on the same CUs than one after the other?  Two streams, half a batch each:
   python tools/corun_probe.py            (product library: persistent grids fill the CUs, so the
                                           two launches serialise -- the reference point)
-  SNNQP_DIAG_LIB=build/diag/<occ1>/libsnnqp.so python tools/corun_probe.py
+  SNNQP_DIAG_LIB=diag_build/<occ1>/libsnnqp.so python tools/corun_probe.py
                                          (a diagnostic build that launches ONE workgroup per CU:
                                           the two kernels can then share every CU)"""
 import os, sys

@@ -2,12 +2,12 @@
 
   python tools/diag_build.py NAME [--patch tools/diag/x.patch ...] [--files a.hip,b.hip] -- -DFOO=1 ...
 
-copies snnquantprune_amd/csrc/ to build/diag/NAME/src/, applies the patches there
+copies snnquantprune_amd/csrc/ to diag_build/NAME/src/, applies the patches there
 (ablations and probes live as patches under tools/diag/, not as #if blocks in the product
 kernels), compiles the listed files (default: every file a patch touched, plus api.hip)
-with the extra flags and links build/diag/NAME/libsnnqp.so against the product objects of
+with the extra flags and links diag_build/NAME/libsnnqp.so against the product objects of
 the other files.  The library reports the switches in snnqp_build_flags(); load it with
-SNNQP_DIAG_LIB=build/diag/NAME/libsnnqp.so (tests and the default bench refuse it).
+SNNQP_DIAG_LIB=diag_build/NAME/libsnnqp.so (tests and the default bench refuse it).
 """
 import os
 import shutil
@@ -35,15 +35,15 @@ def main(argv):
       files += argv[i + 1].split(","); i += 2
     else:
       raise SystemExit("unknown argument %s" % argv[i])
-  out = os.path.join(ROOT, "build", "diag", name)
+  out = os.path.join(ROOT, "diag_build", name)
   src = os.path.join(out, "src")
   shutil.rmtree(out, ignore_errors=True)
   os.makedirs(src)
   for f in os.listdir(product.HERE):
     if f.endswith((".hip", ".h")):
       shutil.copy(os.path.join(product.HERE, f), src)
-  # the sources include "../../include/snnqp.h": from build/diag/NAME/src that is build/diag/include
-  inc = os.path.join(ROOT, "build", "diag", "include")
+  # the sources include "../../include/snnqp.h": from diag_build/NAME/src that is diag_build/include
+  inc = os.path.join(ROOT, "diag_build", "include")
   os.makedirs(inc, exist_ok=True)
   shutil.copy(os.path.join(ROOT, "include", "snnqp.h"), inc)
   touched = set()

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 counter passes of one bench step for the product library or a diagnostic variant:
-#   tools/pmc_variant.sh OUTDIR NAME [bench args...]      (NAME = product | build/diag/<NAME>)
+#   tools/pmc_variant.sh OUTDIR NAME [bench args...]      (NAME = product | diag_build/<NAME>)
 # Separate --pmc passes with --kernel-trace only (no other trace domain), per the guide.
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; name=$2; shift 2; mkdir -p $O
-if [ "$name" = product ]; then lib=""; else lib=$GRAFT_REPO_ROOT/build/diag/$name/libsnnqp.so; fi
+if [ "$name" = product ]; then lib=""; else lib=$GRAFT_REPO_ROOT/diag_build/$name/libsnnqp.so; fi
 export TMPDIR=/tmp
 pass() {  # pass name, counters...
   p=$1; shift

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
 for v in "$@"; do
-  if [ "$v" = product ]; then lib=""; else lib=build/diag/$v/libsnnqp.so; fi
+  if [ "$v" = product ]; then lib=""; else lib=diag_build/$v/libsnnqp.so; fi
   SNNQP_DIAG_LIB=$lib timeout -k 10 300 python bench.py --allow-diag --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $O/bench_$v.json 2> $O/bench_$v.err || echo "variant $v failed"
 done
 python - $O <<'PY' | tee $O/summary.txt

@@ -1,5 +1,5 @@
 """In-kernel phase times of dense_wide_kernel from a -DW_STAMP=1 diagnostic build:
-  SNNQP_DIAG_LIB=build/diag/wide_stamp/libsnnqp.so python tools/wide_stamps.py [B]"""
+  SNNQP_DIAG_LIB=diag_build/wide_stamp/libsnnqp.so python tools/wide_stamps.py [B]"""
 import ctypes, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
