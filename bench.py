@@ -81,9 +81,10 @@ def parse(argv=None):
                        "bit-packed wire format of include/snnqp.h, 81 920 B per sample -- what the "
                        "host feed can deliver (uint8 frames need 50 GB/s per GPU at this rate) and "
                        "what the event layer stages directly; u8 (default with --counts and for "
-                       "--model dense): uint8 frames, 655 360 B per sample; f32: the float32 frames "
-                       "the reference's pipeline hands over (inspected and narrowed on device inside "
-                       "the step); ev4: nibble-packed counts <= 15 (327 680 B)")
+                       "--model dense): uint8 frames, 655 360 B per sample; f32: the float32 frames / "
+                       "rows the reference's pipeline hands over (flax_qconv.py:101, flax_qdense.py:67), "
+                       "staged in place by the first kernel and checked on the device; ev4: nibble-packed "
+                       "counts <= 15 (327 680 B)")
   ap.add_argument("--feed", choices=("resident", "host"), default="resident",
                   help="resident: the batch is in HBM before the timed region (the contract's "
                        "`value`).  host: every step's batch comes from page-locked host memory "
@@ -706,10 +707,9 @@ def main(argv=None):
   # process only: a capture that failed on some rank of a multi-GPU job would take the whole
   # line with it, and the figure is a per-GPU one anyway (--graph runs it on every rank).
   cap_leg = None
-  # Only what can be captured: integer frames (float32 frames are inspected on the host before they
-  # are narrowed -- a read-back no capture allows).
+  # (Every input format captures: float32 frames are checked on the device since round 5.)
   if (gpu and ops is not None and not args.stand_in and not args.graph and args.feed == "resident"
-      and not args.no_fed_leg and world == 1 and args.input in ("u8", "ev1", "ev4", "bits")):
+      and not args.no_fed_leg and world == 1):
     captured = nn.capture(model, variables, x, trgt=None, train=False, rng=None)
     for _ in range(2):
       parallel.all_gather_rows(captured()[0])
@@ -767,7 +767,7 @@ def main(argv=None):
                       "potentials f32",
       "data": ("synthetic Poisson(%g) event counts" if args.counts else "synthetic Poisson(%g)>0 spikes")
               % args.lam + {"ev1": " as bit-packed frames (EV1, include/snnqp.h)", "ev4": " as nibble-packed "
-                            "frames (EV4)", "u8": " as uint8 frames", "f32": " as float32 frames",
+                            "frames (EV4)", "u8": " as uint8 frames", "f32": " as float32 frames (staged in place, checked on the device)",
                             "bits": " as bit-packed rows"}[args.input] +
               ", N(0,1/fan_in) weights, " +
               ("random BatchNorm statistics" if args.random_bn else "BatchNorm as initialised") +
@@ -853,6 +853,17 @@ def main(argv=None):
                                           input="u8", layer_bits=None, classes=11), dev, 50, 5, False),
         "c5": config_leg(args, dict(model="c3", batch=512, frames=50, bits=4, prune=0.95, input="ev1",
                                     layer_bits=[2, 4, 2, 4], classes=10), dev, args.steps, 3, False),
+        # the reference's own input format: float32 rows / frames staged in place and checked on
+        # the device (flax_qdense.py:67, flax_qconv.py:101); the dense layer's HBM roofline is on
+        # the bytes the kernel really reads
+        "c2_b4096_f32": config_leg(args, dict(model="dense", batch=4096, frames=20, bits=8, prune=0.5,
+                                              input="f32", layer_bits=None, classes=11), dev, 50, 5, True),
+        "c2_b4096_bits": config_leg(args, dict(model="dense", batch=4096, frames=20, bits=8, prune=0.5,
+                                               input="bits", layer_bits=None, classes=11), dev, 50, 5, False),
+        "c2_f32": config_leg(args, dict(model="dense", batch=256, frames=20, bits=8, prune=0.5,
+                                        input="f32", layer_bits=None, classes=11), dev, 200, 20, True),
+        "c3_f32": config_leg(args, dict(model="c3", batch=1024, frames=20, bits=4, prune=0.9, input="f32",
+                                        layer_bits=None, classes=11), dev, args.steps, 3, True),
     }
   if world == 1 and not args.no_cpu_baseline and args.model == "c3":
     line["cpu_baseline"] = cpu_baseline(args, variables_np)
@@ -874,6 +885,9 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
   # bytes of one input frame as conv0 reads it (ev4 frames are unpacked to uint8 first)
   in_bytes = {"f32": 128 * 128 * 2 * 4, "u8": 128 * 128 * 2, "ev4": 128 * 128 * 2,
               "ev1": 128 * 128 * 2 // 8, "bits": 0}[args.input]
+  # bytes of one [2048] row as the dense head reads it: uint8 in place, float32 in place (the
+  # reference's own format, flax_qdense.py:67), or bit-packed
+  row_bytes = {"u8": 2048, "f32": 8192}.get(args.input, 256)
   spec = {
       "conv3x3[128x128x2->128]": (B * T * 128 * 128 * 128 * 18,
                                   B * T * (in_bytes + 64 * 64 * 16), INT8_MFMA_PEAK_TOPS),
@@ -888,14 +902,14 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
                                   conv_peak(lb[3])),
       # config C2 (bit-packed spikes in and out, int8 codes once per launch)
       # (uint8 rows are read in place: 2048 B per sample-step, not the 256 B of a bit-packed row)
-      "dense[2048->512]": (B * T * 2048 * 512, B * T * ((2048 if args.input == "u8" else 256) + 64) + 2048 * 512,
+      "dense[2048->512]": (B * T * 2048 * 512, B * T * (row_bytes + 64) + 2048 * 512,
                            INT8_MFMA_PEAK_TOPS),
       "dense[512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 16) + 512 * 128, INT8_MFMA_PEAK_TOPS),
       # config C2 as ONE launch (snnqp_dense_head_forward): the uint8 rows as the kernel reads them
       # (2048 B per sample-step, in place), both code matrices once, the logits; the hidden
       # raster never leaves the CU
       "dense_head[2048->512->%d]" % nout: (B * T * (2048 * 512 + 512 * nout),
-                                           B * T * (2048 if args.input == "u8" else 256) + 2048 * 512
+                                           B * T * row_bytes + 2048 * 512
                                            + 512 * 128 + B * 4 * args.classes, INT8_MFMA_PEAK_TOPS),
   }
   traffic, traffic_src, pmc, pmc_src = {}, None, {}, None

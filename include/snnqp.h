@@ -166,9 +166,11 @@ typedef struct {
  * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
  * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
  * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward, snnqp_device_status,
- * snnqp_workqueue_*, snnqp_dense_lif_forward_ws).  A binding compares snnqp_version() with the SNNQP_VERSION it was
- * written against and refuses a library of another version (_lib.py does). */
-#define SNNQP_VERSION 400
+ * snnqp_workqueue_*, snnqp_dense_lif_forward_ws; 500: float32 inputs into integer blocks --
+ * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
+ * predicated snnqp_*_if entry points, snnqp_pack_bits_checked).  A binding compares snnqp_version()
+ * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
+#define SNNQP_VERSION 500
 int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build
@@ -236,6 +238,10 @@ int snnqp_unpack_frames(const void *x, int fmt, int64_t frames, int32_t H, int32
                         uint8_t *y, snnqp_stream_t stream);
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
                     uint32_t *bits, snnqp_stream_t stream);
+/* the same, and SNNQP_FLAG_GT_ONE is OR-ed into the device word `flags` (nullable; zeroed by the
+ * caller) when an element is neither 0 nor 1 -- the raster then is not the tensor */
+int snnqp_pack_bits_checked(const void *x, int in_type, int64_t rows, int32_t C,
+                            uint32_t *bits, int32_t *flags, snnqp_stream_t stream);
 int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
                       snnqp_stream_t stream);
 
@@ -281,14 +287,45 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
  *       patch x up to 32 timesteps) whose largest value was <= 1, 2, <= 7, <= 31, above; [6..7]
  *       are reserved.  From these the caller refines its next hint asynchronously -- a hint
  *       that covers MOST chunks is the fast one: a hot pixel then costs its own few chunks the
- *       general path instead of the whole batch the slower tables.  Nothing ever waits for it. */
+ *       general path instead of the whole batch the slower tables.  Nothing ever waits for it.
+ * FLOAT32 INPUT INTO INTEGER CODES (the reference casts every input to float32, flax_qconv.py:101,
+ *       flax_qdense.py:67; its event frames and spike rasters are integer-valued float32 tensors).
+ *       With SNNQP_W_I8 weights, in_type SNNQP_F32 and Cin == 2 the event-layer MFMA kernel stages
+ *       the float32 frames IN PLACE (strides in elements): every value is converted to its uint8
+ *       count on the way into LDS and checked while it waits in a register.  x_flags: one device
+ *       word, zeroed by this call on `stream` in front of the kernel; the kernel ORs
+ *       SNNQP_FLAG_NOT_INTEGER into it when a staged value is not an integer in [0, 255] (-0.0
+ *       counts as 0) -- the launch's results are then meaningless and the caller's
+ *       snnqp_conv_lif_forward_if(x_flags, ...) with the float32 kernel, enqueued right behind,
+ *       redoes the block.  Nothing is read back: the pair is enqueued unconditionally and can be
+ *       captured into a graph.  x_flags is required for this combination, ignored otherwise.
+ *       Other geometries refuse float32 input into integer codes (SNNQP_EUNSUPPORTED): narrow
+ *       it with snnqp_narrow_f32 / snnqp_pack_bits_checked (their flag words serve as the
+ *       predicate in the same way). */
 int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            int64_t x_stride_b, int32_t T, int32_t B,
                            const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                            const int8_t *wt, const snnqp_bn_t *bn,
                            const snnqp_neuron_t *nrn, const float *u0,
                            float *u_out, void *s_out, int s_type, int pool,
-                           int impl, int x_max, int32_t *x_seen, snnqp_stream_t stream);
+                           int impl, int x_max, int32_t *x_seen, int32_t *x_flags,
+                           snnqp_stream_t stream);
+
+/* The same block on the direct-form kernel (any geometry, any types; SNNQP_W_F32 weights: the
+ * fmaf chain over (kh, kw, cin) ascending), enqueued unconditionally but EXECUTED only if
+ * *pred != 0 when the stream reaches it (pred: a device word, e.g. the x_flags of the speculative
+ * integer launch in front of it, or flags[1] of snnqp_narrow_f32).  It writes the same outputs
+ * (pool == 2: the 2x2 max-pool fused, spikes [T][B][OH/2][OW/2][Cout]); when it does not run it
+ * costs one small grid.  Together: a float32 tensor whose values are all integers in [0, 255]
+ * gets the exact-integer contraction, any other tensor the reference's float32 one -- decided per
+ * tensor on the device, with no read-back.
+ * replaces: the same call site as snnqp_conv_lif_forward. */
+int snnqp_conv_lif_forward_if(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                              int64_t x_stride_b, int32_t T, int32_t B,
+                              const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                              const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                              float *u_out, void *s_out, int s_type, int pool,
+                              snnqp_stream_t stream);
 
 /* Blocks that SNNQP_IMPL_AUTO handed to the direct-form kernel since the library was loaded
  * (or the last reset): it serves every geometry and type, 20-25 x slower than the MFMA kernels.
@@ -375,7 +412,11 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
  * in front of the kernel -- a kernel node when the stream is being captured -- so that nothing an
  * earlier launch, an aborted replay or a stray store left there can reach this one).
  * ws = NULL or too small: no split, as snnqp_dense_lif_forward.
- * snnqp_dense_workspace_bytes returns 0 when the split would not be used. */
+ * snnqp_dense_workspace_bytes returns 0 when the split would not be used.
+ * x_flags: float32 rows into integer codes (see snnqp_conv_lif_forward): the wide kernel (more
+ * than 128 features, T <= 64, K % 16 == 0, rows 16-byte aligned, w->col_sum) stages them in place
+ * and reports into the word; required then, ignored otherwise; other shapes refuse the
+ * combination (SNNQP_EUNSUPPORTED: narrow the rows with snnqp_narrow_f32 first). */
 int64_t snnqp_dense_workspace_bytes(int in_type, int32_t T, int32_t B, int32_t K, int32_t N,
                                     const snnqp_weight_t *w);
 int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
@@ -384,7 +425,13 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
                                const int8_t *wt, const snnqp_bn_t *bn,
                                const snnqp_neuron_t *nrn, const float *u0,
                                float *u_out, void *s_out, int s_type, int impl,
-                               void *ws, int64_t ws_bytes, snnqp_stream_t stream);
+                               int32_t *x_flags, void *ws, int64_t ws_bytes, snnqp_stream_t stream);
+/* the dense block on the direct-form kernel, executed only if *pred != 0 (snnqp_conv_lif_forward_if) */
+int snnqp_dense_lif_forward_if(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                               int64_t x_stride_b, int32_t T, int32_t B, int32_t K, int32_t N,
+                               const snnqp_weight_t *w, const snnqp_bn_t *bn,
+                               const snnqp_neuron_t *nrn, const float *u0, float *u_out,
+                               void *s_out, int s_type, snnqp_stream_t stream);
 
 /* ---- the dense head as one launch -----------------------------------------------
  * replaces: the two dense SpikingBlocks and the vote that end CextNet,
@@ -394,7 +441,13 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
  *           (per block spiking_learning.py:446-462 with flax_qdense.py:74-89; no norm_fn, no
  *           bias: models.py:200-208, 231-236), i.e. config C2 of BASELINE.json as a whole.
  * x     [T][B][K] by strides, SNNQP_U8 (any count 0..255, read in place; needs w1->col_sum,
- *       K % 16 == 0, 16-byte aligned rows) or SNNQP_BITS (zero bits beyond K).
+ *       K % 16 == 0, 16-byte aligned rows), SNNQP_BITS (zero bits beyond K), or SNNQP_F32 -- the
+ *       rows as the reference holds them (flax_qdense.py:67), read in place under the same
+ *       conditions as uint8 rows: 4 x the bytes, checked on the way into LDS; x_flags as for
+ *       snnqp_conv_lif_forward (required for SNNQP_F32; when the word comes back set, the caller's
+ *       predicated launches -- snnqp_dense_lif_forward_if with the float32 kernel of the first
+ *       block into s1_out, snnqp_dense_lif_forward_if of the second block, snnqp_vote_if -- redo
+ *       the head).
  * w1/wt1  int8 codes [K][N1] and their tiles (snnqp_pack_codes_mfma, Npad = N1 rounded up to 32,
  *       K rows zero-padded to a multiple of 32); w2/wt2 the same for [N1][N2] (its K is N1).
  * logits  float32 [B][N2 / group], as snnqp_vote gives them.
@@ -418,7 +471,7 @@ int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_stride_t,
                              const snnqp_weight_t *w2, const int8_t *wt2,
                              const snnqp_neuron_t *nrn2, int32_t group,
                              uint32_t *s1_out, uint32_t *s2_out, float *logits,
-                             void *ws, int64_t ws_bytes, snnqp_stream_t stream);
+                             int32_t *x_flags, void *ws, int64_t ws_bytes, snnqp_stream_t stream);
 
 /* ---- element-wise pieces ----------------------------------------------------
  * replaces: neural_dynamics(u, x) scanned over T, spiking_learning.py:460
@@ -474,6 +527,9 @@ int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int
  * mean over T (sequential float32 sum / T), then mean over `group` neurons. */
 int snnqp_vote(const void *s, int type, int32_t T, int32_t B, int32_t N,
                int32_t group, float *logits, snnqp_stream_t stream);
+/* executed only if *pred != 0 (snnqp_conv_lif_forward_if) */
+int snnqp_vote_if(const int32_t *pred, const void *s, int type, int32_t T, int32_t B, int32_t N,
+                  int32_t group, float *logits, snnqp_stream_t stream);
 
 #ifdef __cplusplus
 }

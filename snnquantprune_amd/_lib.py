@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
 
 # include/snnqp.h SNNQP_VERSION the prototypes below were written against
-ABI_VERSION = 400
+ABI_VERSION = 500
 
 # enums of include/snnqp.h
 F32, U8, BITS, EV1, EV4 = 0, 1, 2, 3, 4
@@ -76,13 +76,23 @@ _PROTOTYPES = {
                                     c_void_p]),
     "snnqp_pack_bits": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p,
                                 c_void_p]),
+    "snnqp_pack_bits_checked": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p, c_void_p,
+                                        c_void_p]),
     "snnqp_unpack_bits": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "snnqp_conv_forward": (c_int, [c_void_p, c_int, c_int64, POINTER(ConvGeomT),
                                    POINTER(WeightT), c_void_p, c_void_p, c_void_p]),
     "snnqp_conv_lif_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
-        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "snnqp_conv_lif_forward_if": (c_int, [
+        c_void_p, c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
+        POINTER(WeightT), POINTER(BnT), POINTER(NeuronT), c_void_p, c_void_p, c_void_p, c_int, c_int,
+        c_void_p]),
+    "snnqp_dense_lif_forward_if": (c_int, [
+        c_void_p, c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
+        POINTER(WeightT), POINTER(BnT), POINTER(NeuronT), c_void_p, c_void_p, c_void_p, c_int,
+        c_void_p]),
     "snnqp_dense_lif_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
@@ -91,12 +101,12 @@ _PROTOTYPES = {
     "snnqp_dense_lif_forward_ws": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
-        c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
+        c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "snnqp_dense_head_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "snnqp_dense_head_forward": (c_int, [
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(WeightT),
         c_void_p, POINTER(NeuronT), c_int32, POINTER(WeightT), c_void_p, POINTER(NeuronT), c_int32,
-        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "snnqp_device_status": (c_int, [c_int, POINTER(c_uint32), c_int]),
     "snnqp_workqueue_capture_mark": (c_int, [c_int, POINTER(c_int64)]),
     "snnqp_workqueue_capture_release": (c_int, [c_int, c_int64, c_int64]),
@@ -122,6 +132,8 @@ _PROTOTYPES = {
     "snnqp_density": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "snnqp_vote": (c_int, [c_void_p, c_int, c_int32, c_int32, c_int32, c_int32,
                            c_void_p, c_void_p]),
+    "snnqp_vote_if": (c_int, [c_void_p, c_void_p, c_int, c_int32, c_int32, c_int32, c_int32,
+                              c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -74,8 +74,11 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            const snnqp_neuron_t *nrn,
                            const float *u0, float *u_out, void *s_out,
                            int s_type, int pool, int impl, int x_max, int32_t *x_seen,
-                           snnqp_stream_t stream) {
+                           int32_t *x_flags, snnqp_stream_t stream) {
   SNNQP_REQUIRE(g && w && nrn, SNNQP_EINVAL, "conv_lif_forward: null descriptor");
+  if (in_type == SNNQP_F32 && w->wtype == SNNQP_W_I8)
+    SNNQP_REQUIRE(x_flags != nullptr, SNNQP_EINVAL,
+                  "conv_lif_forward: float32 input into integer codes needs x_flags (snnqp.h)");
   if (int rc = refuse_after_device_report((hipStream_t)stream, "conv_lif_forward")) return rc;
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
                     nrn->kind <= SNNQP_NEURON_LIF,
@@ -89,14 +92,52 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
     SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "conv_lif_forward: MFMA kernel: %s", why);
   if (!why && impl != SNNQP_IMPL_GENERIC)
     return run_conv3x3_mfma(x, in_type, x_stride_t, x_stride_b, T, B, g, w, wt, bn,
-                            nrn, u0, u_out, (uint32_t *)s_out, pool, x_max, x_seen,
+                            nrn, u0, u_out, (uint32_t *)s_out, pool, x_max, x_seen, x_flags,
                             (hipStream_t)stream);
+  SNNQP_REQUIRE(!(in_type == SNNQP_F32 && w->wtype == SNNQP_W_I8), SNNQP_EUNSUPPORTED,
+                "conv_lif_forward: float32 input into integer codes is staged by the event-layer MFMA "
+                "kernel only (%s); narrow it first (snnqp_narrow_f32 / snnqp_pack_bits_checked)",
+                why ? why : "impl = GENERIC");
   SNNQP_REQUIRE(pool == 1, SNNQP_EUNSUPPORTED,
                 "conv_lif_forward: the direct-form kernel does not fuse the "
                 "max-pool; call snnqp_maxpool2x2 after it");
   if (impl == SNNQP_IMPL_AUTO) note_fallback(false, why);
   return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, g, w, bn, nrn, u0,
                      u_out, s_out, s_type, nullptr, (hipStream_t)stream);
+}
+
+int snnqp_conv_lif_forward_if(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                              int64_t x_stride_b, int32_t T, int32_t B,
+                              const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                              const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                              float *u_out, void *s_out, int s_type, int pool,
+                              snnqp_stream_t stream) {
+  SNNQP_REQUIRE(pred && g && w && nrn, SNNQP_EINVAL, "conv_lif_forward_if: null argument");
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "conv_lif_forward_if")) return rc;
+  SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF && nrn->kind <= SNNQP_NEURON_LIF,
+                SNNQP_EINVAL, "conv_lif_forward_if: unknown neuron kind %d", nrn->kind);
+  SNNQP_REQUIRE(pool == 1 || pool == 2, SNNQP_EINVAL, "conv_lif_forward_if: pool must be 1 or 2");
+  return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, g, w, bn, nrn, u0, u_out, s_out, s_type,
+                     nullptr, (hipStream_t)stream, pool, pred);
+}
+
+int snnqp_dense_lif_forward_if(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                               int64_t x_stride_b, int32_t T, int32_t B, int32_t K, int32_t N,
+                               const snnqp_weight_t *w, const snnqp_bn_t *bn,
+                               const snnqp_neuron_t *nrn, const float *u0, float *u_out,
+                               void *s_out, int s_type, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(pred && w && nrn && K > 0 && N > 0, SNNQP_EINVAL, "dense_lif_forward_if: bad argument");
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "dense_lif_forward_if")) return rc;
+  SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF && nrn->kind <= SNNQP_NEURON_LIF,
+                SNNQP_EINVAL, "dense_lif_forward_if: unknown neuron kind %d", nrn->kind);
+  snnqp_conv_geom_t g;
+  g.H = 1; g.W = 1; g.Cin = K; g.Cout = N; g.KH = 1; g.KW = 1;
+  g.stride_h = g.stride_w = 1;
+  g.pad_h_lo = g.pad_h_hi = g.pad_w_lo = g.pad_w_hi = 0;
+  g.in_dil_h = g.in_dil_w = g.k_dil_h = g.k_dil_w = 1;
+  g.groups = 1;
+  return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, &g, w, bn, nrn, u0, u_out, s_out, s_type,
+                     nullptr, (hipStream_t)stream, 1, pred);
 }
 
 int snnqp_current_min(const snnqp_weight_t *w, const snnqp_bn_t *bn, int32_t bound,
@@ -120,7 +161,7 @@ int snnqp_dense_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                             float *u_out, void *s_out, int s_type, int impl,
                             snnqp_stream_t stream) {
   return snnqp_dense_lif_forward_ws(x, in_type, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn, u0,
-                                    u_out, s_out, s_type, impl, nullptr, 0, stream);
+                                    u_out, s_out, s_type, impl, nullptr, nullptr, 0, stream);
 }
 
 int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
@@ -129,8 +170,12 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
                                const int8_t *wt, const snnqp_bn_t *bn,
                                const snnqp_neuron_t *nrn, const float *u0,
                                float *u_out, void *s_out, int s_type, int impl,
-                               void *ws, int64_t ws_bytes, snnqp_stream_t stream) {
+                               int32_t *x_flags, void *ws, int64_t ws_bytes, snnqp_stream_t stream) {
   SNNQP_REQUIRE(w && nrn, SNNQP_EINVAL, "dense_lif_forward: null descriptor");
+  const bool f32_int = in_type == SNNQP_F32 && w->wtype == SNNQP_W_I8;
+  if (f32_int)
+    SNNQP_REQUIRE(x_flags != nullptr, SNNQP_EINVAL,
+                  "dense_lif_forward: float32 rows into integer codes need x_flags (snnqp.h)");
   if (int rc = refuse_after_device_report((hipStream_t)stream, "dense_lif_forward")) return rc;
   SNNQP_REQUIRE(K > 0 && N > 0, SNNQP_EINVAL, "dense_lif_forward: bad K/N");
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
@@ -150,7 +195,11 @@ int snnqp_dense_lif_forward_ws(const void *x, int in_type, int64_t x_stride_t,
   if (impl != SNNQP_IMPL_GENERIC &&
       !dense_wide_unsupported(in_type, T, K, N, x_stride_t, x_stride_b, x, w, wt, nrn, s_type))
     return run_dense_wide(x, in_type, x_stride_t, x_stride_b, T, B, K, N, w, wt, bn, nrn, u0, u_out,
-                          (uint32_t *)s_out, (hipStream_t)stream);
+                          (uint32_t *)s_out, x_flags, (hipStream_t)stream);
+  SNNQP_REQUIRE(!f32_int, SNNQP_EUNSUPPORTED,
+                "dense_lif_forward: float32 rows into integer codes are staged by the wide MFMA kernel only "
+                "(more than 128 features, T <= 64, K %% 16 == 0, 16-byte aligned rows); narrow them first "
+                "(snnqp_narrow_f32)");
   const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
   if (!why && T > (in_type == SNNQP_U8 ? 64 : 96))
     why = "more than 96 (uint8 input: 64) timesteps (one sample must fit a row tile)";

@@ -78,6 +78,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
   constexpr bool EV1 = IN == SNNQP_EV1;
   constexpr bool EV4 = IN == SNNQP_EV4;     // one byte per pixel: polarity 0 low nibble, 1 high
+  // float32 frames as the reference hands them over (flax_qconv.py:101): eight bytes per pixel,
+  // converted to the two count bytes and checked while they wait in registers (snnqp.h, x_flags)
+  constexpr bool F32IN = IN == SNNQP_F32;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tc = a.tchunk;                       // <= TCHUNK
@@ -231,8 +234,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     const bool s_valid = s_task && s_gy >= 0 && s_gy < a.H && s_gx >= 0 && s_gx < a.W;
     // byte offset of the pixel within a frame (frames are below 2 GiB: launch check); threads
     // without a pixel read the frame's first one and drop it
-    const uint32_t s_off = s_valid ? (uint32_t)(s_gy * a.W + s_gx) * (EV4 ? 1u : 2u) : 0u;
-    const uint8_t *s_frames = xb + (int64_t)b * a.xs_b;
+    const uint32_t s_off = s_valid ? (uint32_t)(s_gy * a.W + s_gx) * (EV4 ? 1u : F32IN ? 8u : 2u) : 0u;
+    const uint8_t *s_frames = xb + (int64_t)b * a.xs_b * (F32IN ? 4 : 1);
     // EV1: the 20 bits of a halo row start `lead` bits before pixel x0 of the row (none when
     // x0 = 0: the pixel left of the image does not exist); pixels outside the image are
     // cleared by a mask of two bits per halo column (workgroup-uniform: scalars)
@@ -283,6 +286,33 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       // wait in registers for the workgroup to agree on the path.
       uint32_t v[STG_N];
       uint32_t mx = 0;
+      if constexpr (F32IN) {
+        // two rounds of STG_N / 2 eight-byte loads: the raw pairs need two registers each
+        uint32_t fbad = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < STG_N; r0 += STG_N / 2) {
+          typedef float f2v __attribute__((ext_vector_type(2)));
+          f2v raw[STG_N / 2];
+#pragma unroll
+          for (int i = r0; i < r0 + STG_N / 2; ++i) {
+            const int tt = 2 * i + s_half;
+            raw[i - r0] = f2v{0.0f, 0.0f};
+            if (tt < nt) raw[i - r0] = *(const f2v *)(s_frames + (int64_t)(t0 + tt) * a.xs_t * 4 + s_off);
+          }
+#pragma unroll
+          for (int i = r0; i < r0 + STG_N / 2; ++i) {
+            // fl(cvt(x)) - x is +0.0 exactly for the integers v_cvt_u32_f32 holds (-0.0 counts
+            // as 0), NaN for NaN, non-zero otherwise; the range is checked on the integers
+            const f2v f = raw[i - r0];
+            const uint32_t ua = __float2uint_rz(f.x), ub = __float2uint_rz(f.y);
+            fbad |= __float_as_uint(__uint2float_rn(ua) - f.x) | __float_as_uint(__uint2float_rn(ub) - f.y);
+            fbad |= (ua | ub) >> 8;
+            v[i] = (ua & 0xFFu) | ((ub & 0xFFu) << 8);
+          }
+        }
+        fbad = s_valid ? fbad : 0u;
+        if (__ballot(fbad != 0u) != 0ull && lane == 0 && a.x_flags) atomicOr(a.x_flags, SNNQP_FLAG_NOT_INTEGER);
+      } else {
 #pragma unroll
       for (int i = 0; i < STG_N; ++i) {    // all loads first; the skip is a scalar branch
         const int tt = 2 * i + s_half;
@@ -295,6 +325,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
             v[i] = *(const uint16_t *)(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
           }
         }
+      }
       }
 #pragma unroll
       for (int i = 0; i < STG_N; ++i) {
@@ -619,8 +650,11 @@ const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
   } else if (in_type == SNNQP_EV4) {    // nibble-packed count frames (<= 15), staged directly
     if (g->Cin != 2) return "EV4 frames have Cin == 2";
     if ((int64_t)g->H * g->W >= (int64_t)1 << 31) return "EV4 frame of 2 GiB or more";
+  } else if (in_type == SNNQP_F32) {    // integer-valued float32 frames, staged in place and checked
+    if (g->Cin != 2) return "float32 input into integer codes needs Cin == 2";
+    if ((int64_t)g->H * g->W * 8 >= (int64_t)1 << 31) return "float32 frame of 2 GiB or more";
   } else {
-    return "input must be BITS, U8, EV1 or EV4";
+    return "input must be BITS, U8, EV1, EV4 or (Cin == 2) F32";
   }
   if (nrn->kind == SNNQP_NEURON_LIF && !nrn->decay) return "LIF without decay";
   if (in_type == SNNQP_BITS && !wt) return "MFMA-tiled codes `wt` not given";
@@ -641,7 +675,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     int x_max, int32_t *x_seen, hipStream_t st) {
+                     int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st) {
   SNNQP_REQUIRE(x && w->w && s_out, SNNQP_EINVAL, "conv3x3 mfma: null pointer");
   SNNQP_REQUIRE(in_type != SNNQP_BITS || wt, SNNQP_EINVAL,
                 "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
@@ -663,6 +697,13 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
   a.x_seen = x_seen;
+  a.x_flags = nullptr;
+  if (in_type == SNNQP_F32) {
+    SNNQP_REQUIRE(x_flags != nullptr && (((uintptr_t)x) & 7) == 0 && xs_t % 2 == 0 && xs_b % 2 == 0,
+                  SNNQP_EINVAL, "conv3x3 mfma: float32 frames need x_flags and 8-byte aligned pixels");
+    if (int rc = zero_words_async((uint32_t *)x_flags, 1, st)) return rc;
+    a.x_flags = x_flags;
+  }
   a.patch_h = 8;
   a.tiles_y = (g->H + 7) / 8; a.tiles_x = (g->W + 7) / 8;
   a.npatch = (int64_t)B * a.tiles_y * a.tiles_x;
@@ -692,6 +733,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   do {                                                                             \
     if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
     else if (in_type == SNNQP_EV4) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV4>, a, gy, st, LDS); \
+    else if (in_type == SNNQP_F32) launch_persistent(KERN<NFV, PL, LM, SNNQP_F32>, a, gy, st, LDS); \
     else launch_persistent(KERN<NFV, PL, LM, SNNQP_U8>, a, gy, st, LDS);            \
   } while (0)
 #define SNNQP_CONV_LAUNCH_NF(KERN, NFV, LM, LDS)                                   \

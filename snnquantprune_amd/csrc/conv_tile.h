@@ -78,6 +78,7 @@ struct ConvMfmaArgs {
   int32_t lut_bound;  // > 0: |acc| <= lut_bound while inputs <= x_limit, dequant by LDS table
   int32_t x_limit;    // u8c2 kernel: largest input value the table mode is sized for
   int32_t *x_seen;    // u8c2 kernel: (nullable) atomically max-ed with the largest input seen
+  int32_t *x_flags;   // u8c2 kernel, float32 frames: OR-ed with SNNQP_FLAG_NOT_INTEGER (snnqp.h)
   int32_t xcd_split;  // patch schedule keeps a sample on one XCD (grid % 8 == 0, B >= 8)
   int32_t tchunk;     // u8c2 kernel: timesteps staged per pass (<= 32)
   uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk

@@ -4,7 +4,11 @@
 //                                                                   (the whole head, ONE launch)
 // for int8 codes (flax_qdense.py:74-89 after the pack step) over uint8 rows read in place
 // (x - 128 against the codes; the 128 * col_sum that gives the sum over x back is what the
-// accumulators start from) or bit-packed rows.
+// accumulators start from), bit-packed rows, or FLOAT32 rows as the reference hands them over
+// (flax_qdense.py:67 casts every input to float32): staged in place -- sixteen bytes of four
+// values per lane and load, converted to the same x - 128 bytes on their way into LDS and checked
+// while they wait in registers (an integer in [0, 255]?  else SNNQP_FLAG_NOT_INTEGER is OR-ed into
+// the launch's flag word and the caller's predicated float32 launch redoes the block).
 //
 // What differs from dense_mfma.hip (128 columns per workgroup, two K groups, the int32 tile
 // transposed through LDS for the neuron):
@@ -84,7 +88,25 @@ struct DenseWideArgs {
   uint32_t *hs_tickets;           // [tiles], zeroed on the stream in front of every launch
   uint32_t *hs_raster;            // [tiles][2][ROWS][8 words]
   uint32_t *status;               // the device's status word (runtime.hip), or null
+  int32_t *x_flags;               // float32 rows: OR-ed with SNNQP_FLAG_NOT_INTEGER (zeroed by the launcher)
 };
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int W_FRING = 6;        // float32 rows: 16-byte loads a thread keeps in flight
+
+// four float32 values -> the four bytes x - 128 of the int8 operand; `bad` collects what is not
+// an integer in [0, 255]: fl(cvt(x)) - x is +0.0 exactly for the integers v_cvt_u32_f32 can hold
+// (-0.0 counts as 0), a NaN for a NaN, non-zero otherwise; the range is checked on the integers
+__device__ __forceinline__ uint32_t f32x4_to_i8x4(const v4f &f, uint32_t &bad) {
+  const uint32_t u0 = __float2uint_rz(f.x), u1 = __float2uint_rz(f.y), u2 = __float2uint_rz(f.z),
+                 u3 = __float2uint_rz(f.w);
+  const float d0 = __uint2float_rn(u0) - f.x, d1 = __uint2float_rn(u1) - f.y,
+              d2 = __uint2float_rn(u2) - f.z, d3 = __uint2float_rn(u3) - f.w;
+  bad |= __float_as_uint(d0) | __float_as_uint(d1);
+  bad |= __float_as_uint(d2) | __float_as_uint(d3);
+  bad |= (u0 | u1 | u2 | u3) >> 8;
+  return (u0 | (u1 << 8) | (u2 << 16) | (u3 << 24)) ^ 0x80808080u;
+}
 
 __device__ __forceinline__ void wide_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -272,7 +294,8 @@ __device__ __forceinline__ void mask_words(uint32_t (&words)[(16 * RT * CT * 2 +
 template <int RT, int CT, int IN, bool FUSE>
 __global__ void __launch_bounds__(W_THREADS)
 dense_wide_kernel(DenseWideArgs a) {
-  constexpr bool U8 = IN == SNNQP_U8;
+  constexpr bool F32IN = IN == SNNQP_F32;
+  constexpr bool U8 = IN == SNNQP_U8 || F32IN;     // the operand bytes are x - 128
   constexpr int ROWS = RT * 32;
   constexpr int ABYTES = ROWS * W_BK;
   // staging tasks of a chunk: one 16-byte piece of a uint8 row, or one 32-bit word of a bit row
@@ -280,9 +303,15 @@ dense_wide_kernel(DenseWideArgs a) {
   constexpr int NTASK = ROWS * WPR;
   constexpr int TPT = (NTASK + W_THREADS - 1) / W_THREADS;
   typedef typename std::conditional<U8, v4i, uint32_t>::type stg_t;
+  // float32 rows: NU 16-byte loads per thread and chunk; load j of wave w covers the chunk's 512
+  // bytes of the two rows rho = 16 j + 2 w + (lane >> 5), four values per lane (1 KiB, coalesced)
+  constexpr int NU = F32IN ? 2 * RT : 0;
   constexpr int NFRAG = W_KSC * RT;               // A fragments of a chunk
   constexpr int NSLOT = NFRAG * CT;               // MFMAs of a chunk
-  constexpr int RB = RT * CT >= 6 ? 6 : 12;       // B ring, k-steps (the unrolled body is 12 long)
+  // B ring, k-steps (the unrolled body is 12 long).  float32 rows: the loop runs at the pace of
+  // HBM, a look-ahead of three k-steps covers the L2 round trip, and the sixteen registers pay for
+  // the row loads in flight (RT 4 x CT 2 spilled 450 bytes with a ring of 6)
+  constexpr int RB = RT * CT >= 6 ? (F32IN && RT * CT >= 8 ? 4 : 6) : 12;
   constexpr int NW = (16 * RT * CT * 2 + 63) / 64;
   // (the fused head overlays the dead A images: raster | count / T per (sample, feature) | a flag)
   constexpr int LDSB = W_NBUF * ABYTES > ROWS * W_S1P * 4 + W_VOTE_SB * 512 + 16 ? W_NBUF * ABYTES
@@ -323,13 +352,30 @@ dense_wide_kernel(DenseWideArgs a) {
   }
 
   // ---- staging tasks: the same (row, piece) for every chunk -------------------------------
-  uint32_t roff[TPT];
-  uint32_t rmask[TPT];
-  int wr_off[TPT];
-  const uint8_t *xb = (const uint8_t *)a.x + (U8 ? (int64_t)b0 * a.xs_b : 0);
+  uint32_t roff[F32IN ? NU : TPT];
+  uint32_t rmask[F32IN ? 1 : TPT];
+  int wr_off[F32IN ? 1 : TPT];
+  uint32_t bad = 0;
+  const uint8_t *xb = (const uint8_t *)a.x + (U8 ? (int64_t)b0 * a.xs_b * (F32IN ? 4 : 1) : 0);
   const uint32_t *xw = (const uint32_t *)a.x + (U8 ? 0 : (int64_t)b0 * a.xs_b);
+  if constexpr (F32IN) {
+    rmask[0] = 0u;
 #pragma unroll
-  for (int q = 0; q < TPT; ++q) {
+    for (int j = 0; j < NU; ++j) {
+      const int rho = 16 * j + 2 * wave + h;
+      const int wv = rho & 31;
+      const int hh = (wv >> 2) & 1, kk = (rho >> 5) * 16 + (wv >> 3) * 4 + (wv & 3);
+      const int jj = kk / a.T, tt = kk - jj * a.T, ss = 2 * jj + hh;
+      const bool live = jj < a.SPH && ss < nsamp;
+      rmask[0] |= live ? 1u << j : 0u;
+      // byte offset of the row (< 2^31: launch check)
+      roff[j] = live ? (uint32_t)(((int64_t)tt * a.xs_t + (int64_t)ss * a.xs_b) * 4) : 0u;
+    }
+    // rho >> 1 = 8 j + wave: the swizzle of wa_addr does not depend on j, a row pair is 2 KiB on
+    wr_off[0] = wa_addr(2 * wave + h, n >> 2) + (n & 3) * 4;
+  }
+#pragma unroll
+  for (int q = 0; q < (F32IN ? 0 : TPT); ++q) {
     const int task = tid + q * W_THREADS;
     const int rho = (task / WPR) % ROWS, wi = task % WPR;
     const int wv = rho & 31;
@@ -364,6 +410,21 @@ dense_wide_kernel(DenseWideArgs a) {
     }
   };
 
+  // float32 rows: unit (chunk, j).  A chunk beyond K (or the dead chunk behind the last one)
+  // loads the row's first bytes and stores zeros
+  auto f32_load = [&](int chunk, int j) -> v4f {
+    const uint32_t cb = (uint32_t)(chunk * W_BK + n * 4) * 4u;
+    return *(const v4f *)(xb + roff[j] + (chunk * W_BK + n * 4 < a.K ? cb : 0u));
+  };
+  auto f32_store = [&](const v4f &v, int chunk, int j, int buf) {
+    uint32_t flag = 0;
+    const uint32_t w = f32x4_to_i8x4(v, flag);
+    const bool on = ((rmask[0] >> j) & 1u) && chunk * W_BK + n * 4 < a.K;
+    bad |= on ? flag : 0u;
+    *(uint32_t *)(lds + buf * ABYTES + wr_off[0] + j * 2048) = on ? w : 0u;
+  };
+  v4f fring[F32IN ? W_FRING : 1];
+
   // ---- B fragments: ring of RB k-steps ------------------------------------------------------
   const v4i *wtile[CT];
 #pragma unroll
@@ -385,7 +446,7 @@ dense_wide_kernel(DenseWideArgs a) {
     return *(const v4i *)(lds + buf * ABYTES + (f % RT) * 32 * W_BK + rd_off[f / RT]);
   };
 
-  stg_t stgr[W_NBUF][TPT];
+  stg_t stgr[F32IN ? 1 : W_NBUF][F32IN ? 1 : TPT];
   v4i av[W_PF + 1];
   constexpr int XSLOT = (NFRAG - W_PF) * CT > 0 ? (NFRAG - W_PF) * CT : 1;   // slots that may write LDS
   // One chunk = NSLOT slots; slot s = (k-step, row tile, column tile): the MFMA, then -- at the
@@ -408,6 +469,19 @@ dense_wide_kernel(DenseWideArgs a) {
       if (r == 0) {
         load_b1(bring[(i * W_KSC + ks + RB - 1) % RB][ct], lc, ks + RB - 1, ct);
       }
+      if constexpr (F32IN) {
+        // float32 rows: unit g of chunk lc + 2 leaves its register for image (i + 2) % 3, and the
+        // register takes the unit W_FRING further on (the unrolled body of three chunks holds
+        // 3 NU units, a multiple of the ring: every index below is an immediate)
+#pragma unroll
+        for (int gq = 0; gq < NU; ++gq)
+          if (s == (gq * NSLOT) / NU) {
+            const int slot = (i * NU + 2 * NU + gq) % W_FRING;
+            f32_store(fring[slot], phys(lc + 2), gq, wbuf);
+            const int ahead = gq + W_FRING;
+            fring[slot] = f32_load(phys(lc + 2 + ahead / NU), ahead % NU);
+          }
+      } else {
       // rows of chunk lc + 4 (ring slot (i + 1) % 3: its chunk lc + 1 was staged a step ago)
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
@@ -417,6 +491,7 @@ dense_wide_kernel(DenseWideArgs a) {
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (s == (q * XSLOT) / TPT) stage_store1(stgr[(i + 2) % W_NBUF][q], phys(lc + 2), q, wbuf);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // LDS operations of a wave complete in order and the W_PF youngest are the next chunk's
@@ -425,6 +500,25 @@ dense_wide_kernel(DenseWideArgs a) {
   };
 
   // ---- prologue ------------------------------------------------------------------------------
+  if constexpr (F32IN) {
+    // chunks 0 and 1 into their images, W_FRING units at a time; then the ring as step 0 expects
+    // it: the first units of chunk 2 in flight
+#pragma unroll
+    for (int u0 = 0; u0 < 2 * NU; u0 += W_FRING) {
+#pragma unroll
+      for (int u = u0; u < u0 + W_FRING && u < 2 * NU; ++u) fring[u % W_FRING] = f32_load(phys(u / NU), u % NU);
+      if (u0 == 0) {
+#pragma unroll
+        for (int ks = 0; ks < RB - 1; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) load_b1(bring[ks][ct], 0, ks, ct);
+      }
+#pragma unroll
+      for (int u = u0; u < u0 + W_FRING && u < 2 * NU; ++u) f32_store(fring[u % W_FRING], phys(u / NU), u % NU, u / NU);
+    }
+#pragma unroll
+    for (int u = 2 * NU; u < 2 * NU + W_FRING; ++u) fring[u % W_FRING] = f32_load(phys(u / NU), u % NU);
+  } else {
 #pragma unroll
   for (int d = 0; d < W_NBUF; ++d)
 #pragma unroll
@@ -439,6 +533,7 @@ dense_wide_kernel(DenseWideArgs a) {
     for (int q = 0; q < TPT; ++q) stage_store1(stgr[d][q], phys(d), q, d);
 #pragma unroll
   for (int q = 0; q < TPT; ++q) stgr[0][q] = stage_load1(phys(3), q);
+  }
   wide_barrier();
 #pragma unroll
   for (int f = 0; f < W_PF; ++f) av[f] = frag(0, f);
@@ -448,6 +543,9 @@ dense_wide_kernel(DenseWideArgs a) {
       if (c + i < nchunks) fused_chunk(i, c + i);   // (the chunks beyond K are the last ones)
   }
   wide_barrier();                                   // every wave is done with the A images
+  if constexpr (F32IN) {
+    if (__ballot(bad != 0u) != 0ull && lane == 0 && a.x_flags) atomicOr(a.x_flags, SNNQP_FLAG_NOT_INTEGER);
+  }
 
   // (fused head: the second block's B fragments are requested now, they land during the walk)
   v4i b2[FUSE ? 16 : 1];
@@ -639,15 +737,19 @@ static int pick_wide_rt(int T, int B, int CT, unsigned gy, int sph_cap, int *sph
 const char *dense_wide_unsupported(int in_type, int32_t T, int32_t K, int32_t N, int64_t xs_t,
                                    int64_t xs_b, const void *x, const snnqp_weight_t *w,
                                    const int8_t *wt, const snnqp_neuron_t *nrn, int s_type) {
-  const char *why = dense_mfma_unsupported(in_type, K, N, w, wt, nrn, s_type);
+  // (float32 rows are staged as the uint8 ones are: the same requirements on K and col_sum)
+  const char *why = dense_mfma_unsupported(in_type == SNNQP_F32 ? SNNQP_U8 : in_type, K, N, w, wt, nrn, s_type);
   if (why) return why;
   if (T > 64) return "more than 64 timesteps (a sample must fit the rows of one lane half)";
   if (N <= 128) return "at most 128 features: the 128-column kernel";
   if (xs_t < 0 || xs_b < 0) return "negative strides";
   if (in_type == SNNQP_U8 && ((((uintptr_t)x) & 15) != 0 || xs_t % 16 != 0 || xs_b % 16 != 0))
     return "uint8 rows not 16-byte aligned";
+  if (in_type == SNNQP_F32 && ((((uintptr_t)x) & 15) != 0 || xs_t % 4 != 0 || xs_b % 4 != 0))
+    return "float32 rows not 16-byte aligned";
   // 32-bit offsets from the workgroup's first sample (at most 128 samples)
-  if ((int64_t)(T - 1) * xs_t + 128 * xs_b + (in_type == SNNQP_U8 ? K : (K + 31) / 32) >= ((int64_t)1 << 31))
+  if (((int64_t)(T - 1) * xs_t + 128 * xs_b + (in_type == SNNQP_BITS ? (K + 31) / 32 : K)) *
+          (in_type == SNNQP_F32 ? 4 : 1) >= ((int64_t)1 << 31))
     return "input strides beyond 32-bit offsets within a workgroup";
   return nullptr;
 }
@@ -726,14 +828,22 @@ static int fill_and_launch(DenseWideArgs &a, int in_type, bool fuse, void *ws, i
   }
   const int rt = p.rt;
   const unsigned gx = p.gx, gy = p.gy;
-  const bool u8 = in_type == SNNQP_U8;
-  if (fuse) {
-    if (p.ct == 2) { if (u8) launch_wide_rt<2, SNNQP_U8, true>(rt, a, gx, gy, st); else launch_wide_rt<2, SNNQP_BITS, true>(rt, a, gx, gy, st); }
-    else { if (u8) launch_wide_rt<1, SNNQP_U8, true>(rt, a, gx, gy, st); else launch_wide_rt<1, SNNQP_BITS, true>(rt, a, gx, gy, st); }
-  } else {
-    if (p.ct == 2) { if (u8) launch_wide_rt<2, SNNQP_U8, false>(rt, a, gx, gy, st); else launch_wide_rt<2, SNNQP_BITS, false>(rt, a, gx, gy, st); }
-    else { if (u8) launch_wide_rt<1, SNNQP_U8, false>(rt, a, gx, gy, st); else launch_wide_rt<1, SNNQP_BITS, false>(rt, a, gx, gy, st); }
+  if (in_type == SNNQP_F32) {
+    SNNQP_REQUIRE(a.x_flags != nullptr, SNNQP_EINVAL, "dense wide: float32 rows need x_flags");
+    if (int rc = zero_words_async((uint32_t *)a.x_flags, 1, st)) return rc;
   }
+#define SNNQP_WIDE_IN(CTV, FUSEV)                                                          \
+  do {                                                                                     \
+    if (in_type == SNNQP_U8) launch_wide_rt<CTV, SNNQP_U8, FUSEV>(rt, a, gx, gy, st);        \
+    else if (in_type == SNNQP_F32) launch_wide_rt<CTV, SNNQP_F32, FUSEV>(rt, a, gx, gy, st); \
+    else launch_wide_rt<CTV, SNNQP_BITS, FUSEV>(rt, a, gx, gy, st);                          \
+  } while (0)
+  if (fuse) {
+    if (p.ct == 2) SNNQP_WIDE_IN(2, true); else SNNQP_WIDE_IN(1, true);
+  } else {
+    if (p.ct == 2) SNNQP_WIDE_IN(2, false); else SNNQP_WIDE_IN(1, false);
+  }
+#undef SNNQP_WIDE_IN
   SNNQP_CHECK_LAUNCH("dense_wide_kernel");
   return SNNQP_OK;
 }
@@ -741,7 +851,7 @@ static int fill_and_launch(DenseWideArgs &a, int in_type, bool fuse, void *ws, i
 int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
                    int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
-                   float *u_out, uint32_t *s_out, hipStream_t st) {
+                   float *u_out, uint32_t *s_out, int32_t *x_flags, hipStream_t st) {
   SNNQP_REQUIRE(x && s_out, SNNQP_EINVAL, "dense wide: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense wide: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
@@ -754,6 +864,7 @@ int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
   a.dq = make_dequant(w->L, w->m);
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out;
+  a.x_flags = x_flags;
   return fill_and_launch(a, in_type, false, nullptr, 0, st);
 }
 
@@ -766,7 +877,8 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
                                         const snnqp_weight_t *w2, const int8_t *wt2,
                                         const snnqp_neuron_t *nrn2, int32_t group,
                                         uint32_t *s1_out, uint32_t *s2_out, float *logits,
-                                        void *ws, int64_t ws_bytes, snnqp_stream_t stream) {
+                                        int32_t *x_flags, void *ws, int64_t ws_bytes,
+                                        snnqp_stream_t stream) {
   using namespace snnqp;
   SNNQP_REQUIRE(x && w1 && w2 && nrn1 && nrn2 && logits, SNNQP_EINVAL, "dense_head_forward: null argument");
   if (const uint32_t code = device_status_read(stream_device((hipStream_t)stream))) {
@@ -788,13 +900,18 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
   else if (T < 1) why = "no timestep";
   if (!why) {
     // (the 128-feature floor of the stand-alone wide kernel does not apply to the fused head)
-    why = dense_mfma_unsupported(in_type, K, N1, w1, wt1, nrn1, SNNQP_BITS);
+    why = dense_mfma_unsupported(in_type == SNNQP_F32 ? SNNQP_U8 : in_type, K, N1, w1, wt1, nrn1, SNNQP_BITS);
     if (!why) why = dense_mfma_unsupported(SNNQP_BITS, N1, N2, w2, wt2, nrn2, SNNQP_BITS);
     if (!why && (x_stride_t < 0 || x_stride_b < 0)) why = "negative strides";
     if (!why && in_type == SNNQP_U8 &&
         ((((uintptr_t)x) & 15) != 0 || x_stride_t % 16 != 0 || x_stride_b % 16 != 0))
       why = "uint8 rows not 16-byte aligned";
-    if (!why && (int64_t)(T - 1) * x_stride_t + 128 * x_stride_b + K >= ((int64_t)1 << 31))
+    if (!why && in_type == SNNQP_F32 &&
+        ((((uintptr_t)x) & 15) != 0 || x_stride_t % 4 != 0 || x_stride_b % 4 != 0))
+      why = "float32 rows not 16-byte aligned";
+    if (!why && in_type == SNNQP_F32 && !x_flags) why = "float32 rows need x_flags";
+    if (!why && ((int64_t)(T - 1) * x_stride_t + 128 * x_stride_b + K) * (in_type == SNNQP_F32 ? 4 : 1) >=
+                    ((int64_t)1 << 31))
       why = "input strides beyond 32-bit offsets within a workgroup";
   }
   SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "dense_head_forward: %s", why);
@@ -810,6 +927,7 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
   a.N2 = N2; a.KS2 = (N1 + 31) / 32; a.group = group;
   a.wt2 = wt2; a.dq2 = make_dequant(w2->L, w2->m); a.nrn2 = make_neuron(nrn2);
   a.s2_out = s2_out; a.logits = logits;
+  a.x_flags = x_flags;
   return fill_and_launch(a, in_type, true, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -26,7 +26,9 @@ struct GenericArgs {
   void *s_out;               // spikes (neuron) or float32 currents (no neuron)
   int32_t s_type;
   int32_t *acc_out;          // optional int32 accumulators (no-neuron mode)
-  int64_t total;             // B * OH * OW * Cout
+  int64_t total;             // B * OH * OW * Cout (OH, OW: pooled when the pool is fused)
+  int32_t FH, FW;            // full-resolution output size (u0 / u_out)
+  const int32_t *pred;       // nullable device word: skip the launch unless *pred != 0
 };
 
 template <int IN>
@@ -43,95 +45,129 @@ __device__ __forceinline__ float load_float(const void *x, int64_t pix_off,
   return (float)load_int<IN == SNNQP_F32 ? SNNQP_U8 : IN>(x, pix_off, c);
 }
 
-template <int IN, bool INTPATH>
+// POOL = 2: a thread owns the 2x2 window of neurons behind one POOLED output (their four membrane
+// potentials) and writes the OR of their spikes -- the max-pool of examples/tcja/models.py:145-147
+// fused, as the MFMA kernels have it; a.total, a.OH / a.OW then count pooled outputs, a.FH / a.FW
+// the full-resolution ones (u0 / u_out).  pred: the whole launch is skipped unless *pred != 0 when
+// the stream reaches it (the float32 re-evaluation behind a speculative integer launch).
+template <int IN, bool INTPATH, int POOL>
 __global__ void __launch_bounds__(256)
 generic_block_kernel(GenericArgs a) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = idx < a.total;
+  if (a.pred && *(const volatile int32_t *)a.pred == 0) return;
+  constexpr int P = POOL * POOL;
   const snnqp_conv_geom_t &g = a.g;
-  int64_t r = live ? idx : 0;
-  const int32_t co = (int32_t)(r % g.Cout); r /= g.Cout;
-  const int32_t ox = (int32_t)(r % a.OW); r /= a.OW;
-  const int32_t oy = (int32_t)(r % a.OH); r /= a.OH;
-  const int32_t b = (int32_t)r;
-  const int32_t grp = co / a.CoutG;
-  const int32_t cin0 = grp * a.CinG;
   const int64_t pix_elems = (IN == SNNQP_BITS) ? a.CWin : g.Cin;
-
-  float bmean = 0.f, bmul = 1.f, bbias = 0.f, dec = 0.f;
   const bool has_bn = a.bn.mean != nullptr;
-  if (has_bn) { bmean = a.bn.mean[co]; bmul = a.bn.mul[co]; bbias = a.bn.bias[co]; }
-  if (a.nrn.kind == SNNQP_NEURON_LIF) dec = a.nrn.decay[co];
-  float u = 0.0f;
-  if (live && a.u0 && a.nrn.kind != SNNQP_NEURON_NONE) u = a.u0[idx];
   const bool word_aligned = (g.Cout & 31) == 0;
   const int32_t CWout = (g.Cout + 31) / 32;
+  const int64_t span = (a.total + 255) / 256 * 256;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < span; idx += (int64_t)gridDim.x * 256) {
+    const bool live = idx < a.total;
+    int64_t r = live ? idx : 0;
+    const int32_t co = (int32_t)(r % g.Cout); r /= g.Cout;
+    const int32_t px = (int32_t)(r % a.OW); r /= a.OW;
+    const int32_t py = (int32_t)(r % a.OH); r /= a.OH;
+    const int32_t b = (int32_t)r;
+    const int32_t grp = co / a.CoutG;
+    const int32_t cin0 = grp * a.CinG;
 
-  for (int32_t t = 0; t < a.T; ++t) {
-    const int64_t img_off = (int64_t)t * a.xs_t + (int64_t)b * a.xs_b;
-    int iacc = 0;
-    float facc = 0.0f;
-    if (live) {
-      for (int32_t kh = 0; kh < g.KH; ++kh) {
-        const int32_t yd = oy * g.stride_h - g.pad_h_lo + kh * g.k_dil_h;
-        if (yd < 0 || yd >= a.Hd || (yd % g.in_dil_h) != 0) continue;
-        const int32_t iy = yd / g.in_dil_h;
-        for (int32_t kw = 0; kw < g.KW; ++kw) {
-          const int32_t xd = ox * g.stride_w - g.pad_w_lo + kw * g.k_dil_w;
-          if (xd < 0 || xd >= a.Wd || (xd % g.in_dil_w) != 0) continue;
-          const int32_t ix = xd / g.in_dil_w;
-          const int64_t pix_off = img_off + ((int64_t)iy * g.W + ix) * pix_elems;
-          const int64_t wbase = ((int64_t)(kh * g.KW + kw) * a.CinG) * g.Cout + co;
-          if (INTPATH) {
-            const int8_t *w = (const int8_t *)a.w;
-            for (int32_t ci = 0; ci < a.CinG; ++ci)
-              iacc += load_int<IN>(a.x, pix_off, cin0 + ci) *
-                      (int)w[wbase + (int64_t)ci * g.Cout];
-          } else {
-            const float *w = (const float *)a.w;
-            for (int32_t ci = 0; ci < a.CinG; ++ci)
-              facc = __builtin_fmaf(load_float<IN>(a.x, pix_off, cin0 + ci),
-                                    w[wbase + (int64_t)ci * g.Cout], facc);
+    float bmean = 0.f, bmul = 1.f, bbias = 0.f, dec = 0.f;
+    if (has_bn) { bmean = a.bn.mean[co]; bmul = a.bn.mul[co]; bbias = a.bn.bias[co]; }
+    if (a.nrn.kind == SNNQP_NEURON_LIF) dec = a.nrn.decay[co];
+    float u[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      u[p] = 0.0f;
+      if (live && a.u0 && a.nrn.kind != SNNQP_NEURON_NONE)
+        u[p] = a.u0[(((int64_t)b * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co];
+    }
+
+    for (int32_t t = 0; t < a.T; ++t) {
+      const int64_t img_off = (int64_t)t * a.xs_t + (int64_t)b * a.xs_b;
+      const int64_t o = (int64_t)t * a.total + idx;
+      bool s = false;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int32_t oy = py * POOL + p / POOL, ox = px * POOL + p % POOL;
+        int iacc = 0;
+        float facc = 0.0f;
+        if (live) {
+          for (int32_t kh = 0; kh < g.KH; ++kh) {
+            const int32_t yd = oy * g.stride_h - g.pad_h_lo + kh * g.k_dil_h;
+            if (yd < 0 || yd >= a.Hd || (yd % g.in_dil_h) != 0) continue;
+            const int32_t iy = yd / g.in_dil_h;
+            for (int32_t kw = 0; kw < g.KW; ++kw) {
+              const int32_t xd = ox * g.stride_w - g.pad_w_lo + kw * g.k_dil_w;
+              if (xd < 0 || xd >= a.Wd || (xd % g.in_dil_w) != 0) continue;
+              const int32_t ix = xd / g.in_dil_w;
+              const int64_t pix_off = img_off + ((int64_t)iy * g.W + ix) * pix_elems;
+              const int64_t wbase = ((int64_t)(kh * g.KW + kw) * a.CinG) * g.Cout + co;
+              if (INTPATH) {
+                const int8_t *w = (const int8_t *)a.w;
+                for (int32_t ci = 0; ci < a.CinG; ++ci)
+                  iacc += load_int<IN>(a.x, pix_off, cin0 + ci) *
+                          (int)w[wbase + (int64_t)ci * g.Cout];
+              } else {
+                const float *w = (const float *)a.w;
+                for (int32_t ci = 0; ci < a.CinG; ++ci)
+                  facc = __builtin_fmaf(load_float<IN>(a.x, pix_off, cin0 + ci),
+                                        w[wbase + (int64_t)ci * g.Cout], facc);
+              }
+            }
           }
         }
+        float cur = INTPATH ? dequant_acc(iacc, a.dq) : facc;
+        if (has_bn) cur = bn_apply(cur, bmean, bmul, bbias);
+        if (a.nrn.kind == SNNQP_NEURON_NONE) {       // (POOL == 1: run_generic)
+          if (live) {
+            ((float *)a.s_out)[o] = cur;
+            if (INTPATH && a.acc_out) a.acc_out[o] = iacc;
+          }
+          continue;
+        }
+        if (live) s |= neuron_step(u[p], cur, a.nrn, dec);
+      }
+      if (a.nrn.kind == SNNQP_NEURON_NONE) continue;
+      if (a.s_type == SNNQP_F32) {
+        if (live) ((float *)a.s_out)[o] = s ? 1.0f : 0.0f;
+      } else if (word_aligned) {
+        // Cout % 32 == 0: the packed layout is the linear bit index idx.
+        const unsigned long long m = __ballot(s);
+        const int lane = threadIdx.x & 63;
+        if (live && (lane & 31) == 0)
+          ((uint32_t *)a.s_out)[o >> 5] = (uint32_t)(lane ? (m >> 32) : m);
+      } else if (live && s) {
+        const int64_t row = idx / g.Cout;
+        const int64_t rows = a.total / g.Cout;
+        atomicOr(&((uint32_t *)a.s_out)[((int64_t)t * rows + row) * CWout + (co >> 5)],
+                 1u << (co & 31));
       }
     }
-    float cur = INTPATH ? dequant_acc(iacc, a.dq) : facc;
-    if (has_bn) cur = bn_apply(cur, bmean, bmul, bbias);
-    const int64_t o = (int64_t)t * a.total + idx;
-    if (a.nrn.kind == SNNQP_NEURON_NONE) {
-      if (live) {
-        ((float *)a.s_out)[o] = cur;
-        if (INTPATH && a.acc_out) a.acc_out[o] = iacc;
-      }
-      continue;
-    }
-    bool s = false;
-    if (live) s = neuron_step(u, cur, a.nrn, dec);
-    if (a.s_type == SNNQP_F32) {
-      if (live) ((float *)a.s_out)[o] = s ? 1.0f : 0.0f;
-    } else if (word_aligned) {
-      // Cout % 32 == 0: the packed layout is the linear bit index idx.
-      const unsigned long long m = __ballot(s);
-      const int lane = threadIdx.x & 63;
-      if (live && (lane & 31) == 0)
-        ((uint32_t *)a.s_out)[o >> 5] = (uint32_t)(lane ? (m >> 32) : m);
-    } else if (live && s) {
-      const int64_t row = idx / g.Cout;
-      const int64_t rows = a.total / g.Cout;
-      atomicOr(&((uint32_t *)a.s_out)[((int64_t)t * rows + row) * CWout + (co >> 5)],
-               1u << (co & 31));
+    if (live && a.u_out && a.nrn.kind != SNNQP_NEURON_NONE) {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        a.u_out[(((int64_t)b * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co] = u[p];
     }
   }
-  if (live && a.u_out && a.nrn.kind != SNNQP_NEURON_NONE) a.u_out[idx] = u;
+}
+
+// words := 0 unless *pred == 0 (the packed raster of a predicated launch whose Cout is not a
+// multiple of 32 is assembled with atomicOr)
+__global__ void __launch_bounds__(256) zero_words_if_kernel(const int32_t *pred, uint32_t *p, int64_t n) {
+  if (pred && *(const volatile int32_t *)pred == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
 }
 
 template <int IN, bool INTPATH>
-static int launch_generic(const GenericArgs &a, hipStream_t st) {
-  const int64_t blocks = ceil_div64(a.total, 256);
-  SNNQP_REQUIRE(blocks < (1ll << 31), SNNQP_EINVAL, "generic block: grid too large");
-  hipLaunchKernelGGL((generic_block_kernel<IN, INTPATH>), dim3((unsigned)blocks),
-                     dim3(256), 0, st, a);
+static int launch_generic(const GenericArgs &a, int pool, hipStream_t st) {
+  int64_t blocks = ceil_div64(a.total, 256);
+  // a grid-stride walk: a predicated launch that is not taken costs one small grid, and no
+  // launch needs more than 2^31 workgroups
+  if (blocks > 16384) blocks = 16384;
+  if (pool == 2)
+    hipLaunchKernelGGL((generic_block_kernel<IN, INTPATH, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((generic_block_kernel<IN, INTPATH, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   SNNQP_CHECK_LAUNCH("generic_block_kernel");
   return SNNQP_OK;
 }
@@ -153,15 +189,19 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
                 int32_t B, const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                 const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                 float *u_out, void *s_out, int s_type, int32_t *acc_out,
-                hipStream_t st) {
+                hipStream_t st, int pool, const int32_t *pred) {
   int32_t OH, OW;
   int rc = check_geom(g, &OH, &OW);
   if (rc) return rc;
+  SNNQP_REQUIRE(pool == 1 || (pool == 2 && nrn && nrn->kind != SNNQP_NEURON_NONE), SNNQP_EINVAL,
+                "generic block: pool must be 1, or 2 with a neuron");
   SNNQP_REQUIRE(x && w && w->w && s_out, SNNQP_EINVAL, "generic block: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "generic block: negative T/B");
   GenericArgs a;
   a.x = x; a.xs_t = xs_t; a.xs_b = xs_b; a.T = T; a.B = B; a.g = *g;
-  a.OH = OH; a.OW = OW;
+  a.FH = OH; a.FW = OW;
+  a.OH = OH / pool; a.OW = OW / pool;
+  a.pred = pred;
   a.Hd = g->H > 0 ? (g->H - 1) * g->in_dil_h + 1 : 0;
   a.Wd = g->W > 0 ? (g->W - 1) * g->in_dil_w + 1 : 0;
   a.CinG = g->Cin / g->groups; a.CoutG = g->Cout / g->groups;
@@ -172,7 +212,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.s_type = s_type;
   a.acc_out = acc_out;
-  a.total = (int64_t)B * OH * OW * g->Cout;
+  a.total = (int64_t)B * a.OH * a.OW * g->Cout;
   if (a.total == 0 || T == 0) return SNNQP_OK;
   if (a.nrn.kind == SNNQP_NEURON_LIF)
     SNNQP_REQUIRE(a.nrn.decay, SNNQP_EINVAL, "LIF neuron needs a decay vector");
@@ -181,8 +221,11 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
     SNNQP_REQUIRE(s_type == SNNQP_F32 || s_type == SNNQP_BITS, SNNQP_EINVAL,
                   "spike output type must be F32 or BITS");
     if (s_type == SNNQP_BITS && (g->Cout & 31) != 0) {
-      const int64_t words = (int64_t)T * B * OH * OW * ((g->Cout + 31) / 32);
-      SNNQP_HIP(hipMemsetAsync(s_out, 0, words * 4, st));
+      const int64_t words = (int64_t)T * B * a.OH * a.OW * ((g->Cout + 31) / 32);
+      const int64_t zb = (words + 255) / 256;
+      hipLaunchKernelGGL(zero_words_if_kernel, dim3((unsigned)(zb < 4096 ? zb : 4096)), dim3(256), 0, st,
+                         pred, (uint32_t *)s_out, words);
+      SNNQP_CHECK_LAUNCH("zero_words_if_kernel");
     }
   }
   const bool intpath = (w->wtype == SNNQP_W_I8);
@@ -195,14 +238,14 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
     const int64_t kk = (int64_t)g->KH * g->KW * a.CinG;
     SNNQP_REQUIRE(kk * 255 * 127 < (1ll << 31), SNNQP_EUNSUPPORTED,
                   "contraction length %lld overflows int32", (long long)kk);
-    return in_type == SNNQP_U8 ? launch_generic<SNNQP_U8, true>(a, st)
-                               : launch_generic<SNNQP_BITS, true>(a, st);
+    return in_type == SNNQP_U8 ? launch_generic<SNNQP_U8, true>(a, pool, st)
+                               : launch_generic<SNNQP_BITS, true>(a, pool, st);
   }
   SNNQP_REQUIRE(w->wtype == SNNQP_W_F32, SNNQP_EINVAL, "unknown weight type");
   switch (in_type) {
-    case SNNQP_F32: return launch_generic<SNNQP_F32, false>(a, st);
-    case SNNQP_U8: return launch_generic<SNNQP_U8, false>(a, st);
-    case SNNQP_BITS: return launch_generic<SNNQP_BITS, false>(a, st);
+    case SNNQP_F32: return launch_generic<SNNQP_F32, false>(a, pool, st);
+    case SNNQP_U8: return launch_generic<SNNQP_U8, false>(a, pool, st);
+    case SNNQP_BITS: return launch_generic<SNNQP_BITS, false>(a, pool, st);
   }
   set_error("unknown input type %d", in_type);
   return SNNQP_EINVAL;

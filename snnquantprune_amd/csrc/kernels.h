@@ -8,7 +8,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
                 int32_t B, const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                 const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                 float *u_out, void *s_out, int s_type, int32_t *acc_out,
-                hipStream_t st);
+                hipStream_t st, int pool = 1, const int32_t *pred = nullptr);
 
 // nullptr when the MFMA kernel can serve the request, else the reason.
 const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,
@@ -22,7 +22,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     int x_max, int32_t *x_seen, hipStream_t st);
+                     int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st);
 
 // per-device state (runtime.hip): the status word kernels report broken invariants into, the
 // probe of the matrix pipe's denormal arithmetic behind DQ_TABLE
@@ -62,7 +62,7 @@ const char *dense_wide_unsupported(int in_type, int32_t T, int32_t K, int32_t N,
 int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B,
                    int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
-                   float *u_out, uint32_t *s_out, hipStream_t st);
+                   float *u_out, uint32_t *s_out, int32_t *x_flags, hipStream_t st);
 
 // codes of magnitude <= 7 on the f8f6f4 MFMA (dense_fp6.hip); row_tiles 0 = choose
 // (ws / ws_bytes: optional workspace for a K split over workgroups, dense_fp6_workspace_bytes)

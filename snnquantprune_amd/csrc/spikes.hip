@@ -117,7 +117,8 @@ f32_to_u8_kernel(const float *__restrict__ x, uint8_t *__restrict__ y,
 template <typename T>
 __global__ void __launch_bounds__(256)
 pack_bits_kernel(const T *__restrict__ x, int64_t rows, int32_t C, int32_t CW,
-                 uint32_t *__restrict__ bits) {
+                 uint32_t *__restrict__ bits, int32_t *__restrict__ flags) {
+  bool bad = false;                  // a value that is neither 0 nor 1 (flags != null)
   const int lane = threadIdx.x & 63;
   const int64_t cpr = (C + 63) / 64;  // chunks per row
   const int64_t nchunks = rows * cpr;
@@ -128,12 +129,17 @@ pack_bits_kernel(const T *__restrict__ x, int64_t rows, int32_t C, int32_t CW,
     const int32_t c0 = (int32_t)(ch % cpr) * 64;
     const int32_t c = c0 + lane;
     bool v = false;
-    if (c < C) v = x[row * C + c] != (T)0;
+    if (c < C) {
+      const T e = x[row * C + c];
+      v = e != (T)0;
+      bad |= v && !(e == (T)1);
+    }
     const unsigned long long m = __ballot(v);
     const int32_t w0 = c0 >> 5;
     if (lane == 0) bits[row * CW + w0] = (uint32_t)m;
     if (lane == 1 && w0 + 1 < CW) bits[row * CW + w0 + 1] = (uint32_t)(m >> 32);
   }
+  if (flags && __ballot(bad) != 0ull && lane == 0) atomicOr(flags, SNNQP_FLAG_GT_ONE);
 }
 
 __global__ void __launch_bounds__(256)
@@ -186,7 +192,8 @@ maxpool_bits_kernel(const uint32_t *__restrict__ x, int64_t NB, int32_t H,
 template <bool BITS>
 __global__ void __launch_bounds__(256)
 vote_kernel(const void *__restrict__ s, int32_t T, int32_t B, int32_t N,
-            int32_t group, float *__restrict__ logits) {
+            int32_t group, float *__restrict__ logits, const int32_t *pred) {
+  if (pred && *(const volatile int32_t *)pred == 0) return;
   const int32_t NC = N / group;
   const int32_t CW = (N + 31) / 32;
   const int64_t n = (int64_t)B * NC;
@@ -381,6 +388,11 @@ int snnqp_f32_to_u8(const float *x, uint8_t *y, int64_t n,
 
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
                     uint32_t *bits, snnqp_stream_t stream) {
+  return snnqp_pack_bits_checked(x, in_type, rows, C, bits, nullptr, stream);
+}
+
+int snnqp_pack_bits_checked(const void *x, int in_type, int64_t rows, int32_t C,
+                            uint32_t *bits, int32_t *flags, snnqp_stream_t stream) {
   SNNQP_REQUIRE(rows >= 0 && C > 0, SNNQP_EINVAL, "pack_bits: bad shape");
   SNNQP_REQUIRE(in_type == SNNQP_F32 || in_type == SNNQP_U8, SNNQP_EINVAL,
                 "pack_bits: input must be F32 or U8");
@@ -391,10 +403,10 @@ int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
   const int grid = grid_for(nchunks * 64);
   if (in_type == SNNQP_F32)
     hipLaunchKernelGGL(pack_bits_kernel<float>, dim3(grid), dim3(256), 0,
-                       (hipStream_t)stream, (const float *)x, rows, C, CW, bits);
+                       (hipStream_t)stream, (const float *)x, rows, C, CW, bits, flags);
   else
     hipLaunchKernelGGL(pack_bits_kernel<uint8_t>, dim3(grid), dim3(256), 0,
-                       (hipStream_t)stream, (const uint8_t *)x, rows, C, CW, bits);
+                       (hipStream_t)stream, (const uint8_t *)x, rows, C, CW, bits, flags);
   SNNQP_CHECK_LAUNCH("pack_bits_kernel");
   return SNNQP_OK;
 }
@@ -526,6 +538,11 @@ int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int
 
 int snnqp_vote(const void *s, int type, int32_t T, int32_t B, int32_t N,
                int32_t group, float *logits, snnqp_stream_t stream) {
+  return snnqp_vote_if(nullptr, s, type, T, B, N, group, logits, stream);
+}
+
+int snnqp_vote_if(const int32_t *pred, const void *s, int type, int32_t T, int32_t B, int32_t N,
+                  int32_t group, float *logits, snnqp_stream_t stream) {
   SNNQP_REQUIRE(s && logits && T > 0 && B >= 0 && N > 0 && group > 0,
                 SNNQP_EINVAL, "vote: bad argument");
   SNNQP_REQUIRE(N % group == 0, SNNQP_EINVAL,
@@ -536,10 +553,10 @@ int snnqp_vote(const void *s, int type, int32_t T, int32_t B, int32_t N,
   const int64_t n = (int64_t)B * (N / group);
   if (type == SNNQP_BITS)
     hipLaunchKernelGGL(vote_kernel<true>, dim3(grid_for(n)), dim3(256), 0,
-                       (hipStream_t)stream, s, T, B, N, group, logits);
+                       (hipStream_t)stream, s, T, B, N, group, logits, pred);
   else
     hipLaunchKernelGGL(vote_kernel<false>, dim3(grid_for(n)), dim3(256), 0,
-                       (hipStream_t)stream, s, T, B, N, group, logits);
+                       (hipStream_t)stream, s, T, B, N, group, logits, pred);
   SNNQP_CHECK_LAUNCH("vote_kernel");
   return SNNQP_OK;
 }

@@ -108,8 +108,10 @@ def _head_key(mod, cfg, x, hidden, nout):
   if isinstance(x, ops.PackedSpikes):
     if not (x.bits.is_cuda and x.ndim == 3 and x.flat_perm is None):
       return None
-  elif not (isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda and x.ndim == 3
-            and x.is_contiguous()):
+  elif not (isinstance(x, torch.Tensor) and x.dtype in (torch.uint8, torch.float32) and x.is_cuda
+            and x.ndim == 3 and x.is_contiguous()):
+    return None
+  if isinstance(x, torch.Tensor) and x.dtype == torch.float32 and not packing.AUTO_INTEGER_INPUTS:
     return None
   p = root.variables.get("params")
   try:
@@ -119,7 +121,7 @@ def _head_key(mod, cfg, x, hidden, nout):
   except (KeyError, TypeError):
     return None
   q = cfg.quant
-  extra = (type(x).__name__, tuple(x.shape), hidden, nout, _layer_bits(cfg, 0), _layer_bits(cfg, 1), id(q.get("weight")),
+  extra = (type(x).__name__, str(getattr(x, "dtype", "")), tuple(x.shape), hidden, nout, _layer_bits(cfg, 0), _layer_bits(cfg, 1), id(q.get("weight")),
            float(q.prune_percentage) >= 0.0, id(cfg.neuron_dynamics))
   return ts, extra
 
@@ -145,8 +147,9 @@ class DenseSNN(nn.Module):
         _head_plans = TensorCache(32)
       plan = _head_plans.get(*key)
       if plan is not None:
-        w1, K, N1, nrn1, w2, N2, nrn2, group, tm, _refs = plan
-        return ops.dense_head_forward(x, w1, K, N1, nrn1, w2, N2, nrn2, group=group, time_major=tm)[0], None
+        w1, K, N1, nrn1, w2, N2, nrn2, group, tm, fb, _refs = plan
+        return ops.dense_head_forward(x, w1, K, N1, nrn1, w2, N2, nrn2, group=group, time_major=tm,
+                                      fallback=fb)[0], None
     layer = SpikingBlock(
         connection_fn=QuantDense(hidden, use_bias=False, dtype=self.dtype,
                                  config=cfg.quant, bits=_layer_bits(cfg, 0),

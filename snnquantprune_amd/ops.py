@@ -384,64 +384,31 @@ def pack_codes_fp6(codes: torch.Tensor, n_pad: Optional[int] = None) -> torch.Te
 
 
 class NotCapturable(RuntimeError):
-  """The step needs a value on the host (the inspection of float32 activations: are they
-  integers, spikes, how large?) and is being recorded into a hipGraph, which cannot wait for
-  one.  Feed the model integer frames (uint8 or the packed formats of snnqp.h), or run it
-  eagerly."""
+  """The step needs a value on the host and is being recorded into a hipGraph, which cannot wait
+  for one.  (Nothing in this package does any more -- float32 inputs are checked on the device,
+  snnqp.h x_flags -- the class stays for callers that catch it.)"""
 
 
-def _no_capture(what: str):
-  if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-    raise NotCapturable("%s reads a device value back to the host and cannot be captured into a "
-                        "graph (nn.capture): pass integer frames, or call the model eagerly" % what)
+@dataclass
+class FloatFallback:
+  """What redoes an integer block whose float32 input turns out not to be integer-valued
+  (the reference casts every input to float32, flax_qdense.py:67 / flax_qconv.py:101: a tensor of
+  integers in [0, 255] takes the exact-integer kernels, anything else the float32 ones -- decided
+  per tensor on the device, with no read-back: snnqp.h, x_flags and the *_if entry points).
 
-
-def inspect_f32(x: torch.Tensor) -> int:
-  """Flags of a float32 activation tensor (one device pass + a 4-byte readback)."""
-  _no_capture("the inspection of float32 activations (ops.inspect_f32)")
-  x = _f32c(x)
-  _require_gpu(x)
-  flags = torch.zeros(1, dtype=torch.int32, device=x.device)
-  L.check(L.lib().snnqp_inspect_f32(_ptr(x), x.numel(), _ptr(flags), _stream()))
-  return int(flags.item())
-
-
-_u8_flag_cache = None
+  weight  the float32 fake-quantised kernel of the same layer (Weight, W_F32)
+  x       the float32 tensor, when the integer launch reads a narrowed copy of it (narrow_f32_async /
+          pack_bits_checked); None when the integer kernel stages the float32 tensor itself
+  pred    the device word (int32 tensor of one element) the narrowing pass reported into; None when
+          the integer kernel reports into a word of its own"""
+  weight: "Weight"
+  x: Optional[torch.Tensor] = None
+  pred: Optional[torch.Tensor] = None
 
 
 def forget_inputs():
-  """Drops the cached facts about activation tensors (their maxima), as if every tensor were
-  new: bench.py calls it each step so that whatever a fresh batch costs is inside the timed
-  region."""
-  global _u8_flag_cache
-  _u8_flag_cache = None
-
-
-def input_max_bound(x) -> int:
-  """Upper bound of an integer-typed activation: 1 for spikes; for uint8 tensors the maximum
-  (at least 1) from one device pass and a 4-byte read-back (cached per tensor version).
-  Off the BASELINE configurations' paths: the event layer checks its own input (CountHint),
-  dense blocks read uint8 rows as they are; what still asks is a uint8 tensor into a conv
-  block with more than two channels, or into a dense block whose K is not a multiple of 16."""
-  global _u8_flag_cache
-  if isinstance(x, (PackedSpikes, PackedFrames)):
-    return 1 if isinstance(x, PackedSpikes) or x.fmt == L.EV1 else 15
-  if x.dtype != torch.uint8:
-    return 0
-  if _u8_flag_cache is None:
-    from ._cache import TensorCache
-    _u8_flag_cache = TensorCache(16)
-  v = _u8_flag_cache.get((x,))
-  if v is None:
-    _no_capture("the inspection of uint8 activations (ops.input_max_bound)")
-    _require_gpu(x)
-    xc = x.contiguous()
-    flags = torch.zeros(1, dtype=torch.int32, device=x.device)
-    L.check(L.lib().snnqp_inspect_u8(_ptr(xc), xc.numel(), _ptr(flags), _stream()))
-    f = int(flags.item())
-    v = max(1, f >> 8)
-    _u8_flag_cache.put((x,), None, v)
-  return v
+  """Kept for callers of earlier versions (bench.py called it each step to drop cached facts about
+  the last batch): nothing about an activation tensor is cached on the host any more."""
 
 
 class CountHint:
@@ -540,25 +507,33 @@ def f32_to_u8(x: torch.Tensor) -> torch.Tensor:
   return y
 
 
-def narrow_f32(x: torch.Tensor):
-  """float32 activations -> (uint8 copy | None, max value): one device pass that
-  inspects and narrows; None when some element is not an integer in [0, 255]."""
-  global _u8_flag_cache
-  _no_capture("narrowing float32 frames (ops.narrow_f32)")
+def narrow_f32_async(x: torch.Tensor):
+  """float32 activations -> (uint8 copy, pred): one device pass (snnqp_narrow_f32) and NO
+  read-back.  `pred` is a one-element int32 device tensor, non-zero when some element is not an
+  integer in [0, 255] (the copy is then meaningless): the predicate of the float32 launch that
+  follows the integer one (FloatFallback)."""
   x = _f32c(x)
   _require_gpu(x)
   y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
   flags = torch.zeros(2, dtype=torch.int32, device=x.device)
   L.check(L.lib().snnqp_narrow_f32(_ptr(x), _ptr(y), x.numel(), _ptr(flags), _stream()))
-  f0, f1 = flags.tolist()
-  if f1 & L.FLAG_NOT_INTEGER:
-    return None, 0
-  vmax = max(1, f0 >> 8)
-  if _u8_flag_cache is None:
-    from ._cache import TensorCache
-    _u8_flag_cache = TensorCache(16)
-  _u8_flag_cache.put((y,), None, vmax)         # input_max_bound(y) needs no second pass
-  return y, vmax
+  return y, flags[1:2]
+
+
+def pack_bits_checked(x: torch.Tensor):
+  """float32 / uint8 [..., C] -> (PackedSpikes, pred): `pred` (one int32 device word) is non-zero
+  when some element is neither 0 nor 1 -- the raster then is not the tensor.  No read-back."""
+  _require_gpu(x)
+  if x.dtype not in (torch.float32, torch.uint8):
+    x = x.to(torch.float32)
+  x = x.contiguous()
+  C = x.shape[-1]
+  rows = x.numel() // C if C else 0
+  bits = torch.empty(tuple(x.shape[:-1]) + ((C + 31) // 32,), dtype=torch.int32, device=x.device)
+  flags = torch.zeros(1, dtype=torch.int32, device=x.device)
+  L.check(L.lib().snnqp_pack_bits_checked(_ptr(x), L.F32 if x.dtype == torch.float32 else L.U8,
+                                          rows, C, _ptr(bits), _ptr(flags), _stream()))
+  return PackedSpikes(bits, C), flags
 
 
 def pack_bits(x: torch.Tensor) -> PackedSpikes:
@@ -695,14 +670,22 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
                      bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
                      want_u: bool = True, packed_out: bool = False, pool: int = 1,
                      impl: int = L.IMPL_AUTO, time_major: bool = True, x_max: int = 0,
-                     x_seen: Optional[torch.Tensor] = None):
+                     x_seen: Optional[torch.Tensor] = None,
+                     fallback: Optional[FloatFallback] = None):
   """x [T, B, H, W, Cin] (or [B, T, ...] with time_major=False) ->
   (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout]).
   x_max: the largest input value expected (a hint, snnqp.h); x_seen: eight int32 device words
-  that receive the largest uint8 input value the launch met and the chunk counts by maximum."""
+  that receive the largest uint8 input value the launch met and the chunk counts by maximum.
+  fallback: float32 input into integer codes (FloatFallback): the integer launch is followed by
+  the predicated float32 one into the same outputs."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
+  x_flags = None
+  if in_type == L.F32 and weight.is_int:
+    if fallback is None:
+      raise ValueError("float32 input into integer codes needs a FloatFallback (the float32 kernel)")
+    x_flags = torch.empty(1, dtype=torch.int32, device=xt.device)
   if x_seen is not None:
     assert x_seen.dtype == torch.int32 and x_seen.numel() >= 8 and x_seen.is_cuda, \
         "x_seen: eight int32 device words (snnqp.h)"
@@ -735,18 +718,34 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
         _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
         _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
         _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
-        int(x_max), _ptr(x_seen), _stream()))
+        int(x_max), _ptr(x_seen), _ptr(x_flags), _stream()))
+  if fallback is not None:
+    # the same block on the float32 kernel, executed only if the word says so (snnqp.h)
+    xf = _f32c(xt if fallback.x is None else fallback.x)
+    pred = x_flags if fallback.pred is None else fallback.pred
+    fw = fallback.weight.struct()
+    fs_t, fs_b = _tb_strides(xf, T, B, time_major, geom.H * geom.W * geom.Cin)
+    L.check(L.lib().snnqp_conv_lif_forward_if(
+        _ptr(pred), _ptr(xf), L.F32, fs_t, fs_b, T, B, ctypes.byref(g), ctypes.byref(fw),
+        ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0), _ptr(u_out), _ptr(s),
+        L.BITS if packed_out else L.F32, pool, _stream()))
   return u_out, (PackedSpikes(s, geom.Cout) if packed_out else s)
 
 
 def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
                       bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None,
                       want_u: bool = True, packed_out: bool = False,
-                      impl: int = L.IMPL_AUTO, time_major: bool = True):
-  """x [T, B, K] -> (u_T [B, N] | None, spikes [T, B, N])."""
+                      impl: int = L.IMPL_AUTO, time_major: bool = True,
+                      fallback: Optional[FloatFallback] = None):
+  """x [T, B, K] -> (u_T [B, N] | None, spikes [T, B, N]).  fallback: as conv_lif_forward."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
+  x_flags = None
+  if in_type == L.F32 and weight.is_int:
+    if fallback is None:
+      raise ValueError("float32 rows into integer codes need a FloatFallback (the float32 kernel)")
+    x_flags = torch.empty(1, dtype=torch.int32, device=xt.device)
   T, B = (xt.shape[0], xt.shape[1]) if time_major else (xt.shape[1], xt.shape[0])
   xs_t, xs_b = _tb_strides(xt, T, B, time_major, xt.shape[-1])
   dev = xt.device
@@ -767,8 +766,16 @@ def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
     L.check(L.lib().snnqp_dense_lif_forward_ws(
         _ptr(xt), in_type, xs_t, xs_b, T, B, K, N, ctypes.byref(w), _ptr(weight.wt),
         ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0),
-        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl,
+        _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, impl, _ptr(x_flags),
         _ptr(ws), 0 if ws is None else ws.numel(), _stream()))
+  if fallback is not None:
+    xf = _f32c(xt if fallback.x is None else fallback.x)
+    pred = x_flags if fallback.pred is None else fallback.pred
+    fw = fallback.weight.struct()
+    L.check(L.lib().snnqp_dense_lif_forward_if(
+        _ptr(pred), _ptr(xf), L.F32, xs_t, xs_b, T, B, K, N, ctypes.byref(fw),
+        ctypes.byref(b) if b is not None else None, ctypes.byref(n), _ptr(u0), _ptr(u_out), _ptr(s),
+        L.BITS if packed_out else L.F32, _stream()))
   return u_out, (PackedSpikes(s, N) if packed_out else s)
 
 
@@ -797,10 +804,12 @@ def _dense_workspace(dev, nbytes: int):
 
 def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight, N2: int,
                        nrn2: Neuron, group: int = 10, want_s1: bool = False,
-                       want_s2: bool = False, time_major: bool = True):
+                       want_s2: bool = False, time_major: bool = True,
+                       fallback: Optional[FloatFallback] = None):
   """The dense head as ONE launch (snnqp_dense_head_forward; examples/tcja/models.py:200-255):
-  x [T, B, K] uint8 or PackedSpikes -> (logits [B, N2 // group], hidden raster | None,
-  output raster | None).  Raises SnnqpError(EUNSUPPORTED) when the head does not fit the fused
+  x [T, B, K] uint8, PackedSpikes or float32 (the rows as the reference holds them, staged in
+  place; `fallback` = the float32 kernel of the FIRST block) -> (logits [B, N2 // group], hidden
+  raster | None, output raster | None).  Raises SnnqpError(EUNSUPPORTED) when the head does not fit the fused
   kernel; the caller then runs the two blocks and the vote one by one."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
@@ -811,8 +820,14 @@ def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight,
   if N2 % group:
     raise ValueError("vote: %d features not divisible by group %d" % (N2, group))
   logits = torch.empty((B, N2 // group), dtype=torch.float32, device=dev)
-  s1 = torch.empty((T, B, (N1 + 31) // 32), dtype=torch.int32, device=dev) if want_s1 else None
-  s2 = torch.empty((T, B, (N2 + 31) // 32), dtype=torch.int32, device=dev) if want_s2 else None
+  x_flags = None
+  if in_type == L.F32:
+    if fallback is None or fallback.x is not None:
+      raise ValueError("float32 rows into the fused head need a FloatFallback of the first block")
+    x_flags = torch.empty(1, dtype=torch.int32, device=dev)
+  redo = fallback is not None          # the predicated launches go through both rasters
+  s1 = torch.empty((T, B, (N1 + 31) // 32), dtype=torch.int32, device=dev) if (want_s1 or redo) else None
+  s2 = torch.empty((T, B, (N2 + 31) // 32), dtype=torch.int32, device=dev) if (want_s2 or redo) else None
   a, b, n1, n2 = w1.struct(), w2.struct(), nrn1.struct(), nrn2.struct()
   # a batch that fills at most half the chip: two workgroups per tile through a workspace
   nws = _head_ws_bytes.get((T, B, N1))
@@ -822,8 +837,23 @@ def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight,
   with _timed("dense_head[%d->%d->%d]" % (K, N1, N2)):
     L.check(L.lib().snnqp_dense_head_forward(
         _ptr(xt), in_type, xs_t, xs_b, T, B, K, N1, ctypes.byref(a), _ptr(w1.wt), ctypes.byref(n1),
-        N2, ctypes.byref(b), _ptr(w2.wt), ctypes.byref(n2), int(group), _ptr(s1), _ptr(s2),
-        _ptr(logits), _ptr(ws), 0 if ws is None else ws.numel(), _stream()))
+        N2, ctypes.byref(b), _ptr(w2.wt), ctypes.byref(n2), int(group),
+        _ptr(s1) if (want_s1 or redo) else None, _ptr(s2) if (want_s2 or redo) else None,
+        _ptr(logits), _ptr(x_flags), _ptr(ws), 0 if ws is None else ws.numel(), _stream()))
+  if redo:
+    # not integer-valued after all: the first block on the float32 kernel, the second (its input
+    # is a spike raster whatever produced it) on the integer direct form, the vote -- each
+    # executed only if the word says so
+    fw = fallback.weight.struct()
+    lib = L.lib()
+    L.check(lib.snnqp_dense_lif_forward_if(_ptr(x_flags), _ptr(xt), L.F32, xs_t, xs_b, T, B, K, N1,
+                                           ctypes.byref(fw), None, ctypes.byref(n1), None, None, _ptr(s1),
+                                           L.BITS, _stream()))
+    cw1 = (N1 + 31) // 32
+    L.check(lib.snnqp_dense_lif_forward_if(_ptr(x_flags), _ptr(s1), L.BITS, B * cw1, cw1, T, B, N1, N2,
+                                           ctypes.byref(b), None, ctypes.byref(n2), None, None, _ptr(s2),
+                                           L.BITS, _stream()))
+    L.check(lib.snnqp_vote_if(_ptr(x_flags), _ptr(s2), L.BITS, T, B, N2, int(group), _ptr(logits), _stream()))
   return (logits, PackedSpikes(s1, N1) if want_s1 else None,
           PackedSpikes(s2, N2) if want_s2 else None)
 

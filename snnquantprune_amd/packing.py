@@ -19,10 +19,28 @@ from . import ops
 from ._cache import TensorCache
 from .quant import QuantDesc
 
-# When True a float32 activation tensor is inspected on the device (one pass +
-# a 4-byte readback) and, if every value is a small non-negative integer, is
-# routed through the exact-integer kernels, like typed uint8 / PackedSpikes.
+# When True a float32 activation tensor into a quantised layer takes the exact-integer kernels
+# SPECULATIVELY -- the reference casts every input to float32 (flax_qdense.py:67,
+# flax_qconv.py:101), so its event frames and spike rasters arrive as integer-valued float32
+# tensors -- with the check on the device: the integer kernel (or the narrowing pass in front of
+# it) verifies every value it reads, and a float32 launch enqueued right behind it redoes the block
+# when one is not an integer in [0, 255] (ops.FloatFallback; snnqp.h, x_flags).  No inspection
+# pass, no read-back, capturable.  False (or integer_inputs(False) around layers whose inputs
+# are real-valued by construction): float32 tensors take the float32 kernels directly.
 AUTO_INTEGER_INPUTS = True
+
+
+class _Speculate:
+  """prepare_input's answer for a float32 tensor that MAY be integer-valued: truthy."""
+
+  def __bool__(self):
+    return True
+
+  def __repr__(self):
+    return "SPECULATE"
+
+
+SPECULATE = _Speculate()
 
 
 import contextlib
@@ -150,32 +168,19 @@ def clear_cache():
 
 
 def prepare_input(x, prefer_bits: Optional[bool] = None):
-  """Returns (tensor-or-PackedSpikes, integer_typed).
-
-  PackedSpikes and uint8 / bool / integer tensors are integer-typed as they are;
-  float32 tensors are inspected when AUTO_INTEGER_INPUTS is set."""
+  """Returns (tensor-or-PackedSpikes, integer_typed): True for PackedSpikes / PackedFrames and
+  uint8 tensors as they are, SPECULATE for a float32 tensor under AUTO_INTEGER_INPUTS (still the
+  float32 tensor: whether it holds integers is found out on the device, by the kernel that reads
+  it), False for a float32 tensor otherwise.  Other integer dtypes are widened to float32 (exact
+  below 2^24) and speculate like it; nothing is read back."""
   if isinstance(x, (ops.PackedSpikes, ops.PackedFrames)):
     return x, True
   if not isinstance(x, torch.Tensor):
     x = torch.as_tensor(x)
-  if x.dtype == torch.uint8:
-    return x, True
-  if x.dtype in (torch.bool, torch.int8, torch.int16, torch.int32, torch.int64):
-    if x.dtype != torch.bool and (int(x.min()) < 0 or int(x.max()) > 255):
-      return x.to(torch.float32), False
-    return x.to(torch.uint8), True
+  if x.dtype in (torch.uint8, torch.bool):
+    return (x if x.dtype == torch.uint8 else x.to(torch.uint8)), True
   if x.dtype != torch.float32:
     x = x.to(torch.float32)
   if not AUTO_INTEGER_INPUTS or x.numel() == 0:
     return x, False
-  if prefer_bits is None:
-    prefer_bits = x.shape[-1] >= 32
-  if not prefer_bits:            # e.g. the 2-channel event frames: one pass narrows + inspects
-    y, _ = ops.narrow_f32(x)
-    return (x, False) if y is None else (y, True)
-  flags = ops.inspect_f32(x)
-  if flags & L.FLAG_NOT_INTEGER:
-    return x, False
-  if not (flags & L.FLAG_GT_ONE):
-    return ops.pack_bits(x), True
-  return ops.f32_to_u8(x), True
+  return x, SPECULATE

@@ -207,7 +207,10 @@ def fused_dense_head(block1, block2, inputs, group: int = 10, want_s1: bool = Fa
       return None
   if block2.batch_major_input or getattr(inputs, "flat_perm", None) is not None:
     return None
-  if not (isinstance(inputs, ops.PackedSpikes)
+  f32 = isinstance(inputs, torch.Tensor) and inputs.dtype == torch.float32
+  if f32 and not packing.AUTO_INTEGER_INPUTS:
+    return None
+  if not (isinstance(inputs, ops.PackedSpikes) or f32
           or (isinstance(inputs, torch.Tensor) and inputs.dtype == torch.uint8)):
     return None
   x = inputs
@@ -229,14 +232,17 @@ def fused_dense_head(block1, block2, inputs, group: int = 10, want_s1: bool = Fa
   nrn2 = block2.neural_dynamics.neuron(N2)
   if w1 is None or w2 is None or w1.wt is None or w2.wt is None or w1.col_sum is None:
     return None
+  # float32 rows (the reference's own input format) are staged in place and checked by the kernel;
+  # the float32 kernel of the first block stands by (ops.FloatFallback)
+  fb = ops.FloatFallback(pk1.float_weight()) if f32 else None
   try:
     out = ops.dense_head_forward(x, w1, K, N1, nrn1, w2, N2, nrn2, group=group, want_s1=want_s1,
-                                 want_s2=want_s2, time_major=tm)
+                                 want_s2=want_s2, time_major=tm, fallback=fb)
   except L.SnnqpError as e:
     if e.code != L.EUNSUPPORTED:
       raise
     return None
-  fused_dense_head.last_plan = (w1, K, N1, nrn1, w2, N2, nrn2, group, tm)    # models.DenseSNN caches it
+  fused_dense_head.last_plan = (w1, K, N1, nrn1, w2, N2, nrn2, group, tm, fb)    # models.DenseSNN caches it
   return out
 
 
@@ -299,13 +305,14 @@ class SpikingBlock(nn.Module):
     conn, norm = self.connection_fn, self.norm_fn
     flat = getattr(inputs, "flat_perm", None)
     x, integer = packing.prepare_input(inputs)
+    spec = integer is packing.SPECULATE      # float32 that may hold integers: decided on the device
     if flat is not None:
       x.flat_perm = flat
     u0 = None if (u is None or isinstance(u, ZeroCarry)) else u
     tm = not self.batch_major_input
     cin = x.shape[-1]
     pk = conn.packed_kernel(cin)
-    packed_out = integer if self.packed is None else bool(self.packed)
+    packed_out = bool(integer) if self.packed is None else bool(self.packed)
     is_dense = isinstance(conn, QuantDense)
     w = None
     if integer:
@@ -320,6 +327,33 @@ class SpikingBlock(nn.Module):
         w = pk.int_weight_mfma((conn.features + 31) // 32 * 32)
     if w is None:
       w = pk.float_weight()
+      spec = False                 # no integer codes for this layer: float32 all the way
+    fb = None
+    if spec:
+      # Speculate on the integer kernels, with the float32 kernel of the same layer standing by
+      # (ops.FloatFallback): either the integer kernel stages the float32 tensor itself -- the
+      # 2-channel event layer, the wide dense kernel: the hot shapes -- or one device pass narrows
+      # it (to spike bits when the layer is wide enough for the bit kernels, else to uint8 counts)
+      # and reports into the predicate of the float32 launch.  Nothing is read back.
+      fbw = pk.float_weight()
+      T_ = x.shape[0] if tm else x.shape[1]
+      if is_dense:
+        direct = (x.ndim == 3 and w.wt is not None and w.col_sum is not None and cin % 16 == 0
+                  and conn.features > 128 and T_ <= 64 and self.impl == L.IMPL_AUTO and packed_out
+                  and (x.data_ptr() & 15) == 0 and x.is_contiguous())
+      else:
+        direct = (x.ndim == 5 and self.impl != L.IMPL_GENERIC and packed_out
+                  and self._event_layer_geometry(conn.geometry(tuple(x.shape[2:-1]), cin)))
+      if direct:
+        fb = ops.FloatFallback(fbw)
+      elif not is_dense and cin >= 32:
+        xb, pred = ops.pack_bits_checked(x)
+        fb = ops.FloatFallback(fbw, x=x, pred=pred)
+        x = xb
+      else:
+        xu, pred = ops.narrow_f32_async(x)
+        fb = ops.FloatFallback(fbw, x=x, pred=pred)
+        x = xu
     if flat is not None:
       # float path: the fmaf order is the channel-major one -> reorder the data
       c, h, ww = flat
@@ -342,15 +376,9 @@ class SpikingBlock(nn.Module):
 
     # uint8 activations into a dense block (config C2's first layer).  The MFMA dense kernel
     # reads uint8 rows in place, any count 0..255 as x - 128 (snnqp.h, col_sum): no packing
-    # pass, no inspection, nothing for the host to wait for.  Rows it cannot take that way
-    # (K not a multiple of 16, more than 64 timesteps) go the older way when they are binary:
-    # one inspection pass (a read-back, cached per tensor version) and a bit-packing pass.
-    if (is_dense and integer and w.wtype == L.W_I8 and isinstance(x, torch.Tensor)
-        and x.dtype == torch.uint8 and self.impl == L.IMPL_AUTO):
-      T_ = x.shape[0] if tm else x.shape[1]
-      direct = w.wt is not None and w.col_sum is not None and cin % 16 == 0 and T_ <= 64
-      if not direct and ops.input_max_bound(x) == 1:
-        x = ops.pack_bits(x)
+    # pass, no inspection, nothing for the host to wait for.
+    # (Rows it cannot take that way -- K not a multiple of 16, more than 64 timesteps -- run on the
+    # direct-form kernel, whatever their values: nothing is inspected.)
     # float32 kernels -- the real-valued TCJA-gated blocks, and unquantised layers whatever
     # feeds them (float32, uint8 counts or packed spikes: widened on the fly) -- run the
     # connection on the f32 MFMA (the same fmaf chain as the direct-form kernel), then the
@@ -373,7 +401,7 @@ class SpikingBlock(nn.Module):
         raise ValueError("QuantDense block expects [T, B, K] inputs, got %s" % (x.shape,))
       u_out, s = ops.dense_lif_forward(x, w, cin, conn.features, nrn, bn=bn, u0=u0,
                                        want_u=self.return_state, packed_out=packed_out,
-                                       impl=self.impl, time_major=tm)
+                                       impl=self.impl, time_major=tm, fallback=fb)
       if self.pool == 2:
         raise ValueError("pool=2 needs a convolutional block")
       return u_out, s
@@ -385,7 +413,7 @@ class SpikingBlock(nn.Module):
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
     hint = None
     if (integer and cin == 2 and nsp == 2 and
-        ((isinstance(x, torch.Tensor) and x.dtype == torch.uint8) or
+        ((isinstance(x, torch.Tensor) and x.dtype in (torch.uint8, torch.float32)) or
          (isinstance(x, ops.PackedFrames) and x.fmt == L.EV4))):
       # the 2-channel event layer: the kernel checks its input itself and only wants to know
       # what to expect -- no inspection pass, no read-back in front of the launch
@@ -421,14 +449,14 @@ class SpikingBlock(nn.Module):
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,
                                       pool=self.pool, impl=impl, time_major=tm,
-                                      x_max=x_max, x_seen=x_seen)
+                                      x_max=x_max, x_seen=x_seen, fallback=fb)
     except L.SnnqpError as e:
       if e.code != L.EUNSUPPORTED or self.pool != 2 or impl == L.IMPL_MFMA:
         raise
       u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                       want_u=self.return_state, packed_out=packed_out,
                                       pool=1, impl=impl, time_major=tm, x_max=x_max,
-                                      x_seen=x_seen)
+                                      x_seen=x_seen, fallback=fb)
       s = ops.maxpool2x2(s)
     if hint is not None:
       hint.launched()

@@ -79,3 +79,16 @@ def fp6_tiles(codes, n_pad=None):
     out[nb, :, :1024] = lanes[:, :, :16].reshape(KS, 1024)
     out[nb, :, 1024:] = lanes[:, :, 16:].reshape(KS, 512)
   return out
+
+
+def input_max_bound(x):
+  """The x_max hint a test hands to ops.conv_lif_forward: 1 for spikes / binary frames, 15 for
+  nibble-packed counts, the maximum (at least 1) of a uint8 tensor (read on the host: tests may)."""
+  from snnquantprune_amd import _lib as L, ops
+  if isinstance(x, ops.PackedSpikes):
+    return 1
+  if isinstance(x, ops.PackedFrames):
+    return 1 if x.fmt == L.EV1 else 15
+  if x.dtype.is_floating_point:
+    return max(1, int(x.max().item())) if x.numel() else 1
+  return max(1, int(x.max().item())) if x.numel() else 1

@@ -35,7 +35,7 @@ def conv_block_random(dev, N, seed, verbose=False):
       x = torch.from_numpy(np.minimum(rng.poisson(lam, (T, B, H, W, cin)), 255).astype(np.uint8)).to(dev)
       if kind == "binary":
         x = x.clamp(max=1)
-      xin, x_max = x, ops.input_max_bound(x)
+      xin, x_max = x, max(1, int(x.max().item()))
     else:
       x = torch.from_numpy((rng.random((T, B, H, W, cin)) < 0.2).astype(np.uint8)).to(dev)
       xin, x_max = ops.pack_bits(x), 1

@@ -65,8 +65,13 @@ def test_argument_errors_are_reported_without_a_gpu():
   bad = L.BnT(8, 8, 8, 0x7F3)
   rc = lib.snnqp_conv_lif_forward(ctypes.c_void_p(8), L.U8, 128, 128 * 4, 4, 1, ctypes.byref(g3),
                                   ctypes.byref(wi), None, ctypes.byref(bad), ctypes.byref(nrn),
-                                  None, None, ctypes.c_void_p(8), L.BITS, 2, L.IMPL_MFMA, 1, None, None)
+                                  None, None, ctypes.c_void_p(8), L.BITS, 2, L.IMPL_MFMA, 1, None, None, None)
   assert rc == L.EINVAL and b"unknown flag bits" in lib.snnqp_last_error()
+  # float32 input into integer codes without the word its check reports into (snnqp.h, x_flags)
+  rc = lib.snnqp_conv_lif_forward(ctypes.c_void_p(8), L.F32, 128, 128 * 4, 4, 1, ctypes.byref(g3),
+                                  ctypes.byref(wi), None, None, ctypes.byref(nrn),
+                                  None, None, ctypes.c_void_p(8), L.BITS, 2, L.IMPL_MFMA, 1, None, None, None)
+  assert rc == L.EINVAL and b"x_flags" in lib.snnqp_last_error()
 
 
 def test_conv_out_shape_matches_reference_table():
