@@ -334,7 +334,28 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+      // The halo is written in the scale of the path the hint EXPECTS (round 5; it used to wait
+      // for the workgroup's verdict: a barrier more per chunk, and every write behind the
+      // reduction) while the chunk's maximum travels through an LDS atomic; a chunk that exceeds
+      // the hint -- rare by construction of the hint -- is loaded and written again in the
+      // general path's scale.
+      // (every wave read the last chunk's maximum before the barriers of its run_chunk)
+      if (tid == 0) wgw[1] = 0u;
       lds_barrier();                       // previous readers of the LDS images are done
+      if (s_task) {
+#pragma unroll
+        for (int i = 0; i < STG_N; ++i) {
+          const int tt = 2 * i + s_half;
+          if (tt < nt) {    // table modes: both bytes scale without a carry (counts <= 31 / 7)
+            const uint16_t val = (uint16_t)(LUTM == LUT_NONE      ? v[i] ^ 0x8080u    // x - 128
+                                            : LUTM == LUT_CHANNEL ? v[i] << 4
+                                                                  : v[i] << 2);
+            uint8_t *p = lds + tt * HIMG2 + s_dst;
+            *(uint16_t *)p = val;
+            *(uint16_t *)(p + HCOPY2 + 2) = val;
+          }
+        }
+      }
       if (lane == 0 && mx != 0) atomicMax(&wgw[1], mx);
       lds_barrier();
       const uint32_t cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wgw[1]);   // one word
@@ -346,22 +367,32 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       hist[3] += cmax > 7u && cmax <= 31u;
       hist[4] += cmax > 31u;
       general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
-      if (s_task) {
-#pragma unroll
-        for (int i = 0; i < STG_N; ++i) {
-          const int tt = 2 * i + s_half;
-          if (tt < nt) {    // table modes: both bytes scale without a carry (counts <= 31 / 7)
-            const uint16_t val = (uint16_t)(general               ? v[i] ^ 0x8080u    // x - 128
-                                            : LUTM == LUT_CHANNEL ? v[i] << 4
-                                                                  : v[i] << 2);
+      if (LUTM != LUT_NONE && general) {
+        // the rare chunk: its values again (an L2 hit; nothing was kept in registers for it)
+        if (s_task) {
+#pragma unroll 1
+          for (int tt = s_half; tt < nt; tt += 2) {
+            uint32_t w2 = 0;
+            if (s_valid) {
+              if constexpr (F32IN) {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const f2v f = *(const f2v *)(s_frames + (int64_t)(t0 + tt) * a.xs_t * 4 + s_off);
+                w2 = (__float2uint_rz(f.x) & 0xFFu) | ((__float2uint_rz(f.y) & 0xFFu) << 8);
+              } else if constexpr (EV4) {
+                const uint32_t pb = *(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
+                w2 = (pb | (pb << 4)) & 0x0F0Fu;
+              } else {
+                w2 = *(const uint16_t *)(s_frames + (int64_t)(t0 + tt) * a.xs_t + s_off);
+              }
+            }
+            const uint16_t val = (uint16_t)(w2 ^ 0x8080u);
             uint8_t *p = lds + tt * HIMG2 + s_dst;
             *(uint16_t *)p = val;
             *(uint16_t *)(p + HCOPY2 + 2) = val;
           }
         }
+        lds_barrier();
       }
-      lds_barrier();
-      if (tid == 0) wgw[1] = 0u;           // for the next chunk (read above, behind a barrier)
       }
       // the FL-step blocks of the chunk: table path (with the membrane update as a fused
       // multiply-add where that is proven bit-identical for this launch) or general path

@@ -92,7 +92,6 @@ struct DenseWideArgs {
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int W_FRING = 6;        // float32 rows: 16-byte loads a thread keeps in flight
 
 // four float32 values -> the four bytes x - 128 of the int8 operand; `bad` collects what is not
 // an integer in [0, 255]: fl(cvt(x)) - x is +0.0 exactly for the integers v_cvt_u32_f32 can hold
@@ -306,12 +305,26 @@ dense_wide_kernel(DenseWideArgs a) {
   // float32 rows: NU 16-byte loads per thread and chunk; load j of wave w covers the chunk's 512
   // bytes of the two rows rho = 16 j + 2 w + (lane >> 5), four values per lane (1 KiB, coalesced)
   constexpr int NU = F32IN ? 2 * RT : 0;
+  // ... of which W_FRING are in flight per thread (the unrolled body of three chunks holds 3 NU
+  // units: a multiple of the ring, so that every ring index is an immediate).  W_FRING x 16 B x 512
+  // threads is what a CU has on its way from HBM: 48 KiB at 6 -- the stream then runs at
+  // (bytes in flight) / (HBM latency under load, ~2.2 us) = 22 GB/s per CU, 5.6 TB/s over the chip
+#ifndef SNNQP_W_FRING
+  constexpr int W_FRING = RT == 3 ? 9 : 6;
+#else
+  constexpr int W_FRING = SNNQP_W_FRING;
+#endif
+  static_assert(!F32IN || (3 * NU) % W_FRING == 0, "ring must divide the unrolled body");
   constexpr int NFRAG = W_KSC * RT;               // A fragments of a chunk
   constexpr int NSLOT = NFRAG * CT;               // MFMAs of a chunk
   // B ring, k-steps (the unrolled body is 12 long).  float32 rows: the loop runs at the pace of
   // HBM, a look-ahead of three k-steps covers the L2 round trip, and the sixteen registers pay for
   // the row loads in flight (RT 4 x CT 2 spilled 450 bytes with a ring of 6)
-  constexpr int RB = RT * CT >= 6 ? (F32IN && RT * CT >= 8 ? 4 : 6) : 12;
+#ifndef SNNQP_W_RBF
+  constexpr int RB = RT * CT >= 6 ? (F32IN ? 3 : 6) : 12;
+#else
+  constexpr int RB = RT * CT >= 6 ? (F32IN ? SNNQP_W_RBF : 6) : 12;
+#endif
   constexpr int NW = (16 * RT * CT * 2 + 63) / 64;
   // (the fused head overlays the dead A images: raster | count / T per (sample, feature) | a flag)
   constexpr int LDSB = W_NBUF * ABYTES > ROWS * W_S1P * 4 + W_VOTE_SB * 512 + 16 ? W_NBUF * ABYTES
@@ -341,15 +354,25 @@ dense_wide_kernel(DenseWideArgs a) {
   // over x back is what every accumulator of the lane starts from
   int col[CT];
   bool col_live[CT];
+  int acc0[CT];
   v16i acc[RT][CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     col[ct] = (nb0 + ct) * 32 + n;
     col_live[ct] = col[ct] < a.N;
-    const int o = (U8 && col_live[ct]) ? 128 * a.col_sum[col[ct]] : 0;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r][ct] = v16i{o, o, o, o, o, o, o, o, o, o, o, o, o, o, o, o};
+    acc0[ct] = (U8 && col_live[ct]) ? 128 * a.col_sum[col[ct]] : 0;
   }
+  // (float32 rows: the accumulators are set behind the prologue, whose sixteen row loads in
+  // flight live in the registers they will occupy)
+  auto set_acc = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int o = acc0[ct];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r][ct] = v16i{o, o, o, o, o, o, o, o, o, o, o, o, o, o, o, o};
+    }
+  };
+  if constexpr (!F32IN) set_acc();
 
   // ---- staging tasks: the same (row, piece) for every chunk -------------------------------
   uint32_t roff[F32IN ? NU : TPT];
@@ -501,23 +524,23 @@ dense_wide_kernel(DenseWideArgs a) {
 
   // ---- prologue ------------------------------------------------------------------------------
   if constexpr (F32IN) {
-    // chunks 0 and 1 into their images, W_FRING units at a time; then the ring as step 0 expects
-    // it: the first units of chunk 2 in flight
+    // chunks 0 and 1 into their images -- all 2 NU loads in flight at once (one round trip to HBM
+    // instead of three: 16 k -> 8 k cycles per tile) --, then the ring as step 0 expects it: the
+    // first units of chunk 2 in flight
+    {
+      v4f pro[2 * NU];
 #pragma unroll
-    for (int u0 = 0; u0 < 2 * NU; u0 += W_FRING) {
+      for (int u = 0; u < 2 * NU; ++u) pro[u] = f32_load(phys(u / NU), u % NU);
 #pragma unroll
-      for (int u = u0; u < u0 + W_FRING && u < 2 * NU; ++u) fring[u % W_FRING] = f32_load(phys(u / NU), u % NU);
-      if (u0 == 0) {
+      for (int ks = 0; ks < RB - 1; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < RB - 1; ++ks)
+        for (int ct = 0; ct < CT; ++ct) load_b1(bring[ks][ct], 0, ks, ct);
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) load_b1(bring[ks][ct], 0, ks, ct);
-      }
+      for (int u = 2 * NU; u < 2 * NU + W_FRING; ++u) fring[u % W_FRING] = f32_load(phys(u / NU), u % NU);
 #pragma unroll
-      for (int u = u0; u < u0 + W_FRING && u < 2 * NU; ++u) f32_store(fring[u % W_FRING], phys(u / NU), u % NU, u / NU);
+      for (int u = 0; u < 2 * NU; ++u) f32_store(pro[u], phys(u / NU), u % NU, u / NU);
     }
-#pragma unroll
-    for (int u = 2 * NU; u < 2 * NU + W_FRING; ++u) fring[u % W_FRING] = f32_load(phys(u / NU), u % NU);
+    set_acc();
   } else {
 #pragma unroll
   for (int d = 0; d < W_NBUF; ++d)
