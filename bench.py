@@ -94,6 +94,9 @@ def parse(argv=None):
   ap.add_argument("--no-fed-leg", action="store_true",
                   help="skip the short host-fed leg (ev1 frames through the feeder) that the "
                        "default run appends to the line as `fed`")
+  ap.add_argument("--no-legs", action="store_true",
+                  help="skip the other BASELINE configurations (C2, C5, the float32 formats) that the "
+                       "default run times after the headline and reports as `legs`")
   ap.add_argument("--random-bn", action="store_true",
                   help="BatchNorm with random running statistics / scale / bias (a trained "
                        "model) instead of the freshly initialised one (mean 0, var 1, scale 1, "
@@ -842,7 +845,8 @@ def main(argv=None):
   # per-GPU share (B = 512, T = 50, mixed 2/4-bit, 95 % pruned, 10 classes; EV1 frames)
   default_headline = (world == 1 and args.model == "c3" and args.input == "ev1" and B == 1024 and T == 20
                       and not args.layer_bits and args.bits == 4 and not args.counts and not args.random_bn
-                      and args.feed == "resident" and not args.no_fed_leg and not args.graph)
+                      and args.feed == "resident" and not args.no_fed_leg and not args.graph
+                      and not args.no_legs)
   if default_headline:
     del x, frames_u8
     torch.cuda.empty_cache()

@@ -18,5 +18,5 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
-python tools/pmc_summary.py $OUT --json $OUT/summary.json --traffic $OUT/traffic.json --input-format ${PMC_INPUT:-ev1} > $OUT/summary.txt
+python tools/pmc_summary.py $OUT --steps 3 --json $OUT/summary.json --traffic $OUT/traffic.json --input-format ${PMC_INPUT:-ev1} > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -14,5 +14,5 @@ pass() {  # pass name, counters...
 pass w SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 pass i SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_SCA
 pass l SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM
-python tools/pmc_summary.py $O/pmc_$name --json $O/pmc_${name}_summary.json > $O/pmc_${name}_summary.txt 2>&1
+python tools/pmc_summary.py $O/pmc_$name --steps 3 --json $O/pmc_${name}_summary.json > $O/pmc_${name}_summary.txt 2>&1
 grep -A26 "bits_kernel.*#0\|bits_kernel[^#]*$" $O/pmc_${name}_summary.txt | head -30
