@@ -168,7 +168,7 @@ typedef struct {
  * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward, snnqp_device_status,
  * snnqp_workqueue_*, snnqp_dense_lif_forward_ws; 500: float32 inputs into integer blocks --
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
- * predicated snnqp_*_if entry points, snnqp_pack_bits_checked).  A binding compares snnqp_version()
+ * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 500
 int snnqp_version(void);
@@ -253,6 +253,28 @@ int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
 int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
                        const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                        float *y, int32_t *acc, snnqp_stream_t stream);
+
+/* ---- connection on gate x raster (no neuron) ------------------------------------
+ * replaces: QuantConv (flax_qconv.py:93-171; 3x3, stride 1, pad 1) on the product of a spike
+ *           raster and a per-(image, channel) gate -- the conv block behind a TCJA gate,
+ *           x = s * sigmoid(...)[:, :, None, None, :], examples/tcja/models.py:95-97 -> :149-187.
+ * The 'gint' contraction: the gate of a channel multiplies all
+ * nine taps of that channel, so it is factored out of them --
+ *     I[p][c][o] = sum over the taps of code * s          (exact integer, on the matrix pipe)
+ *     acc[p][o]  = fmaf(gate[c], I[p][c][o], acc[p][o])   for c = 0 .. Cin - 1, from +0
+ *     y[p][o]    = fl(fl(acc / L) * m)
+ * s     [NB][H][W][ceil(Cin / 32)] spike words (SNNQP_BITS), gate [NB][Cin] float32,
+ * y     float32 [NB][H][W][Cout].  w: SNNQP_W_I8 codes with code_max <= 7 (DuQ up to 4 bits),
+ * HWIO; packed: the same codes as snnqp_pack_codes_gated lays them out
+ * (snnqp_conv_gated_packed_bytes bytes).  Cin in {32, 64, 96, 128}; any H, W, Cout.
+ * SNNQP_EUNSUPPORTED otherwise: the caller multiplies (snnqp_apply_gate) and takes the float32
+ * connection (snnqp_conv_forward). */
+int64_t snnqp_conv_gated_packed_bytes(int32_t Cin, int32_t Cout);
+int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *packed,
+                           snnqp_stream_t stream);
+int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
+                             const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                             const void *packed, float *y, snnqp_stream_t stream);
 
 /* ---- fused SpikingBlock ---------------------------------------------------
  * replaces: SpikingBlock.__call__ (nn.scan over T of connection -> norm ->

@@ -13,6 +13,10 @@
  *   which q differs from the IEEE quotient fl(a / L) (DuQ dequantisation
  *   x / (n_lvl - 1), quant.py:443).  Must return 0.
  *
+ * oracle_fma_rows: acc[i][j] = fmaf(g[i], x[i][j], acc[i][j]) -- one step of the 'gint' chain
+ *   (snn_oracle.gated_conv: a sigmoid gate per input channel times the exact integer sum of that
+ *   channel's codes over the taps; examples/tcja/models.py:95-97 feeding models.py:149-187).
+ *
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC -fopenmp oracle_c.c -lm
  */
 #include <math.h>
@@ -47,4 +51,12 @@ int64_t oracle_check_div(int32_t L, int32_t amax) {
     if (memcmp(&q, &ref, 4) != 0 && !(q == 0.0f && ref == 0.0f)) ++bad;
   }
   return bad;
+}
+
+void oracle_fma_rows(float *acc, const float *g, const float *x, int64_t m, int64_t n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < m; ++i) {
+    const float gi = g[i];
+    for (int64_t j = 0; j < n; ++j) acc[i * n + j] = fmaf(gi, x[i * n + j], acc[i * n + j]);
+  }
 }

@@ -94,6 +94,8 @@ def clib():
     lib.oracle_fseq_matmul.restype = None
     lib.oracle_check_div.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.oracle_check_div.restype = i64
+    lib.oracle_fma_rows.argtypes = [fp, fp, fp, i64, i64]
+    lib.oracle_fma_rows.restype = None
     _clib = lib
   return _clib
 
@@ -535,6 +537,61 @@ def quant_conv(x, qw: QWeight, strides=None, padding="SAME", input_dilation=None
 # ---------------------------------------------------------------------------
 
 
+def gated_conv(s, gate, qw: QWeight, padding=((1, 1), (1, 1))):
+  """The 'gint' contraction: QuantConv (flax_qconv.py:93-171, stride 1) on the product of a spike
+  raster and a per-(image, channel) gate -- what a TCJA block hands to the next conv block,
+  x = s * sigmoid(...)[:, :, None, None, :] (examples/tcja/models.py:95-97 -> :149-187).
+
+  s [NB, H, W, C] in {0, 1}; gate [NB, C] float32 -> currents float32 [NB, OH, OW, Cout]:
+    I[p, c, o]  = sum over the taps of code[tap, c, o] * s[pixel of the tap, c]    (exact integer)
+    acc[p, o]   = fmaf(gate[c], I[p, c, o], acc[p, o])  for c = 0, 1, ..., C - 1     (start +0)
+    current     = fl(fl(acc / L) * m)                                              (quant.py:443,467)
+  The reference multiplies float32 fake-quantised weights with the float32 products g * s and
+  sums in XLA's order; this contract factors the gate out of the nine taps of its channel -- the
+  same real number, C roundings instead of 9 C -- so that the taps are summed as integers
+  (oracle/int_vs_float.py reports its distance to the reference-literal float mode)."""
+  assert qw.quantised
+  s = np.asarray(s)
+  gate = np.ascontiguousarray(gate, dtype=F32)
+  NB, H, W, C = s.shape
+  kh, kw, cin, cout = qw.q.shape
+  assert cin == C and gate.shape == (NB, C) and _is_integer_valued(s)
+  cols = im2col(s.astype(F32), (kh, kw), (1, 1), resolve_padding((H, W), (kh, kw), (1, 1), padding))
+  OH, OW = cols.shape[1], cols.shape[2]
+  cols = cols.reshape(NB * OH * OW, kh * kw, C)          # (kh, kw, cin) order of im2col
+  codes = qw.q.reshape(kh * kw, C, cout).astype(F32)
+  acc = np.zeros((NB * OH * OW, cout), F32)
+  for c in range(C):
+    I = np.ascontiguousarray(cols[:, :, c]) @ np.ascontiguousarray(codes[:, c, :])   # exact: |I| <= 9 * 127
+    g = np.ascontiguousarray(np.repeat(gate[:, c], OH * OW))
+    clib().oracle_fma_rows(_fp(acc), _fp(g), _fp(np.ascontiguousarray(I, dtype=F32)), acc.shape[0], cout)
+  y = ((acc / qw.L) * qw.m).astype(F32)
+  return y.reshape(NB, OH, OW, cout)
+
+
+def gated_conv_block(spikes, gate, qw: QWeight, bn: Optional[dict], neuron_cfg=None, u0=None):
+  """SpikingBlock(QuantConv 3x3 pad 1, BatchNorm, neuron) on gate[T, B, C] x spikes[T, B, H, W, C]
+  in the 'gint' mode."""
+  norm = None
+  if bn is not None:
+    norm = lambda x: batchnorm_eval(x, bn["mean"], bn["var"], bn.get("scale"),
+                                    bn.get("bias"), bn.get("eps", 1e-5))
+  T = spikes.shape[0]
+  seq = [(spikes[t], gate[t]) for t in range(T)]
+  neuron = _neuron(neuron_cfg or {})
+  u = None
+  out = []
+  for st, gt in seq:
+    x = gated_conv(st, gt, qw)
+    if norm is not None:
+      x = norm(x)
+    if u is None:
+      u = np.zeros_like(x) if u0 is None else np.asarray(u0, F32)
+    u, sp = neuron(u, x)
+    out.append(sp)
+  return u, np.stack(out)
+
+
 def heaviside(x):
   """Forward of atan / fast_sigmoid / ... (spiking_learning.py:139-241): x >= 0."""
   return (np.asarray(x, dtype=F32) >= F32(0)).astype(F32)
@@ -788,12 +845,15 @@ def tcja(x_seq, qw_t: QWeight, qw_c: QWeight, probes: Optional[dict] = None, tag
 
 def cextnet_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
                     tcja_qw: Sequence[Tuple[QWeight, QWeight]], dense_qw: Sequence[QWeight],
-                    neuron_cfg=None, group=10, probes: Optional[dict] = None):
+                    neuron_cfg=None, group=10, probes: Optional[dict] = None, gated="gint"):
   """Full CextNet (models.py:31-257), eval.  conv_qw: the five 3x3 kernels;
   tcja_qw: [(conv_t, conv_c)] x 2; dense_qw: the two dense kernels.  Integer
   mode while activations are spikes, 'fseq' once they are real-valued.
   probes: dict that receives the per-slice densities (`sparse_nums`) the model sows
-  (models.py:128-142 and the like), keyed `<name>_inpt` / `<name>_out`."""
+  (models.py:128-142 and the like), keyed `<name>_inpt` / `<name>_out`.
+  gated: how the conv block behind the first TCJA gate contracts its gate x raster input --
+  "gint" (gated_conv: integer sums per channel, one float32 chain over the gates; the product's
+  contract since round 5) or "fseq" (the fmaf chain over (kh, kw, cin) of the float32 product)."""
   x = np.swapaxes(np.asarray(inputs), 0, 1)
   out = {}
 
@@ -807,14 +867,19 @@ def cextnet_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
     x = max_pool_2x2(s)
     out["pool%d" % i] = x
   mode = "int"
+  pooled_s = gate = None
   for i in range(2):
     probe("conv_t_%d_inpt" % i, x)
-    _, s = conv_block(x, conv_qw[3 + i], bns[3 + i], neuron_cfg, mode)
+    if mode == "fseq" and gated == "gint" and conv_qw[3 + i].quantised:
+      _, s = gated_conv_block(pooled_s, gate, conv_qw[3 + i], bns[3 + i], neuron_cfg)
+    else:
+      _, s = conv_block(x, conv_qw[3 + i], bns[3 + i], neuron_cfg, mode)
     probe("conv_t_%d_out" % i, s)
     out["conv_t_%d" % i] = s
     y, gate = tcja(s, *tcja_qw[i], probes=probes, tag=str(i))
     out["gate%d" % i] = gate
     x = max_pool_2x2(y)
+    pooled_s = max_pool_2x2(s)           # max(g * s_i) = g * max(s_i): g > 0, s in {0, 1}
     mode = "fseq"
   xf = flatten_channel_major(x)
   probe("dense1_inpt", xf)

@@ -1,0 +1,248 @@
+// QuantConv 3x3 on (gate x spike raster): the conv block behind a TCJA gate in the reference's
+// full model (examples/tcja/models.py:95-97 -> :149-187; x = s * sigmoid(...)[:, :, None, None, :]
+// into QuantConv, flax_qconv.py:158-168), in the 'gint' contract:
+//     I[p, c, o] = sum over the nine taps of code[tap, c, o] * s[tap's pixel, c]     (exact integer)
+//     acc[p, o]  = fmaf(gate[c], I[p, c, o], acc[p, o])   for c = 0 .. C - 1          (start +0)
+//     current    = fl(fl(acc / L) * m)
+// The gate of a channel multiplies all nine taps of that channel, so it is factored out of them:
+// the taps are summed as integers on the matrix pipe -- one v_mfma_scale_f32_32x32x64_f8f6f4 per
+// (32 pixels, channel, 32 outputs) with K = the nine taps (fp4 spikes x fp6 codes, exact in the
+// float32 accumulator) -- and the C gates are applied by one fmaf chain per output on the vector
+// unit.  The float32 connection this replaces (fseq_gemm.hip: K = 9 C fmaf on the f32 MFMA) took
+// 3.1 ms for the 8 x 8 x 128 -> 128 layer of CextNet at B = 1024, T = 20; this one is bound by its
+// 64 fmaf per MFMA.
+//
+// A wave owns a 4 x 8-pixel patch of one image and all (up to 128) outputs of a blockIdx.y:
+//  1. the nine tap words of its pixels are transposed once into an LDS table of A-operand dwords,
+//     At[c][pixel] = the eight fp4 nibbles of taps 0..7 of channel c (16 KiB per wave); tap 8 stays
+//     in registers as the spike words of that tap;
+//  2. loop over c: A = {At[c][pixel], tap 8}, B = the pre-packed fp6 codes of (c, 32 outputs),
+//     MFMA from C = 0, then acc = fmaf(gate[c], result, acc) -- gate[c] is a scalar register;
+//  3. dequantise, store float32 currents [NB][H][W][Cout] (BatchNorm and the neuron follow as
+//     the stand-alone scan, as behind the float32 connection).
+#include "kernels.h"
+
+namespace snnqp {
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int CG_WAVES = 4;
+constexpr int CG_CMAX = 128;          // input channels (the LDS table is CMAX x 32 dwords per wave)
+
+struct ConvGatedArgs {
+  const uint32_t *s;      // [NB][H][W][CW] spike words
+  const float *gate;      // [NB][C]
+  const uint32_t *bp;     // packed codes [C][OT][64 lanes][2 dwords] (pack_codes_gated_kernel)
+  float *y;               // [NB][H][W][Cout]
+  int64_t NB, npatch;
+  int32_t H, W, C, CW, Cout, OT, tiles_y, tiles_x;
+  float L, m;
+};
+
+// integer -7..7 -> e2m3 (runtime.hip enc6)
+__device__ __forceinline__ uint32_t enc6(int v) {
+  const uint32_t mag = (uint32_t)(v < 0 ? -v : v);
+  const uint32_t code = mag == 0 ? 0u : mag == 1 ? 8u : mag == 2 ? 16u : mag == 3 ? 20u : mag == 4 ? 24u
+                        : mag == 5 ? 26u : mag == 6 ? 28u : 30u;
+  return code | (v < 0 ? 32u : 0u);
+}
+
+}  // namespace
+
+// codes int8 HWIO [9][C][Cout] -> bp[c][ot][lane][2]: lane (n, h = 0) holds the fp6 values of taps
+// 0..7 at bits [6 j, 6 j + 6) and, lane (n, h = 1), tap 8 at bits [0, 6) -- k = 32 h + j of the
+// 64-deep matrix instruction; columns beyond Cout are zero.
+__global__ void __launch_bounds__(256)
+pack_codes_gated_kernel(const int8_t *w, int32_t C, int32_t Cout, int32_t OT, uint32_t *bp) {
+  const int64_t total = (int64_t)C * OT * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63), n = lane & 31, h = lane >> 5;
+    const int ot = (int)((i >> 6) % OT), c = (int)((i >> 6) / OT);
+    const int o = ot * 32 + n;
+    unsigned long long bits = 0;
+    if (o < Cout) {
+      if (h == 0) {
+        for (int tap = 0; tap < 8; ++tap)
+          bits |= (unsigned long long)enc6(w[((int64_t)tap * C + c) * Cout + o]) << (6 * tap);
+      } else {
+        bits = enc6(w[((int64_t)8 * C + c) * Cout + o]);
+      }
+    }
+    bp[i * 2] = (uint32_t)bits;
+    bp[i * 2 + 1] = (uint32_t)(bits >> 32);
+  }
+}
+
+__global__ void __launch_bounds__(CG_WAVES * 64, 2)
+conv_gated_kernel(ConvGatedArgs a) {
+  __shared__ uint32_t At[CG_WAVES][CG_CMAX][32];
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t patch = (int64_t)blockIdx.x * CG_WAVES + wave;
+  if (patch >= a.npatch) return;                      // (no barrier below: waves are independent)
+  const int ppi = a.tiles_y * a.tiles_x;
+  const int64_t img = patch / ppi;
+  const int pi = (int)(patch - img * ppi);
+  const int y0 = (pi / a.tiles_x) * 4, x0 = (pi % a.tiles_x) * 8;
+  const int py = n >> 3, px = n & 7;                  // this lane's pixel of the 4 x 8 patch
+  const uint32_t *simg = a.s + img * a.H * a.W * a.CW;
+
+  // ---- 1. the tap words of pixel (py, px): lanes of half h transpose the channels
+  //         [h C / 2, (h + 1) C / 2); every lane keeps the words of tap 8 -------------------------
+  auto tap_word = [&](int tap, int wg) -> uint32_t {
+    const int gy = y0 + py + tap / 3 - 1, gx = x0 + px + tap % 3 - 1;
+    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && wg < a.CW;
+    return in ? simg[((int64_t)gy * a.W + gx) * a.CW + wg] : 0u;
+  };
+  uint32_t w8[CG_CMAX / 32];
+#pragma unroll
+  for (int wg = 0; wg < CG_CMAX / 32; ++wg) w8[wg] = tap_word(8, wg);
+  const int wgs_half = (a.CW + 1) / 2;                // word groups per lane half
+  for (int q = 0; q < wgs_half; ++q) {
+    const int wg = h * wgs_half + q;
+    uint32_t tw[8];
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) tw[tap] = tap_word(tap, wg);
+    if (wg < a.CW) {
+#pragma unroll 4
+      for (int b = 0; b < 32; ++b) {
+        uint32_t d0 = 0;
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) d0 |= ((tw[tap] >> b) & 1u) << (4 * tap + 1);   // fp4 1.0 = 0b0010
+        At[wave][wg * 32 + b][n] = d0;
+      }
+    }
+  }
+  // (the table is read by the lanes of this wave only: LDS operations of a wave complete in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- 2. the chain over the channels -------------------------------------------------------
+  const int ot0 = blockIdx.y * 4;
+  const int nt = min(4, a.OT - ot0);
+  v16f acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float *grow = a.gate + img * a.C;             // wave-uniform: scalar loads
+  const uint32_t *bpl = a.bp + ((int64_t)ot0 * 64 + lane) * 2;
+  // four channels per group; the codes of the next group are requested before this group's
+  // matrix instructions (an L2 round trip per group would otherwise sit in front of every one)
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  constexpr int GC = 4;
+  u2 bcur[GC][4], bnxt[GC][4];
+  auto load_group = [&](u2 (&dst)[GC][4], int c0) {
+#pragma unroll
+    for (int j = 0; j < GC; ++j) {
+      const int c = min(c0 + j, a.C - 1);
+      const uint32_t *bc = bpl + (int64_t)c * a.OT * 128;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dst[j][t] = *(const u2 *)(bc + (t < nt ? t : 0) * 128);
+    }
+  };
+  load_group(bcur, 0);
+  for (int c0 = 0; c0 < a.C; c0 += GC) {
+    load_group(bnxt, c0 + GC < a.C ? c0 + GC : c0);
+    float g[GC];
+#pragma unroll
+    for (int j = 0; j < GC; ++j) g[j] = grow[c0 + j];
+#pragma unroll
+    for (int j = 0; j < GC; ++j) {
+      const int c = c0 + j;
+      const uint32_t d0 = At[wave][c][n];
+      // lanes of half 1 hold k = 32 ..: tap 8 in nibble 0 (fp4 1.0 = 0b0010)
+      const uint32_t t8 = ((w8[(c >> 5) & (CG_CMAX / 32 - 1)] >> (c & 31)) & 1u) << 1;
+      const v8i A = {(int)(h ? t8 : d0), 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+          const v8i B = {(int)bcur[j][t].x, (int)bcur[j][t].y, 0, 0, 0, 0, 0, 0};
+          const v16f I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 4 /* fp4 */, 2 /* fp6 */,
+                                                                           0, 127, 0, 127);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(g[j], I[i], acc[t][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GC; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bcur[j][t] = bnxt[j][t];
+  }
+
+  // ---- 3. dequantise and store: lane = output, register i = pixel (i & 3) + 8 (i >> 2) + 4 h ----
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int o = (ot0 + t) * 32 + n;
+    if (t < nt && o < a.Cout) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int gy = y0 + (row >> 3), gx = x0 + (row & 7);
+        if (gy < a.H && gx < a.W) {
+          const float q = acc[t][i] / a.L;
+          a.y[((img * a.H + gy) * a.W + gx) * a.Cout + o] = q * a.m;
+        }
+      }
+    }
+  }
+}
+
+const char *conv_gated_unsupported(const snnqp_conv_geom_t *g, const snnqp_weight_t *w) {
+  if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
+  if (!(w->code_max > 0 && w->code_max <= 7)) return "codes beyond +-7 (fp6)";
+  if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1) return "not 3x3 / stride 1";
+  if (g->pad_h_lo != 1 || g->pad_h_hi != 1 || g->pad_w_lo != 1 || g->pad_w_hi != 1) return "padding is not 1";
+  if (g->in_dil_h != 1 || g->in_dil_w != 1 || g->k_dil_h != 1 || g->k_dil_w != 1 || g->groups != 1)
+    return "dilated or grouped convolution";
+  if (g->Cin < 32 || g->Cin > CG_CMAX || g->Cin % 32) return "input channels not 32, 64, 96 or 128";
+  if (g->H <= 0 || g->W <= 0 || g->Cout <= 0) return "empty geometry";
+  return nullptr;
+}
+
+}  // namespace snnqp
+
+extern "C" int64_t snnqp_conv_gated_packed_bytes(int32_t Cin, int32_t Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (int64_t)Cin * ((Cout + 31) / 32) * 64 * 2 * 4;
+}
+
+extern "C" int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *packed,
+                                      snnqp_stream_t stream) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(w && packed && Cin > 0 && Cout > 0, SNNQP_EINVAL, "pack_codes_gated: bad argument");
+  const int OT = (Cout + 31) / 32;
+  const int64_t total = (int64_t)Cin * OT * 64;
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(pack_codes_gated_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, w, Cin, Cout, OT, (uint32_t *)packed);
+  SNNQP_CHECK_LAUNCH("pack_codes_gated_kernel");
+  return SNNQP_OK;
+}
+
+extern "C" int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
+                                        const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                                        const void *packed, float *y, snnqp_stream_t stream) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(s && gate && g && w && packed && y && NB >= 0, SNNQP_EINVAL, "conv_gated_forward: bad argument");
+  SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
+  const char *why = conv_gated_unsupported(g, w);
+  SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "conv_gated_forward: %s", why);
+  if (NB == 0) return SNNQP_OK;
+  ConvGatedArgs a;
+  a.s = s; a.gate = gate; a.bp = (const uint32_t *)packed; a.y = y;
+  a.NB = NB; a.H = g->H; a.W = g->W; a.C = g->Cin; a.CW = (g->Cin + 31) / 32; a.Cout = g->Cout;
+  a.OT = (g->Cout + 31) / 32;
+  a.tiles_y = (g->H + 3) / 4; a.tiles_x = (g->W + 7) / 8;
+  a.npatch = NB * a.tiles_y * a.tiles_x;
+  a.L = w->L; a.m = w->m;
+  const int64_t gx = (a.npatch + CG_WAVES - 1) / CG_WAVES;
+  SNNQP_REQUIRE(gx < ((int64_t)1 << 31), SNNQP_EUNSUPPORTED, "conv_gated_forward: more than 2^31 workgroups");
+  hipLaunchKernelGGL(conv_gated_kernel, dim3((unsigned)gx, (unsigned)((a.OT + 3) / 4)), dim3(CG_WAVES * 64), 0,
+                     (hipStream_t)stream, a);
+  SNNQP_CHECK_LAUNCH("conv_gated_kernel");
+  return SNNQP_OK;
+}

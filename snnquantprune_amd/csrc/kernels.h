@@ -64,6 +64,9 @@ int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, int32_t *x_flags, hipStream_t st);
 
+// 3x3 convolution on gate x raster (conv_gated.hip); nullptr when it can serve the request
+const char *conv_gated_unsupported(const snnqp_conv_geom_t *g, const snnqp_weight_t *w);
+
 // codes of magnitude <= 7 on the f8f6f4 MFMA (dense_fp6.hip); row_tiles 0 = choose
 // (ws / ws_bytes: optional workspace for a K split over workgroups, dense_fp6_workspace_bytes)
 int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t B, int32_t K,

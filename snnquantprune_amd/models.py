@@ -83,7 +83,7 @@ def _sow_density(mod, name, x, lead_dims=2):
 
 
 def _as_input(inputs):
-  if isinstance(inputs, (ops.PackedSpikes, ops.PackedFrames)):
+  if isinstance(inputs, (ops.PackedSpikes, ops.PackedFrames, ops.GatedSpikes)):
     return inputs
   x = torch.as_tensor(inputs)
   if x.dtype not in (torch.uint8, torch.float32):
@@ -261,7 +261,7 @@ class CextNet(nn.Module):
 
     probe = _probing(self, cfg)
 
-    def TCJA(x_seq, i=0):                               # models.py:41-99
+    def TCJA(x_seq, i=0, gated=False):                  # models.py:41-99
       T, C = x_seq.shape[0], x_seq.shape[-1]
       m = ops.spatial_mean(x_seq)                       # [T, B, C]
       x = m.transpose(0, 1).contiguous()                # [B, T, C]
@@ -282,7 +282,12 @@ class CextNet(nn.Module):
       # The gate is a sigmoid (>= 0) and constant over H, W, the raster is 0/1, so
       # max(g * s_i) == g * max(s_i) exactly: pool the spikes first (an OR of bits) and
       # gate the pooled raster -- a quarter of the float32 traffic, same numbers.
-      return ops.apply_gate(ops.maxpool2x2(x_seq), gate)   # [T, B, H/2, W/2, C] float32
+      pooled = ops.maxpool2x2(x_seq)
+      if gated and isinstance(pooled, ops.PackedSpikes):
+        # the next block is a quantised 3x3 conv: it contracts gate x raster without the product
+        # being written (SpikingBlock._gated_block; config.gated_int = False multiplies it out)
+        return ops.GatedSpikes(pooled, gate)
+      return ops.apply_gate(pooled, gate)   # [T, B, H/2, W/2, C] float32
 
     def conv_block(x, first, pool, packed=None):
       layer = SpikingBlock(
@@ -323,7 +328,8 @@ class CextNet(nn.Module):
       self.sow("intermediates", "conv_t_%d" % i, x)
       if probe:
         _sow_density(self, "conv_t_%d_out" % i, x)
-      x = TCJA(x, i)                                    # gated and pooled
+      # gated and pooled; the first gate feeds a conv block, which may take it unmultiplied
+      x = TCJA(x, i, gated=(i == 0 and bool(cfg.get("gated_int", True))))
       real_valued = True
     x = flatten_channel_major(x)                        # models.py:189-190
     if probe:

@@ -122,6 +122,33 @@ class PackedFrames:
         "EV1" if self.fmt == L.EV1 else "EV4", self.shape, self.device)
 
 
+class GatedSpikes:
+  """gate[T, B, C] x spikes[T, B, H, W, C], NOT multiplied out: what a TCJA block hands to the next
+  block (x_seq * out[:, :, None, None, :], examples/tcja/models.py:97).  A quantised 3x3 conv block
+  contracts it in the 'gint' form (conv_gated_forward: the nine taps of a channel as an integer sum,
+  the gates in one float32 chain); every other consumer multiplies it out (to_dense)."""
+
+  def __init__(self, spikes: "PackedSpikes", gate: torch.Tensor):
+    assert isinstance(spikes, PackedSpikes) and spikes.ndim == 5, "spikes [T, B, H, W, C], bit-packed"
+    assert gate.dtype == torch.float32 and tuple(gate.shape) == (spikes.shape[0], spikes.shape[1], spikes.channels)
+    self.spikes, self.gate = spikes, gate.contiguous()
+
+  @property
+  def shape(self):
+    return self.spikes.shape
+
+  @property
+  def ndim(self):
+    return 5
+
+  @property
+  def device(self):
+    return self.spikes.device
+
+  def to_dense(self) -> torch.Tensor:
+    return apply_gate(self.spikes, self.gate)
+
+
 def frame_units(H: int, W: int, fmt: int) -> int:
   """Words (EV1) / bytes (EV4) of one packed frame."""
   return (H * W * 2 + 31) // 32 if fmt == L.EV1 else H * W
@@ -588,6 +615,33 @@ def conv_forward(x, geom: ConvGeom, weight: Weight, want_acc: bool = False):
   return (y, acc) if want_acc else y
 
 
+def pack_codes_gated(codes: torch.Tensor) -> torch.Tensor:
+  """int8 HWIO codes [3, 3, Cin, Cout] of magnitude <= 7 -> the fp6 operand layout of
+  conv_gated_forward (snnqp_pack_codes_gated)."""
+  _require_gpu(codes)
+  assert codes.dtype == torch.int8 and codes.ndim == 4 and tuple(codes.shape[:2]) == (3, 3)
+  codes = codes.contiguous()
+  cin, cout = codes.shape[2], codes.shape[3]
+  out = torch.empty(int(L.lib().snnqp_conv_gated_packed_bytes(cin, cout)), dtype=torch.uint8, device=codes.device)
+  L.check(L.lib().snnqp_pack_codes_gated(_ptr(codes), cin, cout, _ptr(out), _stream()))
+  return out
+
+
+def conv_gated_forward(x: GatedSpikes, geom: ConvGeom, weight: Weight, packed: torch.Tensor) -> torch.Tensor:
+  """gate x raster [T, B, H, W, Cin] -> float32 currents [T, B, H, W, Cout] in the 'gint' form
+  (snnqp_conv_gated_forward); raises SnnqpError(EUNSUPPORTED) for shapes it does not serve."""
+  bits, gate = x.spikes.bits.contiguous(), x.gate
+  _require_gpu(bits, gate, weight.w, packed)
+  T, B, H, W, _ = x.shape
+  assert (H, W, x.spikes.channels) == (geom.H, geom.W, geom.Cin), (x.shape, geom)
+  y = torch.empty((T, B, H, W, geom.Cout), dtype=torch.float32, device=bits.device)
+  g, w = geom.struct(), weight.struct()
+  with _timed("conv[gated %s]" % geom.tag()):
+    L.check(L.lib().snnqp_conv_gated_forward(_ptr(bits), _ptr(gate), T * B, ctypes.byref(g), ctypes.byref(w),
+                                             _ptr(packed), _ptr(y), _stream()))
+  return y
+
+
 # ---------------------------------------------------------------------------
 # per-launch timing with HIP events on the launch stream (bench.py roofline)
 # ---------------------------------------------------------------------------
@@ -1047,6 +1101,8 @@ def density(x, lead_dims: int = 2, counts: bool = False) -> torch.Tensor:
   (or the exact int32 non-zero counts with counts=True)."""
   if isinstance(x, PackedFrames):
     x = unpack_frames(x)
+  if isinstance(x, GatedSpikes):
+    x = x.to_dense()
   if isinstance(x, PackedSpikes):
     t, typ, C, shape = x.bits, L.BITS, x.channels, x.shape
   elif x.dtype == torch.uint8:

@@ -94,6 +94,16 @@ class PackedKernel:
                            code_max=int(stats[1]), col_sum=col)
     return self._int
 
+  def gated_codes(self):
+    """The codes in the operand layout of ops.conv_gated_forward (3x3 kernels whose codes fit fp6),
+    or None."""
+    w = self.int_weight()
+    if w is None or self.kernel.ndim != 4 or tuple(self.kernel.shape[:2]) != (3, 3) or not (0 < w.code_max <= 7):
+      return None
+    if "_gated" not in self._wt:
+      self._wt["_gated"] = ops.pack_codes_gated(w.w)
+    return self._wt["_gated"]
+
   def float_weight(self) -> ops.Weight:
     """float32 kernel_fwd of flax_qdense.py:74-85 (fake-quant, then * mask)."""
     if self._float is None:
@@ -175,6 +185,8 @@ def prepare_input(x, prefer_bits: Optional[bool] = None):
   below 2^24) and speculate like it; nothing is read back."""
   if isinstance(x, (ops.PackedSpikes, ops.PackedFrames)):
     return x, True
+  if isinstance(x, ops.GatedSpikes):
+    return x, False            # real-valued: the block takes the gated form or multiplies it out
   if not isinstance(x, torch.Tensor):
     x = torch.as_tensor(x)
   if x.dtype in (torch.uint8, torch.bool):

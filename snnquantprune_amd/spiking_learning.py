@@ -303,6 +303,11 @@ class SpikingBlock(nn.Module):
   # -- one launch ---------------------------------------------------------------
   def _fused(self, u, inputs):
     conn, norm = self.connection_fn, self.norm_fn
+    if isinstance(inputs, ops.GatedSpikes):
+      out = self._gated_block(u, inputs)
+      if out is not None:
+        return out
+      inputs = inputs.to_dense()            # not a shape the gated form serves: float32 product
     flat = getattr(inputs, "flat_perm", None)
     x, integer = packing.prepare_input(inputs)
     spec = integer is packing.SPECULATE      # float32 that may hold integers: decided on the device
@@ -468,6 +473,56 @@ class SpikingBlock(nn.Module):
       if u_out is not None:
         u_out = u_out.squeeze(1)
     return u_out, s
+
+  # -- gate x raster into a quantised 3x3 conv block: the 'gint' connection + neuron scan ----
+  def _gated_block(self, u, x):
+    """examples/tcja/models.py:95-97 -> :149-187 without multiplying the gate out: the nine taps of
+    a channel are summed as integers, the gates applied in one float32 chain
+    (ops.conv_gated_forward; oracle gated_conv); BatchNorm and the neuron follow as the scan.
+    None when the block is not a shape that kernel serves."""
+    conn, norm = self.connection_fn, self.norm_fn
+    if (not isinstance(conn, QuantConv) or len(conn._ksize()) != 2 or self.batch_major_input
+        or self.impl == L.IMPL_GENERIC):
+      return None
+    cin = x.shape[-1]
+    geom = conn.geometry(tuple(x.shape[2:-1]), cin)
+    pk = conn.packed_kernel(cin)
+    w = pk.int_weight()
+    if w is None or not (geom.KH == geom.KW == 3 and tuple(geom.stride) == (1, 1)
+                         and tuple(map(tuple, geom.pad)) == ((1, 1), (1, 1)) and tuple(geom.in_dil) == (1, 1)
+                         and tuple(geom.k_dil) == (1, 1) and geom.groups == 1 and cin in (32, 64, 96, 128)):
+      return None
+    packed = pk.gated_codes()
+    if packed is None:
+      return None
+    T, B = x.shape[0], x.shape[1]
+    N = geom.Cout
+    nrn = self.neural_dynamics.neuron(N)
+    bn = norm.coeffs(N) if norm is not None else None
+    u0 = None if (u is None or isinstance(u, ZeroCarry)) else u
+    packed_out = True if self.packed is None else bool(self.packed)
+    per_sample = 4 * T * geom.H * geom.W * N              # bytes of float32 currents
+    step = max(1, min(B, (1 << 30) // max(per_sample, 1)))
+    us, ss = [], []
+    for b0 in range(0, B, step):
+      b1 = min(B, b0 + step)
+      xs = x if (b0 == 0 and b1 == B) else ops.GatedSpikes(
+          ops.PackedSpikes(x.spikes.bits[:, b0:b1].contiguous(), x.spikes.channels), x.gate[:, b0:b1].contiguous())
+      y = ops.conv_gated_forward(xs, geom, w, packed)
+      u_out, s = ops.lif_forward(y, nrn, bn=bn, u0=None if u0 is None else u0[b0:b1],
+                                 want_u=self.return_state, packed_out=packed_out)
+      del y
+      if self.pool == 2:
+        s = ops.maxpool2x2(s)
+      us.append(u_out)
+      ss.append(s)
+    if len(ss) == 1:
+      return us[0], ss[0]
+    if isinstance(ss[0], ops.PackedSpikes):
+      s = ops.PackedSpikes(torch.cat([p.bits for p in ss], 1), ss[0].channels)
+    else:
+      s = torch.cat(ss, 1)
+    return (None if us[0] is None else torch.cat(us, 0)), s
 
   # -- float32 kernel: f32-MFMA connection + neuron scan, batch slice by batch slice ----
   def _float_block(self, x, tm, is_dense, geom, w, nrn, bn, u0, packed_out):

@@ -264,3 +264,31 @@ def test_int_contract_against_reference_literal_float_at_baseline_size(oracle):
       assert 0.01 < lay["firing_rate"] < 0.5, (name, lay["firing_rate"])
       assert lay["u_p999_rel"] <= 1e-5, (name, lay)
   assert c3["argmax_equal"] == "1/1" and c2["argmax_equal"] == "64/64"
+
+
+def test_gint_contraction_against_the_float_modes(oracle):
+  """The `gint` contraction of the conv block behind a TCJA gate (gated_conv: integer sums per
+  channel, one fmaf chain over the gates) against the two float32 restatements of the same layer on
+  the multiplied-out input -- `fseq` (the fmaf chain over (kh, kw, cin)) and the reference-literal
+  `float` mode (BLAS order): the same real numbers, so rasters agree and potentials differ by
+  float32 rounding only.  CextNet's conv_t_1 at its own geometry (8 x 8 x 128 -> 128, T = 20)."""
+  from snnquantprune_amd import synthetic as syn
+  from tests.helpers import bn_of, qweight_of
+  v = syn.cextnet_variables()
+  qw = qweight_of(oracle, v["params"]["QuantConv_6"], 4)
+  bn = bn_of(v, 4)
+  rng = np.random.Generator(np.random.PCG64(77))
+  T, B = 20, 6
+  s = (rng.random((T, B, 8, 8, 128)) < 0.15).astype(np.float32)
+  gate = (1.0 / (1.0 + np.exp(-rng.standard_normal((T, B, 128))))).astype(np.float32)
+  ug, sg = oracle.gated_conv_block(s, gate, qw, bn)
+  x = s * gate[:, :, None, None, :]
+  assert 0.01 < sg.mean() < 0.6
+  for mode in ("fseq", "float"):
+    uf, sf = oracle.conv_block(x, qw, bn, None, mode)
+    flips = int((sg != sf).sum())
+    same = np.all(sg == sf, axis=0)
+    d = np.abs(ug[same].astype(np.float64) - uf[same].astype(np.float64))
+    scale = np.maximum(np.maximum(np.abs(ug[same]), np.abs(uf[same])), 1.0)
+    assert flips <= max(1, sg.size // 100000), (mode, flips, sg.size)
+    assert (d / scale).max() <= 1e-5, (mode, (d / scale).max())

@@ -3292,3 +3292,53 @@ def test_float32_activations_through_the_narrowing_passes(dev, oracle):
     np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg=mode)
     np.testing.assert_array_equal(_np(u), eu, err_msg=mode)
   assert ops.device_status() == 0
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 8, 8, 128, 128), (2, 3, 5, 11, 64, 70), (1, 2, 16, 16, 96, 160),
+                                   (2, 1, 4, 8, 32, 32)],
+                         ids=["cextnet_conv_t_1", "ragged_image_and_outputs", "96_in_160_out", "one_patch"])
+def test_gated_conv_in_the_gint_form(dev, oracle, shape):
+  """QuantConv 3x3 on gate x raster -- the conv block behind a TCJA gate
+  (examples/tcja/models.py:95-97 -> :149-187) -- without multiplying the gate out: the nine taps of
+  a channel summed as integers on the matrix pipe, the gates applied by one fmaf chain
+  (snnqp_conv_gated_forward) against the oracle's `gint` contraction (gated_conv): currents
+  bit-exact, on images that clip patches and output counts that are not multiples of 32; then the
+  whole block (BatchNorm + LIF scan + 2x2 pool) through SpikingBlock against gated_conv_block."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import ops, packing, synthetic as syn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  from snnquantprune_amd.quant import QuantDesc
+  from snnquantprune_amd.spiking_learning import SpikingBlock
+  T, B, H, W, C, N = shape
+  leaf = syn.quant_leaf((3, 3, C, N), 5.0, 971, True, 0.9)
+  bp, bs = syn.bn_leaf(N, True, 972)
+  bn = dict(mean=bs["mean"], var=bs["var"], scale=bp["scale"], bias=bp["bias"])
+  qw = qweight_of(oracle, leaf, 4)
+  rng = np.random.Generator(np.random.PCG64(H * W + C))
+  s = (rng.random((T, B, H, W, C)) < 0.2).astype(np.uint8)
+  gate = (1.0 / (1.0 + np.exp(-rng.standard_normal((T, B, C)) * 1.5))).astype(F32)
+  a, c = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
+  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, 4, a, c, 7.0, c), _t(leaf["prune_0"]["mask"], dev))
+  w = pk.int_weight()
+  geom = ops.ConvGeom(H, W, C, N, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  x = ops.GatedSpikes(ops.pack_bits(_t(s, dev)), _t(gate, dev))
+  y = ops.conv_gated_forward(x, geom, w, pk.gated_codes())
+  ey = np.stack([oracle.gated_conv(s[t].astype(F32), gate[t], qw) for t in range(T)])
+  np.testing.assert_array_equal(_np(y), ey)
+  assert 0.3 < np.abs(ey).max() < 50.0
+  # the block, as the model calls it
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  for pool in (1, 2) if H % 2 == 0 and W % 2 == 0 else (1,):
+    blk = SpikingBlock(connection_fn=QuantConv(features=N, kernel_size=(3, 3), padding=((1, 1), (1, 1)),
+                                               use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale),
+                       neural_dynamics=cfg.neuron_dynamics(dtype=torch.float32),
+                       norm_fn=nn.BatchNorm(use_running_average=True, momentum=0.9, epsilon=1e-5),
+                       pool=pool, return_state=True)
+    variables = nn.tree_from_numpy({"params": {"connection_fn": leaf, "norm_fn": {"scale": bn["scale"], "bias": bn["bias"]}},
+                                    "batch_stats": {"norm_fn": {"mean": bn["mean"], "var": bn["var"]}}}, dev)
+    u, sp = blk.apply(variables, None, x)
+    eu, es = oracle.gated_conv_block(s.astype(F32), gate, qw, bn)
+    np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es) if pool == 2 else es))
+    np.testing.assert_array_equal(_np(u), eu)
+  assert ops.device_status() == 0
