@@ -39,6 +39,7 @@ struct ConvGatedArgs {
   float *y;               // [NB][H][W][Cout]
   int64_t NB, npatch;
   int32_t H, W, C, CW, Cout, OT, tiles_y, tiles_x;
+  int32_t ot_base;        // first output tile of this launch
   float L, m;
 };
 
@@ -76,6 +77,11 @@ pack_codes_gated_kernel(const int8_t *w, int32_t C, int32_t Cout, int32_t OT, ui
   }
 }
 
+// NT: output tiles (of 32) this launch's workgroups hold -- a template parameter, so that the four
+// matrix instructions of a channel and their 64 fmaf are one basic block the scheduler can
+// overlap (with a run-time count every instruction sat in a block of its own, waited for alone:
+// 1.48 ms for CextNet's layer, against ... with this)
+template <int NT>
 __global__ void __launch_bounds__(CG_WAVES * 64, 2)
 conv_gated_kernel(ConvGatedArgs a) {
   __shared__ uint32_t At[CG_WAVES][CG_CMAX][32];
@@ -121,8 +127,8 @@ conv_gated_kernel(ConvGatedArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // ---- 2. the chain over the channels -------------------------------------------------------
-  const int ot0 = blockIdx.y * 4;
-  const int nt = min(4, a.OT - ot0);
+  const int ot0 = a.ot_base + blockIdx.y * 4;
+  constexpr int nt = NT;
   v16f acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -239,10 +245,21 @@ extern "C" int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, in
   a.tiles_y = (g->H + 3) / 4; a.tiles_x = (g->W + 7) / 8;
   a.npatch = NB * a.tiles_y * a.tiles_x;
   a.L = w->L; a.m = w->m;
+  a.ot_base = 0;
   const int64_t gx = (a.npatch + CG_WAVES - 1) / CG_WAVES;
   SNNQP_REQUIRE(gx < ((int64_t)1 << 31), SNNQP_EUNSUPPORTED, "conv_gated_forward: more than 2^31 workgroups");
-  hipLaunchKernelGGL(conv_gated_kernel, dim3((unsigned)gx, (unsigned)((a.OT + 3) / 4)), dim3(CG_WAVES * 64), 0,
-                     (hipStream_t)stream, a);
+  // full groups of four output tiles, then the remainder (its blockIdx.y = 0 is tile group OT / 4)
+  const int full = a.OT / 4, rest = a.OT % 4;
+  if (full > 0)
+    hipLaunchKernelGGL(conv_gated_kernel<4>, dim3((unsigned)gx, (unsigned)full), dim3(CG_WAVES * 64), 0,
+                       (hipStream_t)stream, a);
+  if (rest > 0) {
+    ConvGatedArgs b = a;
+    b.ot_base = full * 4;
+    if (rest == 1) hipLaunchKernelGGL(conv_gated_kernel<1>, dim3((unsigned)gx, 1u), dim3(CG_WAVES * 64), 0, (hipStream_t)stream, b);
+    else if (rest == 2) hipLaunchKernelGGL(conv_gated_kernel<2>, dim3((unsigned)gx, 1u), dim3(CG_WAVES * 64), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(conv_gated_kernel<3>, dim3((unsigned)gx, 1u), dim3(CG_WAVES * 64), 0, (hipStream_t)stream, b);
+  }
   SNNQP_CHECK_LAUNCH("conv_gated_kernel");
   return SNNQP_OK;
 }

@@ -236,13 +236,24 @@ spatial_mean_kernel(const void *__restrict__ x, int64_t NB, int32_t HW, int32_t 
     const int64_t img = i / C;
     const int32_t c = (int32_t)(i - img * C);
     float acc = 0.0f;
-    for (int32_t p = 0; p < HW; ++p) {
-      float v;
-      if (BITS)
-        v = (float)((((const uint32_t *)x)[(img * HW + p) * CW + (c >> 5)] >> (c & 31)) & 1u);
-      else
-        v = ((const float *)x)[(img * HW + p) * C + c];
-      acc = acc + v;
+    if (BITS) {
+      // the sequential float32 sum of 0 / 1 values is their exact count (HW < 2^24): counted as an
+      // integer, eight independent loads in flight (the dependent float chain took 0.29 ms for a
+      // 16 x 16 x 128 raster at B = 1024, T = 20)
+      const uint32_t *xw = (const uint32_t *)x + img * HW * CW + (c >> 5);
+      uint32_t cnt = 0;
+      int32_t p = 0;
+      for (; p + 8 <= HW; p += 8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = xw[(int64_t)(p + j) * CW];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += (w[j] >> (c & 31)) & 1u;
+      }
+      for (; p < HW; ++p) cnt += (xw[(int64_t)p * CW] >> (c & 31)) & 1u;
+      acc = (float)cnt;
+    } else {
+      for (int32_t p = 0; p < HW; ++p) acc = acc + ((const float *)x)[(img * HW + p) * C + c];
     }
     y[i] = acc / (float)HW;
   }
