@@ -472,10 +472,11 @@ class CapturedApply:
   every call (copy what must survive the next call), and new weights need a new capture.
   Kernels that adapt to the data outside the graph (the event layer's count hint,
   ops.CountHint) run with the hint as it was at capture time -- still exact, see snnqp.h.
-  A step that needs a value on the host cannot be captured and raises ops.NotCapturable before
-  anything illegal is recorded: float32 input frames (inspected and narrowed per batch) and
-  models with real-valued activations between blocks (CextNet's TCJA gates); the process stays
-  usable, call such a model eagerly.
+  No step of this package needs a value on the host any more (float32 inputs are checked on the
+  device, snnqp.h x_flags): every model captures, float32 frames included.  Launches that hand
+  partial results over between workgroups get a workspace allocated INSIDE the capture (the
+  graph's private pool: ops._dense_workspace), so the addresses baked into the graph live and
+  die with it.
   """
 
   def __init__(self, module, variables, example, **kwargs):
