@@ -89,8 +89,7 @@ class QuantConv(nn.Module):
 
   @nn.compact_method
   def packed_kernel(self, in_features: int) -> packing.PackedKernel:
-    if self.dtype not in (torch.float32, None, "float32"):
-      raise NotImplementedError("QuantConv computes in float32 (got %r)" % (self.dtype,))
+    nn.check_compute_dtype(self.dtype, "QuantConv")
     assert in_features % self.feature_group_count == 0     # flax_qconv.py:117
     kshape = self._ksize() + (in_features // self.feature_group_count, self.features)
     kernel = self.param("kernel", self.kernel_init, kshape)

@@ -71,8 +71,7 @@ class QuantDense(nn.Module):
   g_scale: float = 0.
 
   def _check_dtype(self):
-    if self.dtype not in (torch.float32, None, "float32"):
-      raise NotImplementedError("QuantDense computes in float32 (got %r)" % (self.dtype,))
+    nn.check_compute_dtype(self.dtype, "QuantDense")
 
   @nn.compact_method
   def packed_kernel(self, in_features: int) -> packing.PackedKernel:

@@ -103,6 +103,46 @@ FrozenConfigDict = ConfigDict
 
 
 # ---------------------------------------------------------------------------
+# compute dtype policy
+# ---------------------------------------------------------------------------
+
+# The kernels compute in exact integers and float32: the modules' default dtype
+# (flax_qdense.py:49, flax_qconv.py:78) and the parity target.  The reference's shipped configs
+# ask for bfloat16 (examples/tcja/configs/prune_quant_joint.py:71), which the layers refuse by
+# default -- running a bfloat16 request in float32 silently would be a different computation than
+# the one asked for.  A caller who wants those configs to load unedited says so:
+#   nn.set_compute_dtype_policy("float32")   # any requested layer dtype is computed in float32
+_DTYPE_POLICY = "strict"
+_dtype_warned = False
+
+
+def set_compute_dtype_policy(policy: str):
+  """"strict" (default): layers refuse a dtype other than float32.  "float32": layers accept any
+  requested dtype and compute in float32 (more precise than the bfloat16 the reference would run;
+  said once on stderr)."""
+  global _DTYPE_POLICY
+  if policy not in ("strict", "float32"):
+    raise ValueError("compute dtype policy must be 'strict' or 'float32'")
+  _DTYPE_POLICY = policy
+
+
+def check_compute_dtype(dtype, who: str):
+  global _dtype_warned
+  if dtype in (torch.float32, None, "float32"):
+    return
+  if _DTYPE_POLICY == "float32":
+    if not _dtype_warned:
+      import sys
+      print("snnquantprune_amd: %s asked for %r; computing in float32 (nn.set_compute_dtype_policy)"
+            % (who, dtype), file=sys.stderr)
+      _dtype_warned = True
+    return
+  raise NotImplementedError(
+      "%s computes in float32 (got %r); nn.set_compute_dtype_policy('float32') runs such a "
+      "request in float32 instead of refusing it" % (who, dtype))
+
+
+# ---------------------------------------------------------------------------
 # initialisers (host side; never on the hot path)
 # ---------------------------------------------------------------------------
 

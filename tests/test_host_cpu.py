@@ -710,3 +710,19 @@ def test_conv_dequant_form_query():
   wf = ops.Weight(L.W_F32, torch.zeros((3, 3, 4, 32)), 1.0, 1.0)
   with pytest.raises(L.SnnqpError):
     ops.conv_dequant_form(wf, mslif)
+
+
+def test_compute_dtype_policy():
+  """The reference's shipped configs ask for bfloat16 (examples/tcja/configs/prune_quant_joint.py:71);
+  the layers refuse that by default and compute it in float32 when the caller opts in."""
+  from snnquantprune_amd import linen as nn
+  nn.check_compute_dtype(torch.float32, "QuantDense")
+  with pytest.raises(NotImplementedError, match="float32"):
+    nn.check_compute_dtype(torch.bfloat16, "QuantDense")
+  nn.set_compute_dtype_policy("float32")
+  try:
+    nn.check_compute_dtype(torch.bfloat16, "QuantDense")      # accepted, computed in float32
+  finally:
+    nn.set_compute_dtype_policy("strict")
+  with pytest.raises(ValueError):
+    nn.set_compute_dtype_policy("bf16")
