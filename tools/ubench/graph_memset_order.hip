@@ -36,11 +36,17 @@ __global__ void zero_words(unsigned *buf, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) buf[i] = 0u;
 }
 
-struct G { hipGraph_t g; hipGraphExec_t e; unsigned *buf; };
+struct G { hipGraph_t g; hipGraphExec_t e; unsigned *buf; unsigned *base; };
+
+// interior: the target is an INTERIOR pointer of a larger allocation (as a framework's pool block
+// or the library's slot pool is), at the offset the failing test had (0xa00)
+static bool g_interior = false;
 
 static G capture(hipStream_t st, unsigned *bad, bool memset_node, int spin) {
   G r;
-  CK(hipMalloc((void **)&r.buf, 4096));
+  CK(hipMalloc((void **)&r.base, 1 << 21));
+  CK(hipMemset(r.base, 0x5a, 1 << 21));
+  r.buf = g_interior ? r.base + 0xa00 / 4 : r.base;
   CK(hipMemset(r.buf, 0, 4096));
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
   if (memset_node) CK(hipMemsetAsync(r.buf, 0, NW * sizeof(unsigned), st));
@@ -60,8 +66,9 @@ int main(int argc, char **argv) {
   CK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
   unsigned *bad;
   CK(hipMalloc((void **)&bad, 4));
-  for (int kind = 0; kind < 2; ++kind) {
-    const bool memset_node = kind == 0;
+  for (int kind = 0; kind < 4; ++kind) {
+    const bool memset_node = (kind & 1) == 0;
+    g_interior = kind >= 2;
     G a = capture(cap, bad, memset_node, spin), b = capture(cap, bad, memset_node, spin);
     for (int mode = 0; mode < 4; ++mode) {
       CK(hipMemset(bad, 0, 4));
@@ -81,11 +88,11 @@ int main(int argc, char **argv) {
       CK(hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost));
       static const char *names[4] = {"one graph, one stream", "two graphs alternating on one stream",
                                      "two graphs on two streams, no host sync", "two graphs on two streams, host sync per pair"};
-      std::printf("%-12s %-50s %d replays each: %u draws of a non-zero-start value\n",
-                  memset_node ? "memset node" : "kernel node", names[mode], iters, nbad);
+      std::printf("%-12s %-9s %-50s %d replays each: %u draws of a non-zero-start value\n",
+                  memset_node ? "memset node" : "kernel node", g_interior ? "interior" : "base", names[mode], iters, nbad);
     }
-    CK(hipGraphExecDestroy(a.e)); CK(hipGraphDestroy(a.g)); CK(hipFree(a.buf));
-    CK(hipGraphExecDestroy(b.e)); CK(hipGraphDestroy(b.g)); CK(hipFree(b.buf));
+    CK(hipGraphExecDestroy(a.e)); CK(hipGraphDestroy(a.g)); CK(hipFree(a.base));
+    CK(hipGraphExecDestroy(b.e)); CK(hipGraphDestroy(b.g)); CK(hipFree(b.base));
   }
   return 0;
 }
