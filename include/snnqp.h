@@ -168,7 +168,8 @@ typedef struct {
  * snnqp_fallback_counts; 301: snnqp_conv_dequant_form; 400: snnqp_dense_head_forward, snnqp_device_status,
  * snnqp_workqueue_*, snnqp_dense_lif_forward_ws; 500: float32 inputs into integer blocks --
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
- * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward).  A binding compares snnqp_version()
+ * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
+ * snnqp_dense_gated_forward).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 500
 int snnqp_version(void);
@@ -275,6 +276,23 @@ int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *pac
 int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
                              const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                              const void *packed, float *y, snnqp_stream_t stream);
+
+/* The same contraction for a QuantDense (flax_qdense.py:87-89) on the channel-major flattening of
+ * gate x raster -- the first dense block behind the second TCJA gate, x[(c HW + p)] = gate[c] *
+ * s[p][c], examples/tcja/models.py:97 -> :189-190 -> :200-216:
+ *     I[c][o] = sum over the HW positions of code[c HW + p][o] * s[p][c]     (exact integer)
+ *     acc[o]  = fmaf(gate[c], I[c][o], acc[o])   for c = 0 .. C - 1, from +0
+ *     y[o]    = fl(fl(acc / L) * m)
+ * s [NB][HW][ceil(C / 32)] spike words, gate [NB][C] float32, y float32 [NB][N]; w: SNNQP_W_I8
+ * codes [C HW][N] with code_max <= 7; packed: snnqp_pack_codes_dense_gated's layout
+ * (snnqp_dense_gated_packed_bytes bytes).  HW <= 16, C in {32, 64, 96, 128}; SNNQP_EUNSUPPORTED
+ * otherwise (the caller multiplies the gate out and takes snnqp_conv_forward). */
+int64_t snnqp_dense_gated_packed_bytes(int32_t C, int32_t N);
+int snnqp_pack_codes_dense_gated(const int8_t *w, int32_t C, int32_t HW, int32_t N, void *packed,
+                                 snnqp_stream_t stream);
+int snnqp_dense_gated_forward(const uint32_t *s, const float *gate, int64_t NB, int32_t HW,
+                              int32_t C, int32_t N, const snnqp_weight_t *w,
+                              const void *packed, float *y, snnqp_stream_t stream);
 
 /* ---- fused SpikingBlock ---------------------------------------------------
  * replaces: SpikingBlock.__call__ (nn.scan over T of connection -> norm ->

@@ -592,6 +592,46 @@ def gated_conv_block(spikes, gate, qw: QWeight, bn: Optional[dict], neuron_cfg=N
   return u, np.stack(out)
 
 
+def gated_dense(s, gate, qw: QWeight):
+  """The 'gint' contraction of a dense layer on the CHANNEL-MAJOR flattening of gate x raster
+  (examples/tcja/models.py:97 -> :189-190 -> :200-216: the first dense block of CextNet sees
+  x[k] = gate[c] * s[c, h, w] with k = (c * H + h) * W + w).
+
+  s [NB, H, W, C] in {0, 1}; gate [NB, C] float32; qw.q [C * H * W, N] -> currents [NB, N]:
+    I[c, o] = sum over (h, w) of code[(c, h, w), o] * s[h, w, c]                  (exact integer)
+    acc[o]  = fmaf(gate[c], I[c, o], acc[o])   for c = 0 .. C - 1                 (start +0)
+    current = fl(fl(acc / L) * m)"""
+  assert qw.quantised
+  s = np.asarray(s)
+  gate = np.ascontiguousarray(gate, dtype=F32)
+  NB, H, W, C = s.shape
+  K, N = qw.q.shape
+  assert K == C * H * W and gate.shape == (NB, C) and _is_integer_valued(s)
+  codes = qw.q.reshape(C, H * W, N).astype(F32)
+  sp = np.transpose(s.reshape(NB, H * W, C), (0, 2, 1)).astype(F32)       # [NB, C, HW]
+  acc = np.zeros((NB, N), F32)
+  for c in range(C):
+    I = np.ascontiguousarray(sp[:, c, :]) @ np.ascontiguousarray(codes[c])   # exact: |I| <= HW * 127
+    clib().oracle_fma_rows(_fp(acc), _fp(np.ascontiguousarray(gate[:, c])), _fp(np.ascontiguousarray(I, dtype=F32)),
+                           NB, N)
+  return ((acc / qw.L) * qw.m).astype(F32)
+
+
+def gated_dense_block(spikes, gate, qw: QWeight, neuron_cfg=None, u0=None):
+  """SpikingBlock(QuantDense, neuron) on the channel-major flattening of gate[T, B, C] x
+  spikes[T, B, H, W, C], 'gint' mode."""
+  neuron = _neuron(neuron_cfg or {})
+  u = None
+  out = []
+  for t in range(spikes.shape[0]):
+    x = gated_dense(spikes[t], gate[t], qw)
+    if u is None:
+      u = np.zeros_like(x) if u0 is None else np.asarray(u0, F32)
+    u, sp = neuron(u, x)
+    out.append(sp)
+  return u, np.stack(out)
+
+
 def heaviside(x):
   """Forward of atan / fast_sigmoid / ... (spiking_learning.py:139-241): x >= 0."""
   return (np.asarray(x, dtype=F32) >= F32(0)).astype(F32)
@@ -883,7 +923,10 @@ def cextnet_forward(inputs, conv_qw: Sequence[QWeight], bns: Sequence[dict],
     mode = "fseq"
   xf = flatten_channel_major(x)
   probe("dense1_inpt", xf)
-  _, s1 = dense_block(xf, dense_qw[0], neuron_cfg, "fseq")
+  if gated == "gint" and dense_qw[0].quantised and pooled_s.shape[2] * pooled_s.shape[3] <= 32:
+    _, s1 = gated_dense_block(pooled_s, gate, dense_qw[0], neuron_cfg)
+  else:
+    _, s1 = dense_block(xf, dense_qw[0], neuron_cfg, "fseq")
   probe("dense1_out", s1)
   probe("dense2_inpt", s1)
   _, s2 = dense_block(s1, dense_qw[1], neuron_cfg, "int")

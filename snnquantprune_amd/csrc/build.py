@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "runtime.hip", "quantize.hip", "spikes.hip", "frames.hip", "elementwise.hip",
            "generic_block.hip", "blocks.hip", "conv3x3_u8c2.hip", "conv3x3_bits.hip",
-           "dense_mfma.hip", "dense_wide.hip", "dense_fp6.hip", "fseq_gemm.hip", "conv_gated.hip"]
+           "dense_mfma.hip", "dense_wide.hip", "dense_fp6.hip", "fseq_gemm.hip", "conv_gated.hip", "dense_gated.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function"]

@@ -66,6 +66,8 @@ int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
 
 // 3x3 convolution on gate x raster (conv_gated.hip); nullptr when it can serve the request
 const char *conv_gated_unsupported(const snnqp_conv_geom_t *g, const snnqp_weight_t *w);
+// dense connection on the channel-major flattening of gate x raster (dense_gated.hip)
+const char *dense_gated_unsupported(int32_t HW, int32_t C, int32_t N, const snnqp_weight_t *w);
 
 // codes of magnitude <= 7 on the f8f6f4 MFMA (dense_fp6.hip); row_tiles 0 = choose
 // (ws / ws_bytes: optional workspace for a K split over workgroups, dense_fp6_workspace_bytes)

@@ -36,6 +36,8 @@ def flatten_channel_major(x):
 
   Packed spikes are not moved: the NHWC words are re-labelled and the consumer
   re-orders its weight rows (an exact re-indexing of an integer sum)."""
+  if isinstance(x, ops.GatedSpikes):
+    return x.flattened()
   if isinstance(x, ops.PackedSpikes):
     T, B, H, W, C = x.shape
     if C % 32:
@@ -284,8 +286,9 @@ class CextNet(nn.Module):
       # gate the pooled raster -- a quarter of the float32 traffic, same numbers.
       pooled = ops.maxpool2x2(x_seq)
       if gated and isinstance(pooled, ops.PackedSpikes):
-        # the next block is a quantised 3x3 conv: it contracts gate x raster without the product
-        # being written (SpikingBlock._gated_block; config.gated_int = False multiplies it out)
+        # the next block is a quantised 3x3 conv (i = 0) or the flatten + dense block (i = 1): it
+        # contracts gate x raster without the product being written (SpikingBlock._gated_block;
+        # config.gated_int = False multiplies it out)
         return ops.GatedSpikes(pooled, gate)
       return ops.apply_gate(pooled, gate)   # [T, B, H/2, W/2, C] float32
 
@@ -328,8 +331,8 @@ class CextNet(nn.Module):
       self.sow("intermediates", "conv_t_%d" % i, x)
       if probe:
         _sow_density(self, "conv_t_%d_out" % i, x)
-      # gated and pooled; the first gate feeds a conv block, which may take it unmultiplied
-      x = TCJA(x, i, gated=(i == 0 and bool(cfg.get("gated_int", True))))
+      # gated and pooled; the blocks behind the gates may take the product unmultiplied
+      x = TCJA(x, i, gated=bool(cfg.get("gated_int", True)))
       real_valued = True
     x = flatten_channel_major(x)                        # models.py:189-190
     if probe:

@@ -128,25 +128,39 @@ class GatedSpikes:
   contracts it in the 'gint' form (conv_gated_forward: the nine taps of a channel as an integer sum,
   the gates in one float32 chain); every other consumer multiplies it out (to_dense)."""
 
-  def __init__(self, spikes: "PackedSpikes", gate: torch.Tensor):
+  def __init__(self, spikes: "PackedSpikes", gate: torch.Tensor, flat: bool = False):
     assert isinstance(spikes, PackedSpikes) and spikes.ndim == 5, "spikes [T, B, H, W, C], bit-packed"
     assert gate.dtype == torch.float32 and tuple(gate.shape) == (spikes.shape[0], spikes.shape[1], spikes.channels)
     self.spikes, self.gate = spikes, gate.contiguous()
+    # flat: stands for the channel-major flattening [T, B, C H W] of the product (the transpose +
+    # reshape of examples/tcja/models.py:189-190) -- nothing is moved, a dense block reads the
+    # raster through its own weight layout (dense_gated_forward)
+    self.flat = bool(flat)
 
   @property
   def shape(self):
+    if self.flat:
+      T, B, H, W, C = self.spikes.shape
+      return (T, B, C * H * W)
     return self.spikes.shape
 
   @property
   def ndim(self):
-    return 5
+    return 3 if self.flat else 5
 
   @property
   def device(self):
     return self.spikes.device
 
+  def flattened(self) -> "GatedSpikes":
+    return GatedSpikes(self.spikes, self.gate, flat=True)
+
   def to_dense(self) -> torch.Tensor:
-    return apply_gate(self.spikes, self.gate)
+    x = apply_gate(self.spikes, self.gate)
+    if self.flat:
+      x = x.permute(0, 1, 4, 2, 3)
+      x = x.reshape(x.shape[0], x.shape[1], -1).contiguous()
+    return x
 
 
 def frame_units(H: int, W: int, fmt: int) -> int:
@@ -639,6 +653,35 @@ def conv_gated_forward(x: GatedSpikes, geom: ConvGeom, weight: Weight, packed: t
   with _timed("conv[gated %s]" % geom.tag()):
     L.check(L.lib().snnqp_conv_gated_forward(_ptr(bits), _ptr(gate), T * B, ctypes.byref(g), ctypes.byref(w),
                                              _ptr(packed), _ptr(y), _stream()))
+  return y
+
+
+def pack_codes_dense_gated(codes: torch.Tensor, C: int, HW: int) -> torch.Tensor:
+  """int8 codes [C * HW, N] (rows channel-major) of magnitude <= 7 -> the fp6 operand layout of
+  dense_gated_forward (snnqp_pack_codes_dense_gated)."""
+  _require_gpu(codes)
+  assert codes.dtype == torch.int8 and codes.ndim == 2 and codes.shape[0] == C * HW
+  codes = codes.contiguous()
+  N = codes.shape[1]
+  out = torch.empty(int(L.lib().snnqp_dense_gated_packed_bytes(C, N)), dtype=torch.uint8, device=codes.device)
+  L.check(L.lib().snnqp_pack_codes_dense_gated(_ptr(codes), C, HW, N, _ptr(out), _stream()))
+  return out
+
+
+def dense_gated_forward(x: GatedSpikes, weight: Weight, packed: torch.Tensor) -> torch.Tensor:
+  """channel-major flattening of gate x raster [T, B, (C, H, W)] -> float32 currents [T, B, N] in
+  the 'gint' form (snnqp_dense_gated_forward); raises SnnqpError(EUNSUPPORTED) for shapes it does
+  not serve."""
+  bits, gate = x.spikes.bits.contiguous(), x.gate
+  _require_gpu(bits, gate, weight.w, packed)
+  T, B, H, W, C = x.spikes.shape
+  N = weight.w.shape[-1]
+  assert weight.w.shape[0] == C * H * W, (tuple(weight.w.shape), x.spikes.shape)
+  y = torch.empty((T, B, N), dtype=torch.float32, device=bits.device)
+  w = weight.struct()
+  with _timed("dense[gated K=%d N=%d]" % (C * H * W, N)):
+    L.check(L.lib().snnqp_dense_gated_forward(_ptr(bits), _ptr(gate), T * B, H * W, C, N, ctypes.byref(w),
+                                              _ptr(packed), _ptr(y), _stream()))
   return y
 
 

@@ -104,6 +104,18 @@ class PackedKernel:
       self._wt["_gated"] = ops.pack_codes_gated(w.w)
     return self._wt["_gated"]
 
+  def gated_dense_codes(self, C: int, HW: int):
+    """The codes of a dense kernel [C * HW, N] in the operand layout of ops.dense_gated_forward
+    (codes that fit fp6, HW <= 16), or None."""
+    w = self.int_weight()
+    if (w is None or self.kernel.ndim != 2 or self.kernel.shape[0] != C * HW or not (0 < w.code_max <= 7)
+        or HW > 16 or C not in (32, 64, 96, 128)):
+      return None
+    key = ("_dgated", C, HW)
+    if key not in self._wt:
+      self._wt[key] = ops.pack_codes_dense_gated(w.w, C, HW)
+    return self._wt[key]
+
   def float_weight(self) -> ops.Weight:
     """float32 kernel_fwd of flax_qdense.py:74-85 (fake-quant, then * mask)."""
     if self._float is None:

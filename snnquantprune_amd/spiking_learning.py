@@ -481,8 +481,11 @@ class SpikingBlock(nn.Module):
     (ops.conv_gated_forward; oracle gated_conv); BatchNorm and the neuron follow as the scan.
     None when the block is not a shape that kernel serves."""
     conn, norm = self.connection_fn, self.norm_fn
-    if (not isinstance(conn, QuantConv) or len(conn._ksize()) != 2 or self.batch_major_input
-        or self.impl == L.IMPL_GENERIC):
+    if self.batch_major_input or self.impl == L.IMPL_GENERIC:
+      return None
+    if x.flat:
+      return self._gated_dense_block(u, x)
+    if not isinstance(conn, QuantConv) or len(conn._ksize()) != 2:
       return None
     cin = x.shape[-1]
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
@@ -523,6 +526,28 @@ class SpikingBlock(nn.Module):
     else:
       s = torch.cat(ss, 1)
     return (None if us[0] is None else torch.cat(us, 0)), s
+
+  def _gated_dense_block(self, u, x):
+    """examples/tcja/models.py:97 -> :189-190 -> :200-216: QuantDense on the channel-major
+    flattening of gate x raster, the positions of a channel summed as integers and the gates
+    applied in one float32 chain (ops.dense_gated_forward; oracle gated_dense).  None when the
+    block is not a shape that kernel serves."""
+    conn, norm = self.connection_fn, self.norm_fn
+    if not isinstance(conn, QuantDense) or self.pool != 1:
+      return None
+    T, B, H, W, C = x.spikes.shape
+    pk = conn.packed_kernel(C * H * W)
+    w = pk.int_weight()
+    packed = pk.gated_dense_codes(C, H * W) if w is not None else None
+    if packed is None:
+      return None
+    N = conn.features
+    nrn = self.neural_dynamics.neuron(N)
+    bn = norm.coeffs(N) if norm is not None else None
+    u0 = None if (u is None or isinstance(u, ZeroCarry)) else u
+    packed_out = True if self.packed is None else bool(self.packed)
+    y = ops.dense_gated_forward(x, w, packed)
+    return ops.lif_forward(y, nrn, bn=bn, u0=u0, want_u=self.return_state, packed_out=packed_out)
 
   # -- float32 kernel: f32-MFMA connection + neuron scan, batch slice by batch slice ----
   def _float_block(self, x, tm, is_dense, geom, w, nrn, bn, u0, packed_out):
@@ -574,6 +599,8 @@ class SpikingBlock(nn.Module):
     conn, norm, nrn_mod = self.connection_fn, self.norm_fn, self.neural_dynamics
     if isinstance(inputs, ops.PackedFrames):
       inputs = inputs.to_u8()
+    if isinstance(inputs, ops.GatedSpikes):
+      inputs = inputs.to_dense()
     if self.batch_major_input:
       inputs = inputs.transpose(0, 1)
     T = inputs.shape[0]

@@ -3342,3 +3342,56 @@ def test_gated_conv_in_the_gint_form(dev, oracle, shape):
     np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es) if pool == 2 else es))
     np.testing.assert_array_equal(_np(u), eu)
   assert ops.device_status() == 0
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 4, 4, 128, 512), (2, 33, 2, 3, 64, 70), (1, 2, 1, 1, 32, 32),
+                                   (2, 3, 4, 4, 96, 600)],
+                         ids=["cextnet_dense1", "ragged_rows_and_outputs", "one_position", "two_output_groups"])
+def test_gated_dense_in_the_gint_form(dev, oracle, shape):
+  """QuantDense on the channel-major flattening of gate x raster -- the dense block behind the second
+  TCJA gate (examples/tcja/models.py:97 -> :189-190 -> :200-216) -- without multiplying the gate
+  out: the positions of a channel summed as integers on the matrix pipe, the gates applied by one
+  fmaf chain (snnqp_dense_gated_forward) against the oracle's `gint` contraction (gated_dense):
+  currents bit-exact, on row counts that are not multiples of 32 and output counts that are not
+  multiples of 32 or run past one workgroup's 512; then the block through SpikingBlock against
+  gated_dense_block, and the same block with the gate multiplied out against the fseq contract."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import ops, packing, synthetic as syn
+  from snnquantprune_amd.flax_qdense import QuantDense
+  from snnquantprune_amd.quant import QuantDesc
+  from snnquantprune_amd.spiking_learning import SpikingBlock
+  T, B, H, W, C, N = shape
+  K = C * H * W
+  leaf = syn.quant_leaf((K, N), 5.0, 981, True, 0.9)
+  qw = qweight_of(oracle, leaf, 4)
+  rng = np.random.Generator(np.random.PCG64(H * W + C + N))
+  s = (rng.random((T, B, H, W, C)) < 0.3).astype(np.uint8)
+  gate = (1.0 / (1.0 + np.exp(-rng.standard_normal((T, B, C)) * 1.5))).astype(F32)
+  a, c = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
+  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, 4, a, c, 7.0, c), _t(leaf["prune_0"]["mask"], dev))
+  w = pk.int_weight()
+  x = ops.GatedSpikes(ops.pack_bits(_t(s, dev)), _t(gate, dev)).flattened()
+  assert tuple(x.shape) == (T, B, K)
+  y = ops.dense_gated_forward(x, w, pk.gated_dense_codes(C, H * W))
+  ey = np.stack([oracle.gated_dense(s[t].astype(F32), gate[t], qw) for t in range(T)])
+  np.testing.assert_array_equal(_np(y), ey)
+  assert 0.3 < np.abs(ey).max() < 200.0
+  # what the flattened product is, for every other consumer
+  dense = (gate[:, :, None, None, :] * s).astype(F32).transpose(0, 1, 4, 2, 3).reshape(T, B, K)
+  np.testing.assert_array_equal(_np(x.to_dense()), dense)
+  # the block, as the model calls it
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  blk = SpikingBlock(connection_fn=QuantDense(N, use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale),
+                     neural_dynamics=cfg.neuron_dynamics(dtype=torch.float32), return_state=True)
+  variables = nn.tree_from_numpy({"params": {"connection_fn": leaf}}, dev)
+  u, sp = blk.apply(variables, None, x)
+  eu, es = oracle.gated_dense_block(s.astype(F32), gate, qw)
+  np.testing.assert_array_equal(_np(sp), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(u), eu)
+  with packing.integer_inputs(False):
+    u2, sp2 = blk.apply(variables, None, _t(dense, dev))
+  eu2, es2 = oracle.dense_block(dense, qw, None, "fseq")
+  np.testing.assert_array_equal(_np(sp2), es2)
+  np.testing.assert_array_equal(_np(u2), eu2)
+  assert ops.device_status() == 0
