@@ -169,7 +169,7 @@ typedef struct {
  * snnqp_workqueue_*, snnqp_dense_lif_forward_ws; 500: float32 inputs into integer blocks --
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
- * snnqp_dense_gated_forward).  A binding compares snnqp_version()
+ * snnqp_dense_gated_forward, snnqp_quantize_ex).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 500
 int snnqp_version(void);
@@ -193,6 +193,15 @@ int snnqp_conv_out_shape(const snnqp_conv_geom_t *g, int32_t *OH, int32_t *OW);
 int snnqp_quantize(int kind, const float *w, const float *mask, int64_t n,
                    int bits, float p0, float p1, float *fq_out,
                    int8_t *codes_out, int32_t *flags, snnqp_stream_t stream);
+/* The same with the reference's `sign` argument (Quantizer.__call__(x, sign), quant.py:331,
+ * :374, :439, :512): sign = 0 quantises to the unsigned levels 0 .. 2^bits - 1 (num_levels /
+ * q_pos = 2^bits - 1, lower clip bound 0; DuQ keeps hard_tanh and only changes n_lv,
+ * quant.py:458-467).  snnqp_quantize is sign = 1, what QuantDense / QuantConv pass
+ * (flax_qdense.py:76).  int8 codes exist for unsigned widths up to 7 bits only
+ * (SNNQP_FLAG_CODE_OVERFLOW beyond). */
+int snnqp_quantize_ex(int kind, const float *w, const float *mask, int64_t n,
+                      int bits, int sign, float p0, float p1, float *fq_out,
+                      int8_t *codes_out, int32_t *flags, snnqp_stream_t stream);
 
 /* Layout step of the pack: int8 codes [K][N] (dense kernel / flattened HWIO
  * convolution kernel, as the reference stores them) -> MFMA B-operand tiles

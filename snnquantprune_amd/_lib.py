@@ -63,6 +63,8 @@ _PROTOTYPES = {
                                      POINTER(c_int32)]),
     "snnqp_quantize": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_float,
                                c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snnqp_quantize_ex": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
+                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snnqp_pack_codes_mfma": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                       c_void_p]),
     "snnqp_pack_codes_fp6": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),

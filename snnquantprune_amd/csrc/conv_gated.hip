@@ -150,11 +150,16 @@ conv_gated_kernel(ConvGatedArgs a) {
     }
   };
   load_group(bcur, 0);
-  for (int c0 = 0; c0 < a.C; c0 += GC) {
-    load_group(bnxt, c0 + GC < a.C ? c0 + GC : c0);
-    float g[GC];
+  // the gates of a group are requested a group ahead as well (scalar loads: their latency would
+  // otherwise sit in front of the group's first fmaf)
+  float g[GC], gn[GC];
 #pragma unroll
-    for (int j = 0; j < GC; ++j) g[j] = grow[c0 + j];
+  for (int j = 0; j < GC; ++j) g[j] = grow[j];
+  for (int c0 = 0; c0 < a.C; c0 += GC) {
+    const int cn = c0 + GC < a.C ? c0 + GC : c0;
+    load_group(bnxt, cn);
+#pragma unroll
+    for (int j = 0; j < GC; ++j) gn[j] = grow[cn + j];
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       const int c = c0 + j;
@@ -174,9 +179,11 @@ conv_gated_kernel(ConvGatedArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < GC; ++j)
+    for (int j = 0; j < GC; ++j) {
+      g[j] = gn[j];
 #pragma unroll
       for (int t = 0; t < 4; ++t) bcur[j][t] = bnxt[j][t];
+    }
   }
 
   // ---- 3. dequantise and store: lane = output, register i = pixel (i & 3) + 8 (i >> 2) + 4 h ----

@@ -9,6 +9,7 @@ namespace snnqp {
 struct QuantP {
   int kind;
   float p0, p1, L, scale;
+  float lo;     // lower clip bound in units of the range: -1 (sign = True) or 0 (sign = False)
 };
 
 __device__ __forceinline__ float clipf(float x, float lo, float hi) {
@@ -26,19 +27,19 @@ __device__ __forceinline__ void quant_one(float w, const QuantP &p, float &q,
       break;
     }
     case SNNQP_Q_UNIFORM_STATIC: {            // quant.py:350-358
-      float x = clipf(w / p.p0, -1.0f, 1.0f) * p.p0;
+      float x = clipf(w / p.p0, p.lo, 1.0f) * p.p0;
       q = rintf(x / p.scale);
       fq = q * p.scale;
       break;
     }
     case SNNQP_Q_PARAMETRIC_D: {              // quant.py:420-425
-      float v = clipf(w / p.p0, -p.L, p.L);
+      float v = clipf(w / p.p0, p.lo * p.L, p.L);   // q_neg = -q_pos or 0, quant.py:378-384
       q = rintf(v);
       fq = q * p.p0;
       break;
     }
     default: {                                // parametric_d_xmax, quant.py:617-625
-      float x = clipf(w / p.p1, -1.0f, 1.0f) * p.p1;
+      float x = clipf(w / p.p1, p.lo, 1.0f) * p.p1;
       q = rintf(x / p.p0);
       fq = p.p0 * q;
       break;
@@ -106,10 +107,10 @@ extern "C" int snnqp_pack_codes_mfma(const int8_t *w, int64_t K, int32_t N,
   return SNNQP_OK;
 }
 
-extern "C" int snnqp_quantize(int kind, const float *w, const float *mask,
-                              int64_t n, int bits, float p0, float p1,
-                              float *fq_out, int8_t *codes_out, int32_t *flags,
-                              snnqp_stream_t stream) {
+extern "C" int snnqp_quantize_ex(int kind, const float *w, const float *mask,
+                                 int64_t n, int bits, int sign, float p0, float p1,
+                                 float *fq_out, int8_t *codes_out, int32_t *flags,
+                                 snnqp_stream_t stream) {
   using namespace snnqp;
   SNNQP_REQUIRE(n >= 0, SNNQP_EINVAL, "quantize: negative size");
   SNNQP_REQUIRE(kind >= SNNQP_Q_DUQ && kind <= SNNQP_Q_PARAMETRIC_D_XMAX,
@@ -117,13 +118,19 @@ extern "C" int snnqp_quantize(int kind, const float *w, const float *mask,
   // quant.py:332-336 "Bit widths below 2 bits are not supported"
   SNNQP_REQUIRE(bits > 1 && bits <= 24, SNNQP_EINVAL,
                 "quantize: bits must be in [2, 24], got %d", bits);
+  // unsigned levels 2^bits - 1 (quant.py:338-341, :378-384, :458-461, :532-535): float32 holds them
+  // up to 2^24; int8 codes only when they fit (the kernel flags SNNQP_FLAG_CODE_OVERFLOW otherwise)
+  SNNQP_REQUIRE(sign || bits <= 23, SNNQP_EINVAL,
+                "quantize: unsigned bits must be in [2, 23], got %d", bits);
   if (n == 0) return SNNQP_OK;
   SNNQP_REQUIRE(w, SNNQP_EINVAL, "quantize: null weights");
   QuantP p;
   p.kind = kind;
   p.p0 = p0;
   p.p1 = p1;
-  p.L = (float)((1 << (bits - 1)) - 1);
+  p.L = sign ? (float)((1 << (bits - 1)) - 1) : (float)((1 << bits) - 1);
+  // DuQ clips with hard_tanh whatever the sign (quant.py:466): only its level count changes
+  p.lo = (sign || kind == SNNQP_Q_DUQ) ? -1.0f : 0.0f;
   p.scale = p0 / p.L;  // uniform_static: xmax / num_levels, quant.py:357
   const int64_t blocks = ceil_div64(n, 256);
   const int grid = (int)(blocks < 4096 ? blocks : 4096);
@@ -132,4 +139,11 @@ extern "C" int snnqp_quantize(int kind, const float *w, const float *mask,
                      flags);
   SNNQP_CHECK_LAUNCH("quantize_kernel");
   return SNNQP_OK;
+}
+
+extern "C" int snnqp_quantize(int kind, const float *w, const float *mask,
+                              int64_t n, int bits, float p0, float p1,
+                              float *fq_out, int8_t *codes_out, int32_t *flags,
+                              snnqp_stream_t stream) {
+  return snnqp_quantize_ex(kind, w, mask, n, bits, 1, p0, p1, fq_out, codes_out, flags, stream);
 }

@@ -375,8 +375,9 @@ def _in_desc(x):
 
 def quantize(kind: int, w: torch.Tensor, mask: Optional[torch.Tensor], bits: int,
              p0: float, p1: float = 0.0, want_fq: bool = True,
-             want_codes: bool = False):
-  """snnqp_quantize: returns (fq | None, codes | None, flags tensor | None)."""
+             want_codes: bool = False, sign: bool = True):
+  """snnqp_quantize_ex: returns (fq | None, codes | None, flags tensor | None); sign = False is
+  the reference's unsigned form (levels 0 .. 2^bits - 1, quant.py:338-341)."""
   w = _f32c(w)
   _require_gpu(w, mask)
   if mask is not None:
@@ -386,9 +387,9 @@ def quantize(kind: int, w: torch.Tensor, mask: Optional[torch.Tensor], bits: int
   codes = torch.empty(w.shape, dtype=torch.int8, device=w.device) if want_codes else None
   flags = torch.zeros(1, dtype=torch.int32, device=w.device) if (
       want_codes or mask is not None) else None
-  L.check(L.lib().snnqp_quantize(kind, _ptr(w), _ptr(mask), w.numel(), int(bits),
-                                 float(p0), float(p1), _ptr(fq), _ptr(codes),
-                                 _ptr(flags), _stream()))
+  L.check(L.lib().snnqp_quantize_ex(kind, _ptr(w), _ptr(mask), w.numel(), int(bits), 1 if sign else 0,
+                                    float(p0), float(p1), _ptr(fq), _ptr(codes),
+                                    _ptr(flags), _stream()))
   return fq, codes, flags
 
 

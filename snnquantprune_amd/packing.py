@@ -79,7 +79,7 @@ class PackedKernel:
     if d is None or d.bits > 8:
       return None
     _, codes, flags = ops.quantize(d.kind, self.kernel, self.mask, d.bits, d.p0, d.p1,
-                                   want_fq=False, want_codes=True)
+                                   want_fq=False, want_codes=True, sign=d.sign)
     if int(flags.item()) & (L.FLAG_CODE_OVERFLOW | L.FLAG_MASK_NOT_BINARY):
       return None
     c2 = codes.reshape(-1, codes.shape[-1]).to(torch.int32)
@@ -123,7 +123,7 @@ class PackedKernel:
       k = self.kernel.to(torch.float32).contiguous()
       if d is not None:
         fq, _, _ = ops.quantize(d.kind, k, self.mask, d.bits, d.p0, d.p1,
-                                want_fq=True, want_codes=False)
+                                want_fq=True, want_codes=False, sign=d.sign)
       elif self.mask is not None:
         fq = k * self.mask.to(k.device, torch.float32)   # quant.py:491
       else:

@@ -117,13 +117,15 @@ def host_scalar(t) -> float:
 
 @dataclass(frozen=True)
 class QuantDesc:
-  """What snnqp_quantize needs, plus the dequantisation y = fl(fl(acc/L) * m)."""
+  """What snnqp_quantize_ex needs, plus the dequantisation y = fl(fl(acc/L) * m).  `sign` is the
+  reference's call argument (quant.py:331): False = the unsigned levels 0 .. 2^bits - 1."""
   kind: int
   bits: int
   p0: float
   p1: float
   L: float
   m: float
+  sign: bool = True
 
 
 def _f32(x: float) -> float:
@@ -131,17 +133,15 @@ def _f32(x: float) -> float:
   return float(np.float32(x))          # rounds a Python float to float32 (host only)
 
 
-def _check_sign(sign):
-  if not sign:
-    raise NotImplementedError(
-        "unsigned (activation) quantisation is not on the forward hot path; the "
-        "layers always call the quantiser with sign=True (flax_qdense.py:76)")
+def _levels(bits: int, sign: bool) -> int:
+  """num_levels / q_pos of quant.py:338-341, :378-384, :532-535."""
+  return 2 ** (bits - 1) - 1 if sign else 2 ** bits - 1
 
 
 def _apply(desc: QuantDesc, x):
   x = torch.as_tensor(x)
   fq, _, _ = ops.quantize(desc.kind, x, None, desc.bits, desc.p0, desc.p1,
-                          want_fq=True, want_codes=False)
+                          want_fq=True, want_codes=False, sign=desc.sign)
   return fq.reshape(x.shape)
 
 
@@ -164,8 +164,7 @@ class uniform_static(nn.Module):
     if type(self.bits) == int:
       assert self.bits > 1, (
           "Bit widths below 2 bits are not supported but got bits: " + str(self.bits))
-    _check_sign(sign)
-    num_levels = 2 ** (self.bits - 1) - 1
+    num_levels = _levels(self.bits, sign)
     xmax = self.variable("quant_params", "dynamic_range_no_train",
                          lambda: torch.ones((1,), device=torch.as_tensor(x).device))
     if self.is_mutable_collection("quant_params"):
@@ -173,7 +172,7 @@ class uniform_static(nn.Module):
       xmax.value = torch.where(v == 0, torch.ones_like(v), v)
     xm = host_scalar(xmax.value)
     return QuantDesc(L.Q_UNIFORM_STATIC, self.bits, xm, 0.0, 1.0,
-                     _f32(_f32(xm) / float(num_levels)))
+                     _f32(_f32(xm) / float(num_levels)), bool(sign))
 
   def __call__(self, x: Array, sign: bool = True) -> Array:
     return _apply(self.describe(x, sign), x)
@@ -191,16 +190,19 @@ class parametric_d(nn.Module):
 
   @nn.compact_method
   def describe(self, inputs, sign: bool = True) -> Optional[QuantDesc]:
-    _check_sign(sign)
-    q_pos = 2 ** (self.bits - 1) - 1
+    q_pos = _levels(self.bits, sign)
     dev = torch.as_tensor(inputs).device
     step = self.variable("quant_params", "step_size",
                          lambda: torch.ones((1,), device=dev))
     if self.is_mutable_collection("quant_params"):
       v = self.init_fn(inputs, bits=self.bits, sign=sign).reshape(1).to(torch.float32)
-      step.value = torch.ones((1,), device=v.device) * v / math.sqrt(q_pos)
+      # init / sqrt(q_pos) as ONE float32 division (quant.py:397-399); a tensor divided by a Python
+      # scalar on the device is a multiplication by the reciprocal, one ulp off
+      import numpy as np
+      sv = np.float32(host_scalar(v)) / np.sqrt(np.float32(q_pos))
+      step.value = torch.full((1,), float(sv), device=v.device)
     s = host_scalar(step.value)
-    return QuantDesc(L.Q_PARAMETRIC_D, self.bits, s, 0.0, 1.0, _f32(s))
+    return QuantDesc(L.Q_PARAMETRIC_D, self.bits, s, 0.0, 1.0, _f32(s), bool(sign))
 
   def __call__(self, inputs: Array, sign: bool = True) -> Array:
     return _apply(self.describe(inputs, sign), inputs)
@@ -221,7 +223,6 @@ class DuQ(nn.Module):
   def describe(self, inputs, sign: bool = True) -> Optional[QuantDesc]:
     if self.bits == -1:
       return None
-    _check_sign(sign)
     if self.bits < 2:
       raise ValueError("DuQ needs bits >= 2 (n_lv - 1 = 0 divides by zero)")
     a = self.param("a", nn.constant(-1), (1,))
@@ -229,8 +230,8 @@ class DuQ(nn.Module):
     a_h, c_h = host_scalar(a), host_scalar(c)
     if a_h == -1.0:
       return None
-    n_lv = 2 ** (self.bits - 1)
-    return QuantDesc(L.Q_DUQ, self.bits, a_h, c_h, float(n_lv - 1), _f32(c_h))
+    n_lv = 2 ** (self.bits - 1) if sign else 2 ** self.bits        # quant.py:458-461
+    return QuantDesc(L.Q_DUQ, self.bits, a_h, c_h, float(n_lv - 1), _f32(c_h), bool(sign))
 
   def __call__(self, inputs: Array, sign: bool = True) -> Array:
     desc = self.describe(inputs, sign)
@@ -269,10 +270,9 @@ class parametric_d_xmax(nn.Module):
 
   @nn.compact_method
   def describe(self, inputs, sign: bool = True) -> Optional[QuantDesc]:
-    _check_sign(sign)
     x = torch.as_tensor(inputs)
     dev = x.device
-    num_levels = 2 ** (self.bits - 1) - 1
+    num_levels = _levels(self.bits, sign)
     one = lambda v: torch.full((1,), float(v), device=dev)  # noqa: E731
     self.variable("quant_config", "max_xmax", one, self.xmax_max)
     self.variable("quant_config", "min_xmax", one, self.xmax_min)
@@ -299,7 +299,8 @@ class parametric_d_xmax(nn.Module):
         v = self.init_fn(x, bits=self.bits, sign=sign).reshape(1).to(torch.float32)
         v = torch.where(v == 0, torch.ones_like(v), v)
         xmax.value = v
-        d.value = v / num_levels
+        import numpy as np
+        d.value = one(float(np.float32(host_scalar(v)) / np.float32(num_levels)))   # one float32 division (:570)
     d_h = min(max(host_scalar(d.value), float(self.d_min)), float(self.d_max))
     xmax_h = min(max(host_scalar(xmax.value), float(self.xmax_min)),
                  float(self.xmax_max))
@@ -315,7 +316,7 @@ class parametric_d_xmax(nn.Module):
       act_mb.value = one(n_wf * nbits if self.act else 0.0)
     if self.is_mutable_collection("weight_size"):
       weight_mb.value = one(0.0 if self.act else n_wf * nbits)
-    return QuantDesc(L.Q_PARAMETRIC_D_XMAX, self.bits, d_h, xmax_h, 1.0, d_h)
+    return QuantDesc(L.Q_PARAMETRIC_D_XMAX, self.bits, d_h, xmax_h, 1.0, d_h, bool(sign))
 
   def __call__(self, inputs: Array, sign: bool = True) -> Array:
     return _apply(self.describe(inputs, sign), inputs)

@@ -121,6 +121,31 @@ def test_unique_values(oracle, bits):
   assert len(np.unique(oracle.duq_forward(data, scale, scale, bits))) == 2 ** bits - 1
 
 
+def test_unsigned_quantisers_known_answers(oracle):
+  """sign=False of quant.py:338-341, :378-384, :458-461, :532-535: hand-derived answers.
+  2-bit unsigned uniform over xmax = 0.9: levels {0, 0.3, 0.6, 0.9}, negatives clip to 0;
+  parametric_d with step 0.25: clip(x / 0.25, 0, 3); DuQ keeps hard_tanh: n_lv - 1 = 3 both ways."""
+  x = np.array([-0.5, 0.0, 0.14, 0.16, 0.5, 0.7, 0.9, 2.0], F32)
+  us = oracle.uniform_static_forward(x, 0.9, 2, sign=False)
+  scale = F32(0.9) / F32(3)
+  np.testing.assert_array_equal(us, np.array([0, 0, 0, 1, 2, 2, 3, 3], F32) * scale)
+  pd = oracle.parametric_d_forward(x, 0.25, 2, sign=False)
+  np.testing.assert_array_equal(pd, np.array([0, 0, 1, 1, 2, 3, 3, 3], F32) * F32(0.25))
+  pdx = oracle.parametric_d_xmax_forward(x, 0.25, 0.75, sign=False)
+  np.testing.assert_array_equal(pdx, np.array([0, 0, 1, 1, 2, 3, 3, 3], F32) * F32(0.25))
+  du = oracle.duq_forward(x, 1.0, 1.0, 2, sign=False)          # round(hard_tanh(x) * 3) / 3
+  np.testing.assert_array_equal(du, (np.array([-2, 0, 0, 0, 2, 2, 3, 3], F32) / F32(3)) * F32(1))   # -1.5 -> -2, 1.5 -> 2: half to even
+  # level counts: 2^bits for the unsigned forms on non-negative data
+  rng = np.random.Generator(np.random.PCG64(77))
+  data = np.abs(rng.uniform(-1, 1, size=(400, 100)) * 23).astype(F32)
+  data[0, 0] = 23
+  for bits in (2, 3, 5, 8):
+    assert len(np.unique(oracle.uniform_static_forward(data, 23.0, bits, sign=False))) == 2 ** bits
+    assert len(np.unique(oracle.parametric_d_forward(data, 23.0 / (2 ** bits - 1), bits, sign=False))) == 2 ** bits
+    assert len(np.unique(oracle.duq_forward(data, 23.0, 23.0, bits, sign=False))) == 2 ** bits
+    assert oracle.parametric_d_init(data, bits, sign=False) == F32(F32(23) / np.sqrt(F32(2 ** bits - 1)))
+
+
 def test_qdense_without_quant_is_plain_matmul(oracle):
   """flax_qdense_test.py:153-250: empty config == nn.Dense."""
   rng = np.random.Generator(np.random.PCG64(3))

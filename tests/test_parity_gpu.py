@@ -3395,3 +3395,61 @@ def test_gated_dense_in_the_gint_form(dev, oracle, shape):
   np.testing.assert_array_equal(_np(sp2), es2)
   np.testing.assert_array_equal(_np(u2), eu2)
   assert ops.device_status() == 0
+
+
+def test_unsigned_quantisers_bit_exact(dev, oracle):
+  """The reference's quantisers with sign=False (quant.py:331-358, :374-425, :439-469, :512-625:
+  levels 0 .. 2^bits - 1, lower clip bound 0; DuQ keeps hard_tanh and only changes n_lv) --
+  snnqp_quantize_ex against the oracle element by element, the module surface (init with
+  calibration + apply) against the oracle's init + forward, and the unsigned level count."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops, quant
+  rng = np.random.Generator(np.random.PCG64(20261))
+  w = (rng.standard_normal((64, 96)) * 0.6).astype(F32)
+  w[0, :8] = [0.0, -0.0, 0.45, -0.45, 0.9, 1.7, -3.0, 0.8999999]
+  x = _t(w, dev)
+  for bits in (2, 3, 4, 8, 11):
+    for sign in (False, True):
+      fq, _, _ = ops.quantize(L.Q_DUQ, x, None, bits, 0.73, 0.41, sign=sign)
+      np.testing.assert_array_equal(_np(fq), oracle.duq_forward(w, 0.73, 0.41, bits, sign))
+      fq, _, _ = ops.quantize(L.Q_UNIFORM_STATIC, x, None, bits, 0.9, sign=sign)
+      np.testing.assert_array_equal(_np(fq), oracle.uniform_static_forward(w, 0.9, bits, sign))
+      fq, _, _ = ops.quantize(L.Q_PARAMETRIC_D, x, None, bits, 0.05, sign=sign)
+      np.testing.assert_array_equal(_np(fq), oracle.parametric_d_forward(w, 0.05, bits, sign))
+      fq, _, _ = ops.quantize(L.Q_PARAMETRIC_D_XMAX, x, None, bits, 2 ** -4, 0.8, sign=sign)
+      np.testing.assert_array_equal(_np(fq), oracle.parametric_d_xmax_forward(w, 2 ** -4, 0.8, sign))
+    # unsigned: nothing below zero survives (DuQ excepted: hard_tanh clips at -1)
+    fq, _, _ = ops.quantize(L.Q_UNIFORM_STATIC, x, None, bits, 0.9, sign=False)
+    assert float(fq.min()) == 0.0 and len(np.unique(_np(fq))) <= 2 ** bits
+  # int8 codes of the unsigned form exist up to 7 bits, are flagged beyond
+  _, codes, fl = ops.quantize(L.Q_UNIFORM_STATIC, x, None, 7, 0.9, want_fq=False, want_codes=True, sign=False)
+  assert int(fl.item()) == 0 and int(codes.max()) == 127 and int(codes.min()) == 0
+  _, _, fl = ops.quantize(L.Q_UNIFORM_STATIC, x, None, 8, 0.9, want_fq=False, want_codes=True, sign=False)
+  assert int(fl.item()) & L.FLAG_CODE_OVERFLOW
+  # the modules: init (calibration) + apply, sign=False throughout
+  data = np.abs(rng.uniform(-1, 1, size=(120, 50)) * 23).astype(F32)
+  data[0, 0] = 23
+  xd = _t(data, dev)
+  for bits in (2, 4, 8):
+    m = quant.uniform_static(bits)
+    v = m.init(0, xd, sign=False)
+    out = _np(m.apply(v, xd, sign=False))
+    np.testing.assert_array_equal(out, oracle.uniform_static_forward(
+        data, oracle.uniform_static_init(data, bits, False), bits, False))
+    assert len(np.unique(out)) == 2 ** bits                      # 0 .. 2^bits - 1
+    m = quant.parametric_d(bits)
+    v = m.init(0, xd, sign=False)
+    step = oracle.parametric_d_init(data, bits, False)
+    assert float(v["quant_params"]["step_size"]) == float(step)
+    np.testing.assert_array_equal(_np(m.apply(v, xd, sign=False)), oracle.parametric_d_forward(data, step, bits, False))
+    m = quant.parametric_d_xmax(bits, init_fn=quant.max_init)
+    v = m.init(0, xd, sign=False)
+    d, xmax = oracle.parametric_d_xmax_init(data, bits, False, init_fn=oracle.max_init)
+    np.testing.assert_array_equal(_np(m.apply(v, xd, sign=False)), oracle.parametric_d_xmax_forward(data, d, xmax, False))
+    dq = quant.DuQ(bits)
+    v = dq.init(0, xd, sign=False)
+    v["params"]["a"] = torch.full((1,), 23.0, device=dev)
+    v["params"]["c"] = torch.full((1,), 23.0, device=dev)
+    out = _np(dq.apply(v, xd, sign=False))
+    np.testing.assert_array_equal(out, oracle.duq_forward(data, 23.0, 23.0, bits, False))
+    assert len(np.unique(out)) == 2 ** bits
