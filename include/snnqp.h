@@ -169,7 +169,7 @@ typedef struct {
  * snnqp_workqueue_*, snnqp_dense_lif_forward_ws; 500: float32 inputs into integer blocks --
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
- * snnqp_dense_gated_forward, snnqp_quantize_ex).  A binding compares snnqp_version()
+ * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 500
 int snnqp_version(void);
@@ -263,6 +263,13 @@ int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
 int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
                        const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                        float *y, int32_t *acc, snnqp_stream_t stream);
+/* The same, executed only if *pred != 0 when the stream reaches it: the float32 connection behind
+ * a speculative integer one (a float32 tensor narrowed by snnqp_narrow_f32, whose flag word is
+ * `pred`) -- QuantDense / QuantConv called on their own with float32 inputs
+ * (flax_qdense.py:67, flax_qconv.py:101).  Direct form, same fmaf chain. */
+int snnqp_conv_forward_if(const int32_t *pred, const void *x, int in_type, int64_t NB,
+                          const snnqp_conv_geom_t *g, const snnqp_weight_t *w, float *y,
+                          snnqp_stream_t stream);
 
 /* ---- connection on gate x raster (no neuron) ------------------------------------
  * replaces: QuantConv (flax_qconv.py:93-171; 3x3, stride 1, pad 1) on the product of a spike

@@ -83,6 +83,8 @@ _PROTOTYPES = {
     "snnqp_unpack_bits": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "snnqp_conv_forward": (c_int, [c_void_p, c_int, c_int64, POINTER(ConvGeomT),
                                    POINTER(WeightT), c_void_p, c_void_p, c_void_p]),
+    "snnqp_conv_forward_if": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(ConvGeomT),
+                                      POINTER(WeightT), c_void_p, c_void_p]),
     "snnqp_conv_gated_packed_bytes": (c_int64, [c_int32, c_int32]),
     "snnqp_pack_codes_gated": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_conv_gated_forward": (c_int, [c_void_p, c_void_p, c_int64, POINTER(ConvGeomT),

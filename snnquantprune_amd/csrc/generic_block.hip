@@ -273,3 +273,18 @@ extern "C" int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
   return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr,
                      nullptr, nullptr, y, SNNQP_F32, acc, (hipStream_t)stream);
 }
+
+// The predicated form of snnqp_conv_forward (snnqp.h): the float32 re-evaluation of a connection
+// whose integer launch met a value that is not an integer in [0, 255].  Direct form (the same fmaf
+// chain as the f32-MFMA kernel, which is not predicated): the rare path.
+extern "C" int snnqp_conv_forward_if(const int32_t *pred, const void *x, int in_type, int64_t NB,
+                                     const snnqp_conv_geom_t *g, const snnqp_weight_t *w, float *y,
+                                     snnqp_stream_t stream) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(pred && g, SNNQP_EINVAL, "conv_forward_if: null argument");
+  SNNQP_REQUIRE(NB >= 0 && NB < (1ll << 31), SNNQP_EINVAL, "conv_forward_if: bad NB");
+  const int64_t pix = (in_type == SNNQP_BITS) ? (g->Cin + 31) / 32 : g->Cin;
+  const int64_t img = (int64_t)g->H * g->W * pix;
+  return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr, nullptr, nullptr, y,
+                     SNNQP_F32, nullptr, (hipStream_t)stream, 1, pred);
+}

@@ -124,7 +124,10 @@ class QuantConv(nn.Module):
       x4 = x.reshape_leading(nb, g.H, g.W)
     else:
       x4 = x.reshape(nb, g.H, g.W, cin)
-    y = ops.conv_forward(x4, g, w)
+    if integer is packing.SPECULATE and w.is_int:     # float32 that may hold integers: decided on the device
+      y = ops.conv_forward_speculative(x4, g, w, pk.float_weight())
+    else:
+      y = ops.conv_forward(x4, g, w)
     if nsp == 1:
       y = y.reshape(nb, y.shape[2], self.features)
     if is_single:

@@ -96,7 +96,11 @@ class QuantDense(nn.Module):
     geom = ops.ConvGeom(1, 1, K, self.features, 1, 1)
     x4 = x.reshape_leading(nb, 1, 1) if isinstance(x, ops.PackedSpikes) \
         else x.reshape(nb, 1, 1, K)
-    y = ops.conv_forward(x4, geom, w).reshape(lead + (self.features,))
+    if integer is packing.SPECULATE and w.is_int:     # float32 that may hold integers: decided on the device
+      y = ops.conv_forward_speculative(x4, geom, w, pk.float_weight())
+    else:
+      y = ops.conv_forward(x4, geom, w)
+    y = y.reshape(lead + (self.features,))
     if self.use_bias:
       y = add_bias(y, quantized_bias(self, pk.kernel))
     return y

@@ -630,6 +630,20 @@ def conv_forward(x, geom: ConvGeom, weight: Weight, want_acc: bool = False):
   return (y, acc) if want_acc else y
 
 
+def conv_forward_speculative(x: torch.Tensor, geom: ConvGeom, int_weight: Weight, float_weight: Weight):
+  """The connection alone on a float32 tensor [NB, H, W, Cin] that MAY hold integers in [0, 255]
+  (QuantDense / QuantConv called outside a SpikingBlock): narrowed to uint8 and checked in one
+  device pass, the integer connection on the copy, then the float32 connection into the same
+  output, executed only if the check failed (snnqp_conv_forward_if).  Nothing is read back."""
+  x = _f32c(x)
+  x8, pred = narrow_f32_async(x)
+  y = conv_forward(x8, geom, int_weight)
+  g, w = geom.struct(), float_weight.struct()
+  L.check(L.lib().snnqp_conv_forward_if(_ptr(pred), _ptr(x), L.F32, x.shape[0], ctypes.byref(g), ctypes.byref(w),
+                                        _ptr(y), _stream()))
+  return y
+
+
 def pack_codes_gated(codes: torch.Tensor) -> torch.Tensor:
   """int8 HWIO codes [3, 3, Cin, Cout] of magnitude <= 7 -> the fp6 operand layout of
   conv_gated_forward (snnqp_pack_codes_gated)."""

@@ -3453,3 +3453,47 @@ def test_unsigned_quantisers_bit_exact(dev, oracle):
     out = _np(dq.apply(v, xd, sign=False))
     np.testing.assert_array_equal(out, oracle.duq_forward(data, 23.0, 23.0, bits, False))
     assert len(np.unique(out)) == 2 ** bits
+
+
+def test_connections_alone_on_float32_inputs(dev, oracle, monkeypatch):
+  """QuantDense / QuantConv called on their own (not inside a SpikingBlock) with the float32 tensors
+  the reference hands them (flax_qdense.py:67, flax_qconv.py:101), quantised kernels: integer-valued
+  inputs give the `int` contract, a non-integer or a value beyond 255 the `fseq` one -- decided on
+  the device (narrowing pass + predicated float32 connection), with nothing read back."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import synthetic as syn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  from snnquantprune_amd.flax_qdense import QuantDense
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  rng = np.random.Generator(np.random.PCG64(4411))
+  leaf = syn.quant_leaf((70, 45), 5.0, 31, True, 0.9)
+  qw = qweight_of(oracle, leaf, 4)
+  m = QuantDense(45, use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale)
+  v = nn.tree_from_numpy({"params": leaf}, dev)
+  x = rng.integers(0, 4, size=(3, 9, 70)).astype(F32)
+  leafc = syn.quant_leaf((3, 3, 6, 20), 5.0, 32, True, 0.9)
+  qc = qweight_of(oracle, leafc, 4)
+  mc = QuantConv(20, (3, 3), strides=(2, 1), padding="SAME", use_bias=False, config=cfg.quant, bits=4,
+                 g_scale=cfg.quant.g_scale)
+  vc = nn.tree_from_numpy({"params": leafc}, dev)
+  xc = rng.integers(0, 3, size=(4, 7, 9, 6)).astype(F32)
+
+  def no_readback(*a, **k):
+    raise AssertionError("host read-back inside a connection")
+  m.apply(v, _t(x, dev)); mc.apply(vc, _t(xc, dev))          # pack once (the pack step reads scalars back)
+  monkeypatch.setattr(torch.Tensor, "item", no_readback)
+  monkeypatch.setattr(torch.Tensor, "tolist", no_readback)
+  for bad, mode in ((None, "int"), (0.5, "fseq"), (300.0, "fseq"), (-1.0, "fseq")):
+    xi, xci = x.copy(), xc.copy()
+    if bad is not None:
+      xi[1, 4, 33] = bad
+      xci[2, 3, 5, 1] = bad
+    y = m.apply(v, _t(xi, dev))
+    yc = mc.apply(vc, _t(xci, dev))
+    monkeypatch.undo()
+    np.testing.assert_array_equal(_np(y), oracle.quant_dense(xi, qw, mode), err_msg=str(bad))
+    np.testing.assert_array_equal(_np(yc), oracle.quant_conv(xci, qc, strides=(2, 1), padding="SAME", mode=mode),
+                                  err_msg=str(bad))
+    monkeypatch.setattr(torch.Tensor, "item", no_readback)
+    monkeypatch.setattr(torch.Tensor, "tolist", no_readback)
+  monkeypatch.undo()
