@@ -162,6 +162,18 @@ typedef struct {
   int32_t groups;               /* feature_group_count   */
 } snnqp_conv_geom_t;
 
+/* Geometry of a 3-D convolution (flax_qconv.py:93-171 with three spatial axes; index 0 = depth,
+ * 1 = height, 2 = width): images [D][H][W][Cin], kernels [KD][KH][KW][Cin / groups][Cout]. */
+typedef struct {
+  int32_t D, H, W, Cin, Cout;
+  int32_t KD, KH, KW;
+  int32_t stride[3];
+  int32_t pad_lo[3], pad_hi[3];
+  int32_t in_dil[3];            /* input_dilation  (lhs) */
+  int32_t k_dil[3];             /* kernel_dilation (rhs) */
+  int32_t groups;               /* feature_group_count   */
+} snnqp_conv3d_geom_t;
+
 /* ABI version of this header: bumped whenever a struct or a signature below changes
  * (100: round 1; 200: snnqp_bn_t.flags, x_max / x_seen of snnqp_conv_lif_forward;
  * 300: SNNQP_EV1 / SNNQP_EV4 frame types, snnqp_pack_frames / snnqp_unpack_frames,
@@ -169,7 +181,8 @@ typedef struct {
  * snnqp_workqueue_*, snnqp_dense_lif_forward_ws; 500: float32 inputs into integer blocks --
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
- * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if).  A binding compares snnqp_version()
+ * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if,
+ * snnqp_conv3d_*).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 500
 int snnqp_version(void);
@@ -270,6 +283,23 @@ int snnqp_conv_forward(const void *x, int in_type, int64_t NB,
 int snnqp_conv_forward_if(const int32_t *pred, const void *x, int in_type, int64_t NB,
                           const snnqp_conv_geom_t *g, const snnqp_weight_t *w, float *y,
                           snnqp_stream_t stream);
+
+/* ---- 3-D QuantConv, alone or as a SpikingBlock --------------------------------------------
+ * replaces: lax.conv_general_dilated at flax_qconv.py:158-168 for kernels with three spatial axes
+ *           (and SpikingBlock.__call__, spiking_learning.py:446-462, around it).
+ * x [T][B][D][H][W][Cin] (strides in elements, words for SNNQP_BITS; types F32 / U8 / BITS);
+ * nrn null or kind SNNQP_NEURON_NONE: the connection alone (pass T = 1, B = the number of images),
+ * s_out = float32 currents [B][OD][OH][OW][Cout] (s_type SNNQP_F32); else s_out = spikes
+ * [T][B][OD][OH][OW][Cout] (F32 or BITS), u0 / u_out [B][OD][OH][OW][Cout].  Contracts as everywhere:
+ * int8 codes x integer input = exact int32 sum, then fl(fl(acc / L) * m); float32 weights = fmaf
+ * chain over (kd, kh, kw, cin) ascending.  Direct form (one thread per output neuron): no shipped
+ * model has a 3-D layer.  pred (nullable): skip the launch unless *pred != 0, as the *_if calls. */
+int snnqp_conv3d_out_shape(const snnqp_conv3d_geom_t *g, int32_t *OD, int32_t *OH, int32_t *OW);
+int snnqp_conv3d_lif_forward(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                             int64_t x_stride_b, int32_t T, int32_t B,
+                             const snnqp_conv3d_geom_t *g, const snnqp_weight_t *w,
+                             const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                             float *u_out, void *s_out, int s_type, snnqp_stream_t stream);
 
 /* ---- connection on gate x raster (no neuron) ------------------------------------
  * replaces: QuantConv (flax_qconv.py:93-171; 3x3, stride 1, pad 1) on the product of a spike

@@ -456,35 +456,34 @@ def conv_out_spatial(in_spatial, k_spatial, strides, pads, lhs_dilation=None,
 
 
 def im2col(x, k_spatial, strides, pads, lhs_dilation=None, rhs_dilation=None):
-  """NHWC (or NWC) -> [B, *out_spatial, prod(k)*Cin] in (k..., cin) order."""
+  """Channels-last [B, *spatial, C] (1, 2 or 3 spatial axes) -> [B, *out_spatial, prod(k) * Cin]
+  in (k..., cin) order -- the flattening of the reference's kernels (HWIO / DHWIO,
+  flax_qconv.py:120-123), which is the order of the `fseq` chain."""
+  import itertools
   x = np.asarray(x)
   n = x.ndim - 2
   lhs_dilation = tuple(lhs_dilation or (1,) * n)
   rhs_dilation = tuple(rhs_dilation or (1,) * n)
-  if n == 1:                      # treat 1-D as 2-D with H = 1
-    cols = im2col(x[:, None], (1,) + tuple(k_spatial), (1,) + tuple(strides),
-                  ((0, 0),) + tuple(pads), (1,) + lhs_dilation,
-                  (1,) + rhs_dilation)
-    return cols[:, 0]
-  assert n == 2, "oracle supports 1-D and 2-D convolutions"
-  B, H, W, C = x.shape
-  if lhs_dilation != (1, 1):
-    hd = (H - 1) * lhs_dilation[0] + 1
-    wd = (W - 1) * lhs_dilation[1] + 1
-    xd = np.zeros((B, hd, wd, C), dtype=x.dtype)
-    xd[:, ::lhs_dilation[0], ::lhs_dilation[1]] = x
-    x, H, W = xd, hd, wd
-  xp = np.pad(x, ((0, 0), pads[0], pads[1], (0, 0)))
-  OH, OW = conv_out_spatial((H, W), k_spatial, strides, pads, None, rhs_dilation)
-  KH, KW = k_spatial
-  cols = np.empty((B, OH, OW, KH, KW, C), dtype=x.dtype)
-  for kh in range(KH):
-    for kw in range(KW):
-      y0, x0 = kh * rhs_dilation[0], kw * rhs_dilation[1]
-      cols[:, :, :, kh, kw, :] = xp[
-          :, y0:y0 + (OH - 1) * strides[0] + 1:strides[0],
-          x0:x0 + (OW - 1) * strides[1] + 1:strides[1], :]
-  return cols.reshape(B, OH, OW, KH * KW * C)
+  assert 1 <= n <= 3, "oracle supports 1-D, 2-D and 3-D convolutions"
+  B, C = x.shape[0], x.shape[-1]
+  sp = x.shape[1:-1]
+  if any(d != 1 for d in lhs_dilation):
+    dsp = tuple((sp[i] - 1) * lhs_dilation[i] + 1 if sp[i] > 0 else 0 for i in range(n))
+    xd = np.zeros((B,) + dsp + (C,), dtype=x.dtype)
+    xd[(slice(None),) + tuple(slice(None, None, lhs_dilation[i]) for i in range(n))] = x
+    x, sp = xd, dsp
+  xp = np.pad(x, ((0, 0),) + tuple(tuple(p) for p in pads) + ((0, 0),))
+  out = conv_out_spatial(sp, k_spatial, strides, pads, None, rhs_dilation)
+  cols = np.empty((B,) + tuple(out) + tuple(k_spatial) + (C,), dtype=x.dtype)
+  for kpos in itertools.product(*[range(k) for k in k_spatial]):
+    src = (slice(None),) + tuple(
+        slice(kpos[i] * rhs_dilation[i], kpos[i] * rhs_dilation[i] + (out[i] - 1) * strides[i] + 1, strides[i])
+        for i in range(n)) + (slice(None),)
+    cols[(slice(None),) * (1 + n) + tuple(kpos) + (slice(None),)] = xp[src]
+  K = C
+  for k in k_spatial:
+    K *= k
+  return cols.reshape((B,) + tuple(out) + (K,))
 
 
 def quant_conv(x, qw: QWeight, strides=None, padding="SAME", input_dilation=None,
@@ -492,7 +491,7 @@ def quant_conv(x, qw: QWeight, strides=None, padding="SAME", input_dilation=None
                return_acc=False):
   """QuantConv.__call__ without bias, flax_qconv.py:93-171.
 
-  x NHWC ([B, H, W, Cin] or [B, W, Cin]); kernel HWIO in qw."""
+  x channels-last ([B, W, Cin], [B, H, W, Cin] or [B, D, H, W, Cin]); kernel HWIO / DHWIO in qw."""
   x = np.asarray(x)
   kshape = qw.kernel.shape
   nsp = len(kshape) - 2

@@ -55,6 +55,12 @@ class ConvGeomT(Structure):
       "in_dil_h", "in_dil_w", "k_dil_h", "k_dil_w", "groups")]
 
 
+class Conv3dGeomT(Structure):
+  _fields_ = ([(n, c_int32) for n in ("D", "H", "W", "Cin", "Cout", "KD", "KH", "KW")]
+              + [(n, c_int32 * 3) for n in ("stride", "pad_lo", "pad_hi", "in_dil", "k_dil")]
+              + [("groups", c_int32)])
+
+
 _PROTOTYPES = {
     "snnqp_version": (c_int, []),
     "snnqp_last_error": (c_char_p, []),
@@ -85,6 +91,11 @@ _PROTOTYPES = {
                                    POINTER(WeightT), c_void_p, c_void_p, c_void_p]),
     "snnqp_conv_forward_if": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(ConvGeomT),
                                       POINTER(WeightT), c_void_p, c_void_p]),
+    "snnqp_conv3d_out_shape": (c_int, [POINTER(Conv3dGeomT), POINTER(c_int32), POINTER(c_int32),
+                                       POINTER(c_int32)]),
+    "snnqp_conv3d_lif_forward": (c_int, [
+        c_void_p, c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(Conv3dGeomT),
+        POINTER(WeightT), POINTER(BnT), POINTER(NeuronT), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snnqp_conv_gated_packed_bytes": (c_int64, [c_int32, c_int32]),
     "snnqp_pack_codes_gated": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_conv_gated_forward": (c_int, [c_void_p, c_void_p, c_int64, POINTER(ConvGeomT),

@@ -1,12 +1,12 @@
 // Direct-form SpikingBlock: one thread owns one output neuron for all T steps
 // (membrane potential in a register), computing its convolution / dense sum
 // from the input each step.  Serves every geometry and element type of
-// QuantConv (flax_qconv.py:93-171) and QuantDense (flax_qdense.py:58-89, the
-// 1x1 convolution on a 1x1 image); the MFMA kernels take over the shapes the
-// BASELINE configs use.  Two arithmetic paths:
+// QuantConv (flax_qconv.py:93-171: 1-D, 2-D and -- with a depth axis, snnqp_conv3d_* -- 3-D) and
+// QuantDense (flax_qdense.py:58-89, the 1x1 convolution on a 1x1 image); the MFMA kernels take
+// over the shapes the BASELINE configs use.  Two arithmetic paths:
 //   INT   int8 codes x integer input (u8 counts or spike bits): exact int32
 //         accumulator, current = fl(fl(acc / L) * m)
-//   FSEQ  float32 weights x any input: fmaf chain over (kh, kw, cin) ascending
+//   FSEQ  float32 weights x any input: fmaf chain over (kd, kh, kw, cin) ascending
 #include "kernels.h"
 
 namespace snnqp {
@@ -29,6 +29,9 @@ struct GenericArgs {
   int64_t total;             // B * OH * OW * Cout (OH, OW: pooled when the pool is fused)
   int32_t FH, FW;            // full-resolution output size (u0 / u_out)
   const int32_t *pred;       // nullable device word: skip the launch unless *pred != 0
+  // depth axis of a 3-D convolution (images [D][H][W][Cin], kernels [KD][KH][KW][Cin/g][Cout]);
+  // D = KD = OD = 1 and unit stride / dilation, zero padding for everything else
+  int32_t D, KD, OD, Dd, stride_d, pad_d_lo, in_dil_d, k_dil_d;
 };
 
 template <int IN>
@@ -67,6 +70,7 @@ generic_block_kernel(GenericArgs a) {
     const int32_t co = (int32_t)(r % g.Cout); r /= g.Cout;
     const int32_t px = (int32_t)(r % a.OW); r /= a.OW;
     const int32_t py = (int32_t)(r % a.OH); r /= a.OH;
+    const int32_t pz = (int32_t)(r % a.OD); r /= a.OD;
     const int32_t b = (int32_t)r;
     const int32_t grp = co / a.CoutG;
     const int32_t cin0 = grp * a.CinG;
@@ -79,7 +83,7 @@ generic_block_kernel(GenericArgs a) {
     for (int p = 0; p < P; ++p) {
       u[p] = 0.0f;
       if (live && a.u0 && a.nrn.kind != SNNQP_NEURON_NONE)
-        u[p] = a.u0[(((int64_t)b * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co];
+        u[p] = a.u0[((((int64_t)b * a.OD + pz) * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co];
     }
 
     for (int32_t t = 0; t < a.T; ++t) {
@@ -92,26 +96,31 @@ generic_block_kernel(GenericArgs a) {
         int iacc = 0;
         float facc = 0.0f;
         if (live) {
-          for (int32_t kh = 0; kh < g.KH; ++kh) {
-            const int32_t yd = oy * g.stride_h - g.pad_h_lo + kh * g.k_dil_h;
-            if (yd < 0 || yd >= a.Hd || (yd % g.in_dil_h) != 0) continue;
-            const int32_t iy = yd / g.in_dil_h;
-            for (int32_t kw = 0; kw < g.KW; ++kw) {
-              const int32_t xd = ox * g.stride_w - g.pad_w_lo + kw * g.k_dil_w;
-              if (xd < 0 || xd >= a.Wd || (xd % g.in_dil_w) != 0) continue;
-              const int32_t ix = xd / g.in_dil_w;
-              const int64_t pix_off = img_off + ((int64_t)iy * g.W + ix) * pix_elems;
-              const int64_t wbase = ((int64_t)(kh * g.KW + kw) * a.CinG) * g.Cout + co;
-              if (INTPATH) {
-                const int8_t *w = (const int8_t *)a.w;
-                for (int32_t ci = 0; ci < a.CinG; ++ci)
-                  iacc += load_int<IN>(a.x, pix_off, cin0 + ci) *
-                          (int)w[wbase + (int64_t)ci * g.Cout];
-              } else {
-                const float *w = (const float *)a.w;
-                for (int32_t ci = 0; ci < a.CinG; ++ci)
-                  facc = __builtin_fmaf(load_float<IN>(a.x, pix_off, cin0 + ci),
-                                        w[wbase + (int64_t)ci * g.Cout], facc);
+          for (int32_t kd = 0; kd < a.KD; ++kd) {
+            const int32_t zd = pz * a.stride_d - a.pad_d_lo + kd * a.k_dil_d;
+            if (zd < 0 || zd >= a.Dd || (zd % a.in_dil_d) != 0) continue;
+            const int32_t iz = zd / a.in_dil_d;
+            for (int32_t kh = 0; kh < g.KH; ++kh) {
+              const int32_t yd = oy * g.stride_h - g.pad_h_lo + kh * g.k_dil_h;
+              if (yd < 0 || yd >= a.Hd || (yd % g.in_dil_h) != 0) continue;
+              const int32_t iy = yd / g.in_dil_h;
+              for (int32_t kw = 0; kw < g.KW; ++kw) {
+                const int32_t xd = ox * g.stride_w - g.pad_w_lo + kw * g.k_dil_w;
+                if (xd < 0 || xd >= a.Wd || (xd % g.in_dil_w) != 0) continue;
+                const int32_t ix = xd / g.in_dil_w;
+                const int64_t pix_off = img_off + (((int64_t)iz * g.H + iy) * g.W + ix) * pix_elems;
+                const int64_t wbase = ((int64_t)((kd * g.KH + kh) * g.KW + kw) * a.CinG) * g.Cout + co;
+                if (INTPATH) {
+                  const int8_t *w = (const int8_t *)a.w;
+                  for (int32_t ci = 0; ci < a.CinG; ++ci)
+                    iacc += load_int<IN>(a.x, pix_off, cin0 + ci) *
+                            (int)w[wbase + (int64_t)ci * g.Cout];
+                } else {
+                  const float *w = (const float *)a.w;
+                  for (int32_t ci = 0; ci < a.CinG; ++ci)
+                    facc = __builtin_fmaf(load_float<IN>(a.x, pix_off, cin0 + ci),
+                                          w[wbase + (int64_t)ci * g.Cout], facc);
+                }
               }
             }
           }
@@ -146,7 +155,7 @@ generic_block_kernel(GenericArgs a) {
     if (live && a.u_out && a.nrn.kind != SNNQP_NEURON_NONE) {
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        a.u_out[(((int64_t)b * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co] = u[p];
+        a.u_out[((((int64_t)b * a.OD + pz) * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co] = u[p];
     }
   }
 }
@@ -189,10 +198,11 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
                 int32_t B, const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                 const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                 float *u_out, void *s_out, int s_type, int32_t *acc_out,
-                hipStream_t st, int pool, const int32_t *pred) {
+                hipStream_t st, int pool, const int32_t *pred, const GenericDepth *dz) {
   int32_t OH, OW;
   int rc = check_geom(g, &OH, &OW);
   if (rc) return rc;
+  SNNQP_REQUIRE(!dz || pool == 1, SNNQP_EINVAL, "generic block: the fused pool is 2-D");
   SNNQP_REQUIRE(pool == 1 || (pool == 2 && nrn && nrn->kind != SNNQP_NEURON_NONE), SNNQP_EINVAL,
                 "generic block: pool must be 1, or 2 with a neuron");
   SNNQP_REQUIRE(x && w && w->w && s_out, SNNQP_EINVAL, "generic block: null pointer");
@@ -202,6 +212,10 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
   a.FH = OH; a.FW = OW;
   a.OH = OH / pool; a.OW = OW / pool;
   a.pred = pred;
+  a.D = dz ? dz->D : 1; a.KD = dz ? dz->KD : 1; a.OD = dz ? dz->OD : 1;
+  a.stride_d = dz ? dz->stride : 1; a.pad_d_lo = dz ? dz->pad_lo : 0;
+  a.in_dil_d = dz ? dz->in_dil : 1; a.k_dil_d = dz ? dz->k_dil : 1;
+  a.Dd = a.D > 0 ? (a.D - 1) * a.in_dil_d + 1 : 0;
   a.Hd = g->H > 0 ? (g->H - 1) * g->in_dil_h + 1 : 0;
   a.Wd = g->W > 0 ? (g->W - 1) * g->in_dil_w + 1 : 0;
   a.CinG = g->Cin / g->groups; a.CoutG = g->Cout / g->groups;
@@ -212,7 +226,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.s_type = s_type;
   a.acc_out = acc_out;
-  a.total = (int64_t)B * a.OH * a.OW * g->Cout;
+  a.total = (int64_t)B * a.OD * a.OH * a.OW * g->Cout;
   if (a.total == 0 || T == 0) return SNNQP_OK;
   if (a.nrn.kind == SNNQP_NEURON_LIF)
     SNNQP_REQUIRE(a.nrn.decay, SNNQP_EINVAL, "LIF neuron needs a decay vector");
@@ -221,7 +235,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
     SNNQP_REQUIRE(s_type == SNNQP_F32 || s_type == SNNQP_BITS, SNNQP_EINVAL,
                   "spike output type must be F32 or BITS");
     if (s_type == SNNQP_BITS && (g->Cout & 31) != 0) {
-      const int64_t words = (int64_t)T * B * a.OH * a.OW * ((g->Cout + 31) / 32);
+      const int64_t words = (int64_t)T * B * a.OD * a.OH * a.OW * ((g->Cout + 31) / 32);
       const int64_t zb = (words + 255) / 256;
       hipLaunchKernelGGL(zero_words_if_kernel, dim3((unsigned)(zb < 4096 ? zb : 4096)), dim3(256), 0, st,
                          pred, (uint32_t *)s_out, words);
@@ -235,7 +249,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
                   "fake-quantised float kernel for float32 input");
     SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
     // int32 accumulator cannot overflow: |acc| <= 255 * 127 * K
-    const int64_t kk = (int64_t)g->KH * g->KW * a.CinG;
+    const int64_t kk = (int64_t)a.KD * g->KH * g->KW * a.CinG;
     SNNQP_REQUIRE(kk * 255 * 127 < (1ll << 31), SNNQP_EUNSUPPORTED,
                   "contraction length %lld overflows int32", (long long)kk);
     return in_type == SNNQP_U8 ? launch_generic<SNNQP_U8, true>(a, pool, st)
@@ -287,4 +301,54 @@ extern "C" int snnqp_conv_forward_if(const int32_t *pred, const void *x, int in_
   const int64_t img = (int64_t)g->H * g->W * pix;
   return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr, nullptr, nullptr, y,
                      SNNQP_F32, nullptr, (hipStream_t)stream, 1, pred);
+}
+
+// ---- 3-D convolutions (flax_qconv.py:93-171 with three spatial axes) --------------------------
+namespace snnqp {
+static int split_geom3(const snnqp_conv3d_geom_t *g3, snnqp_conv_geom_t *g, GenericDepth *dz) {
+  SNNQP_REQUIRE(g3, SNNQP_EINVAL, "conv3d: null geometry");
+  SNNQP_REQUIRE(g3->D >= 0 && g3->KD > 0 && g3->stride[0] > 0 && g3->in_dil[0] > 0 && g3->k_dil[0] > 0 &&
+                    g3->pad_lo[0] >= 0 && g3->pad_hi[0] >= 0,
+                SNNQP_EINVAL, "conv3d: bad depth geometry");
+  g->H = g3->H; g->W = g3->W; g->Cin = g3->Cin; g->Cout = g3->Cout;
+  g->KH = g3->KH; g->KW = g3->KW;
+  g->stride_h = g3->stride[1]; g->stride_w = g3->stride[2];
+  g->pad_h_lo = g3->pad_lo[1]; g->pad_h_hi = g3->pad_hi[1];
+  g->pad_w_lo = g3->pad_lo[2]; g->pad_w_hi = g3->pad_hi[2];
+  g->in_dil_h = g3->in_dil[1]; g->in_dil_w = g3->in_dil[2];
+  g->k_dil_h = g3->k_dil[1]; g->k_dil_w = g3->k_dil[2];
+  g->groups = g3->groups;
+  dz->D = g3->D; dz->KD = g3->KD; dz->stride = g3->stride[0]; dz->pad_lo = g3->pad_lo[0];
+  dz->in_dil = g3->in_dil[0]; dz->k_dil = g3->k_dil[0];
+  const int64_t dd = g3->D > 0 ? (int64_t)(g3->D - 1) * g3->in_dil[0] + 1 : 0;
+  const int64_t kd = (int64_t)(g3->KD - 1) * g3->k_dil[0] + 1;
+  const int64_t td = dd + g3->pad_lo[0] + g3->pad_hi[0];
+  dz->OD = td < kd ? 0 : (int32_t)((td - kd) / g3->stride[0] + 1);
+  return SNNQP_OK;
+}
+}  // namespace snnqp
+
+extern "C" int snnqp_conv3d_out_shape(const snnqp_conv3d_geom_t *g3, int32_t *OD, int32_t *OH, int32_t *OW) {
+  using namespace snnqp;
+  SNNQP_REQUIRE(OD && OH && OW, SNNQP_EINVAL, "conv3d_out_shape: null argument");
+  snnqp_conv_geom_t g;
+  GenericDepth dz;
+  if (int rc = split_geom3(g3, &g, &dz)) return rc;
+  *OD = dz.OD;
+  return snnqp_conv_out_shape(&g, OH, OW);
+}
+
+extern "C" int snnqp_conv3d_lif_forward(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                                        int64_t x_stride_b, int32_t T, int32_t B,
+                                        const snnqp_conv3d_geom_t *g3, const snnqp_weight_t *w,
+                                        const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
+                                        float *u_out, void *s_out, int s_type, snnqp_stream_t stream) {
+  using namespace snnqp;
+  snnqp_conv_geom_t g;
+  GenericDepth dz;
+  if (int rc = split_geom3(g3, &g, &dz)) return rc;
+  SNNQP_REQUIRE(!nrn || (nrn->kind >= SNNQP_NEURON_NONE && nrn->kind <= SNNQP_NEURON_LIF), SNNQP_EINVAL,
+                "conv3d_lif_forward: unknown neuron kind %d", nrn ? nrn->kind : -1);
+  return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, &g, w, bn, nrn, u0, u_out, s_out, s_type,
+                     nullptr, (hipStream_t)stream, 1, pred, &dz);
 }

@@ -4,11 +4,16 @@
 
 namespace snnqp {
 
+// depth axis of a 3-D convolution for the direct-form kernel (OD resolved by the caller)
+struct GenericDepth {
+  int32_t D, KD, OD, stride, pad_lo, in_dil, k_dil;
+};
 int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t T,
                 int32_t B, const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                 const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                 float *u_out, void *s_out, int s_type, int32_t *acc_out,
-                hipStream_t st, int pool = 1, const int32_t *pred = nullptr);
+                hipStream_t st, int pool = 1, const int32_t *pred = nullptr,
+                const GenericDepth *dz = nullptr);
 
 // nullptr when the MFMA kernel can serve the request, else the reason.
 const char *conv3x3_mfma_unsupported(int in_type, const snnqp_conv_geom_t *g,

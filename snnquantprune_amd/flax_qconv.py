@@ -1,10 +1,10 @@
 """QuantConv -- host-side mirror of the reference's ``flax_qconv.py:46-188``.
 
-N-D (here 1-D and 2-D) convolution, NHWC inputs, HWIO `kernel`, string or
-explicit padding, strides, input / kernel dilation, feature groups; weights
-pass through the configured quantiser and the prune mask.  The arithmetic runs
+N-D (here 1-D, 2-D and 3-D) convolution, channels-last inputs, `kernel` with the spatial axes
+first (HWIO / DHWIO), string or explicit padding, strides, input / kernel dilation, feature groups;
+weights pass through the configured quantiser and the prune mask.  The arithmetic runs
 in libsnnqp (csrc/generic_block.hip; csrc/conv3x3_bits.hip / conv3x3_u8c2.hip when fused with the
-neuron in SpikingBlock).
+neuron in SpikingBlock; 3-D kernels on the direct-form kernel only: no shipped model has one).
 """
 
 from __future__ import annotations
@@ -66,8 +66,8 @@ class QuantConv(nn.Module):
     `spatial` (flax_qconv.py:114-144)."""
     ks = self._ksize()
     nsp = len(ks)
-    if nsp not in (1, 2):
-      raise NotImplementedError("QuantConv supports 1-D and 2-D convolutions")
+    if nsp not in (1, 2, 3):
+      raise NotImplementedError("QuantConv supports 1-D, 2-D and 3-D convolutions")
     if len(spatial) != nsp:
       raise ValueError("input has %d spatial dims, kernel has %d" % (len(spatial), nsp))
     strides = tuple(self.strides) if self.strides else (1,) * nsp
@@ -79,6 +79,10 @@ class QuantConv(nn.Module):
       pads = padtype_to_pads(spatial, ks, strides, self.padding)
     else:
       pads = [(int(lo), int(hi)) for lo, hi in self.padding]
+    if nsp == 3:
+      return ops.Conv3dGeom(spatial[0], spatial[1], spatial[2], in_features, self.features, ks[0], ks[1], ks[2],
+                            tuple(strides), tuple(tuple(p) for p in pads), tuple(in_dil), tuple(k_dil),
+                            self.feature_group_count)
     if nsp == 1:
       return ops.ConvGeom(1, spatial[0], in_features, self.features, 1, ks[0],
                           (1, strides[0]), ((0, 0), tuple(pads[0])),
@@ -99,6 +103,8 @@ class QuantConv(nn.Module):
     """Output shape for an input [B, spatial..., Cin] (no batch-less inputs)."""
     nsp = len(self._ksize())
     g = self.geometry(tuple(in_shape[-nsp - 1:-1]), in_shape[-1])
+    if nsp == 3:
+      return tuple(in_shape[:-nsp - 1]) + tuple(g.out_dhw()) + (self.features,)
     oh, ow = g.out_hw()
     sp = (ow,) if nsp == 1 else (oh, ow)
     return tuple(in_shape[:-nsp - 1]) + sp + (self.features,)
@@ -120,6 +126,13 @@ class QuantConv(nn.Module):
     if w is None:
       w = pk.float_weight()
     nb = x.shape[0]
+    if nsp == 3:
+      y = self._call3d(x, integer, g, w, pk)
+      if is_single:
+        y = y.squeeze(0)
+      if self.use_bias:
+        y = add_bias(y, quantized_bias(self, pk.kernel))
+      return y
     if isinstance(x, ops.PackedSpikes):
       x4 = x.reshape_leading(nb, g.H, g.W)
     else:
@@ -135,3 +148,11 @@ class QuantConv(nn.Module):
     if self.use_bias:
       y = add_bias(y, quantized_bias(self, pk.kernel))
     return y
+
+  def _call3d(self, x, integer, g, w, pk):
+    """[NB, D, H, W, Cin] -> float32 [NB, OD, OH, OW, Cout] on the direct-form kernel."""
+    if integer is packing.SPECULATE and w.is_int:     # float32 that may hold integers: decided on the device
+      x8, pred = ops.narrow_f32_async(x)
+      y = ops.conv3d_lif_forward(x8, g, w)
+      return ops.conv3d_lif_forward(x, g, pk.float_weight(), pred=pred, out=y)
+    return ops.conv3d_lif_forward(x, g, w)

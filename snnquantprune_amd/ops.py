@@ -354,6 +354,39 @@ class ConvGeom:
     return oh.value, ow.value
 
 
+@dataclass(frozen=True)
+class Conv3dGeom:
+  """Geometry of a 3-D QuantConv (snnqp_conv3d_geom_t): axis 0 = depth, 1 = height, 2 = width."""
+  D: int
+  H: int
+  W: int
+  Cin: int
+  Cout: int
+  KD: int
+  KH: int
+  KW: int
+  stride: Tuple[int, int, int] = (1, 1, 1)
+  pad: Tuple[Tuple[int, int], Tuple[int, int], Tuple[int, int]] = ((0, 0), (0, 0), (0, 0))
+  in_dil: Tuple[int, int, int] = (1, 1, 1)
+  k_dil: Tuple[int, int, int] = (1, 1, 1)
+  groups: int = 1
+
+  def struct(self) -> L.Conv3dGeomT:
+    i3 = ctypes.c_int32 * 3
+    return L.Conv3dGeomT(self.D, self.H, self.W, self.Cin, self.Cout, self.KD, self.KH, self.KW,
+                         i3(*self.stride), i3(*[p[0] for p in self.pad]), i3(*[p[1] for p in self.pad]),
+                         i3(*self.in_dil), i3(*self.k_dil), self.groups)
+
+  def tag(self) -> str:
+    return "%dx%dx%dx%d->%d" % (self.D, self.H, self.W, self.Cin, self.Cout)
+
+  def out_dhw(self) -> Tuple[int, int, int]:
+    od, oh, ow = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    g = self.struct()
+    L.check(L.lib().snnqp_conv3d_out_shape(ctypes.byref(g), ctypes.byref(od), ctypes.byref(oh), ctypes.byref(ow)))
+    return od.value, oh.value, ow.value
+
+
 def _in_desc(x):
   """(pointer tensor, in_type, words/elements per pixel-row unit)."""
   if isinstance(x, PackedSpikes):
@@ -628,6 +661,49 @@ def conv_forward(x, geom: ConvGeom, weight: Weight, want_acc: bool = False):
   L.check(L.lib().snnqp_conv_forward(_ptr(xt), in_type, NB, ctypes.byref(g),
                                      ctypes.byref(w), _ptr(y), _ptr(acc), _stream()))
   return (y, acc) if want_acc else y
+
+
+def conv3d_lif_forward(x, geom: Conv3dGeom, weight: Weight, neuron: Optional[Neuron] = None,
+                       bn: Optional[BnCoeffs] = None, u0: Optional[torch.Tensor] = None, want_u: bool = True,
+                       packed_out: bool = False, pred: Optional[torch.Tensor] = None, out=None):
+  """3-D QuantConv (snnqp_conv3d_lif_forward).  With a neuron: x [T, B, D, H, W, Cin] ->
+  (u_T [B, OD, OH, OW, Cout] | None, spikes [T, B, OD, OH, OW, Cout]); without: x [NB, D, H, W, Cin]
+  -> float32 currents [NB, OD, OH, OW, Cout].  pred / out: the predicated second launch of a
+  speculative pair writes into the outputs `out` of the first, only if *pred != 0."""
+  xt, in_type = _in_desc(x)
+  xt = xt.contiguous()
+  _require_gpu(xt, weight.w, u0)
+  OD, OH, OW = geom.out_dhw()
+  dev = xt.device
+  unit = geom.D * geom.H * geom.W * xt.shape[-1]
+  g, w = geom.struct(), weight.struct()
+  b = bn.struct() if bn is not None else None
+  if neuron is None:
+    NB = xt.shape[0]
+    y = out if out is not None else torch.empty((NB, OD, OH, OW, geom.Cout), dtype=torch.float32, device=dev)
+    with _timed("conv3d[%s]" % geom.tag()):
+      L.check(L.lib().snnqp_conv3d_lif_forward(_ptr(pred), _ptr(xt), in_type, 0, unit, 1, NB, ctypes.byref(g),
+                                               ctypes.byref(w), None, None, None, None, _ptr(y), L.F32, _stream()))
+    return y
+  T, B = xt.shape[0], xt.shape[1]
+  if out is not None:
+    u_out, s = out
+    s = s.bits if isinstance(s, PackedSpikes) else s
+  else:
+    u_out = torch.empty((B, OD, OH, OW, geom.Cout), dtype=torch.float32, device=dev) if want_u else None
+    oshape = (T, B, OD, OH, OW)
+    s = torch.empty(oshape + (((geom.Cout + 31) // 32,) if packed_out else (geom.Cout,)),
+                    dtype=torch.int32 if packed_out else torch.float32, device=dev)
+  if u0 is not None:
+    u0 = _f32c(u0)
+    assert tuple(u0.shape) == (B, OD, OH, OW, geom.Cout), (u0.shape, (B, OD, OH, OW, geom.Cout))
+  n = neuron.struct()
+  with _timed("conv3d[%s]" % geom.tag()):
+    L.check(L.lib().snnqp_conv3d_lif_forward(_ptr(pred), _ptr(xt), in_type, B * unit, unit, T, B, ctypes.byref(g),
+                                             ctypes.byref(w), ctypes.byref(b) if b is not None else None,
+                                             ctypes.byref(n), _ptr(u0), _ptr(u_out), _ptr(s),
+                                             L.BITS if packed_out else L.F32, _stream()))
+  return u_out, (PackedSpikes(s, geom.Cout) if packed_out else s)
 
 
 def conv_forward_speculative(x: torch.Tensor, geom: ConvGeom, int_weight: Weight, float_weight: Weight):

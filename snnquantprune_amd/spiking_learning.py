@@ -308,6 +308,8 @@ class SpikingBlock(nn.Module):
       if out is not None:
         return out
       inputs = inputs.to_dense()            # not a shape the gated form serves: float32 product
+    if isinstance(conn, QuantConv) and len(conn._ksize()) == 3:
+      return self._conv3d_block(u, inputs)
     flat = getattr(inputs, "flat_perm", None)
     x, integer = packing.prepare_input(inputs)
     spec = integer is packing.SPECULATE      # float32 that may hold integers: decided on the device
@@ -526,6 +528,41 @@ class SpikingBlock(nn.Module):
     else:
       s = torch.cat(ss, 1)
     return (None if us[0] is None else torch.cat(us, 0)), s
+
+  # -- 3-D convolution: the direct-form kernel with a depth axis -----------------------------------
+  def _conv3d_block(self, u, inputs):
+    """SpikingBlock(QuantConv with three spatial axes, [BatchNorm], neuron) on [T, B, D, H, W, C]
+    (flax_qconv.py:93-171 inside spiking_learning.py:446-462): one launch of the direct-form
+    kernel (snnqp_conv3d_lif_forward); float32 inputs speculate on the integer codes like every
+    other block (narrowing pass + predicated float32 launch into the same outputs)."""
+    conn, norm = self.connection_fn, self.norm_fn
+    if self.pool != 1:
+      raise ValueError("the fused 2x2 pool is 2-D")
+    if isinstance(inputs, (ops.PackedFrames, ops.GatedSpikes)):
+      raise ValueError("a 3-D QuantConv block takes tensors or PackedSpikes")
+    x, integer = packing.prepare_input(inputs)
+    if x.ndim != 6:
+      raise ValueError("QuantConv block expects [T, B, spatial..., C] inputs, got %s" % (x.shape,))
+    if self.batch_major_input:
+      x = ops.PackedSpikes(x.bits.transpose(0, 1).contiguous(), x.channels) if isinstance(x, ops.PackedSpikes) \
+          else x.transpose(0, 1).contiguous()
+    cin = x.shape[-1]
+    pk = conn.packed_kernel(cin)
+    geom = conn.geometry(tuple(x.shape[2:-1]), cin)
+    w = pk.int_weight() if integer else None
+    spec = integer is packing.SPECULATE and w is not None
+    if w is None:
+      w = pk.float_weight()
+    nrn = self.neural_dynamics.neuron(conn.features)
+    bn = norm.coeffs(conn.features) if norm is not None else None
+    u0 = None if (u is None or isinstance(u, ZeroCarry)) else u
+    packed_out = bool(integer) if self.packed is None else bool(self.packed)
+    if spec:
+      x8, pred = ops.narrow_f32_async(x)
+      out = ops.conv3d_lif_forward(x8, geom, w, nrn, bn=bn, u0=u0, want_u=self.return_state, packed_out=packed_out)
+      return ops.conv3d_lif_forward(x, geom, pk.float_weight(), nrn, bn=bn, u0=u0, want_u=self.return_state,
+                                    packed_out=packed_out, pred=pred, out=out)
+    return ops.conv3d_lif_forward(x, geom, w, nrn, bn=bn, u0=u0, want_u=self.return_state, packed_out=packed_out)
 
   def _gated_dense_block(self, u, x):
     """examples/tcja/models.py:97 -> :189-190 -> :200-216: QuantDense on the channel-major

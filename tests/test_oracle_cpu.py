@@ -146,6 +146,53 @@ def test_unsigned_quantisers_known_answers(oracle):
     assert oracle.parametric_d_init(data, bits, sign=False) == F32(F32(23) / np.sqrt(F32(2 ** bits - 1)))
 
 
+def test_oracle_3d_convolution_against_a_direct_loop(oracle):
+  """flax_qconv.py:93-171 with three spatial axes: the oracle's N-D im2col against a literal
+  seven-deep loop (stride, padding, both dilations, groups), and a 3-D kernel of depth 1 on a
+  depth-1 volume against the 2-D convolution it is."""
+  rng = np.random.Generator(np.random.PCG64(3303))
+  B, D, H, W, C, N, G = 2, 4, 5, 6, 4, 6, 2
+  KD, KH, KW = 2, 3, 2
+  strides, pads, ldil, rdil = (2, 1, 2), ((1, 0), (1, 2), (0, 1)), (1, 2, 1), (1, 1, 2)
+  x = rng.integers(0, 3, size=(B, D, H, W, C)).astype(F32)
+  kern = rng.standard_normal((KD, KH, KW, C // G, N)).astype(F32)
+  qw = oracle.QWeight(kern)
+  y = oracle.quant_conv(x, qw, strides=strides, padding=pads, input_dilation=ldil, kernel_dilation=rdil,
+                        feature_group_count=G, mode="fseq")
+  sp = tuple((d - 1) * l + 1 for d, l in zip((D, H, W), ldil))
+  xd = np.zeros((B,) + sp + (C,), F32)
+  xd[:, ::ldil[0], ::ldil[1], ::ldil[2]] = x
+  xp = np.pad(xd, ((0, 0),) + pads + ((0, 0),))
+  out = tuple((xp.shape[1 + i] - ((k - 1) * r + 1)) // s + 1
+              for i, (k, r, s) in enumerate(zip((KD, KH, KW), rdil, strides)))
+  assert y.shape == (B,) + out + (N,)
+  ref = np.zeros(y.shape, F32)
+  og, cg = N // G, C // G
+  for b in range(B):
+    for od in range(out[0]):
+      for oh in range(out[1]):
+        for ow in range(out[2]):
+          for o in range(N):
+            g = o // og
+            acc = F32(0)
+            for kd in range(KD):
+              for kh in range(KH):
+                for kw in range(KW):
+                  for c in range(cg):
+                    xv = xp[b, od * strides[0] + kd * rdil[0], oh * strides[1] + kh * rdil[1],
+                            ow * strides[2] + kw * rdil[2], g * cg + c]
+                    acc = F32(np.float64(xv) * np.float64(kern[kd, kh, kw, c, o]) + np.float64(acc))  # one rounding: fmaf
+            ref[b, od, oh, ow, o] = acc
+  np.testing.assert_array_equal(y, ref)
+  # depth 1 is the 2-D convolution
+  x2 = rng.integers(0, 2, size=(3, 7, 6, 4)).astype(F32)
+  k2 = rng.standard_normal((3, 3, 4, 5)).astype(F32)
+  y2 = oracle.quant_conv(x2, oracle.QWeight(k2), strides=(1, 2), padding="SAME", mode="fseq")
+  y3 = oracle.quant_conv(x2[:, None], oracle.QWeight(k2[None]), strides=(1, 1, 2),
+                         padding=((0, 0),) + oracle.resolve_padding((7, 6), (3, 3), (1, 2), "SAME"), mode="fseq")
+  np.testing.assert_array_equal(y3[:, 0], y2)
+
+
 def test_qdense_without_quant_is_plain_matmul(oracle):
   """flax_qdense_test.py:153-250: empty config == nn.Dense."""
   rng = np.random.Generator(np.random.PCG64(3))

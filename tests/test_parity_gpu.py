@@ -3497,3 +3497,79 @@ def test_connections_alone_on_float32_inputs(dev, oracle, monkeypatch):
     monkeypatch.setattr(torch.Tensor, "item", no_readback)
     monkeypatch.setattr(torch.Tensor, "tolist", no_readback)
   monkeypatch.undo()
+
+
+@pytest.mark.parametrize("case", ["same_stride2", "explicit_dilated_grouped", "valid_depth_only"])
+def test_quant_conv_3d(dev, oracle, case):
+  """QuantConv with three spatial axes (flax_qconv.py:93-171: lax.conv_general_dilated over
+  [B, D, H, W, C] with a DHWIO kernel) -- the connection alone in the `int` contract (uint8 counts,
+  packed spikes, integer-valued float32) and the `fseq` contract (real-valued float32, and the same
+  tensor with one non-integer: decided on the device), a batch-less input, then the whole
+  SpikingBlock (BatchNorm + neuron over T, u0 carried) against the oracle's conv_block."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import ops, packing, synthetic as syn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  from snnquantprune_amd.spiking_learning import SpikingBlock
+  rng = np.random.Generator(np.random.PCG64(len(case) * 97))
+  if case == "same_stride2":
+    D, H, W, C, N, ks = 5, 6, 7, 4, 40, (3, 3, 3)
+    kw = dict(strides=(2, 1, 2), padding="SAME")
+  elif case == "explicit_dilated_grouped":
+    D, H, W, C, N, ks = 4, 5, 6, 6, 64, (2, 3, 2)
+    kw = dict(strides=(1, 2, 1), padding=((1, 0), (1, 2), (0, 1)), input_dilation=(1, 2, 1),
+              kernel_dilation=(2, 1, 2), feature_group_count=2)
+  else:
+    D, H, W, C, N, ks = 6, 3, 3, 32, 33, (3, 1, 1)
+    kw = dict(padding="VALID")
+  G = kw.get("feature_group_count", 1)
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  leaf = syn.quant_leaf(ks + (C // G, N), 5.0, 77, True, 0.9)
+  qw = qweight_of(oracle, leaf, 4)
+  okw = dict(strides=kw.get("strides"), padding=kw["padding"], input_dilation=kw.get("input_dilation"),
+             kernel_dilation=kw.get("kernel_dilation"), feature_group_count=G)
+  m = QuantConv(N, ks, use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale, **kw)
+  v = nn.tree_from_numpy({"params": leaf}, dev)
+  B = 3
+  xi = rng.integers(0, 3, size=(B, D, H, W, C)).astype(np.uint8)
+  e_int = oracle.quant_conv(xi.astype(F32), qw, mode="int", **okw)
+  assert m.out_shape(xi.shape) == e_int.shape
+  np.testing.assert_array_equal(_np(m.apply(v, _t(xi, dev))), e_int)
+  np.testing.assert_array_equal(_np(m.apply(v, _t(xi.astype(F32), dev))), e_int)
+  np.testing.assert_array_equal(_np(m.apply(v, _t(xi[0].astype(F32), dev))), e_int[0])       # batch-less
+  xb = (xi > 1).astype(np.uint8)
+  np.testing.assert_array_equal(_np(m.apply(v, ops.pack_bits(_t(xb, dev)))),
+                                oracle.quant_conv(xb.astype(F32), qw, mode="int", **okw))
+  xr = rng.standard_normal((B, D, H, W, C)).astype(F32)
+  with packing.integer_inputs(False):
+    np.testing.assert_array_equal(_np(m.apply(v, _t(xr, dev))), oracle.quant_conv(xr, qw, mode="fseq", **okw))
+  xn = xi.astype(F32)
+  xn[1, 2, 1, 1, 0] = 0.25
+  np.testing.assert_array_equal(_np(m.apply(v, _t(xn, dev))), oracle.quant_conv(xn, qw, mode="fseq", **okw))
+  # the block
+  T = 4
+  bp, bs = syn.bn_leaf(N, True, 78)
+  bn = dict(mean=bs["mean"], var=bs["var"], scale=bp["scale"], bias=bp["bias"])
+  blk = SpikingBlock(connection_fn=QuantConv(N, ks, use_bias=False, config=cfg.quant, bits=4,
+                                             g_scale=cfg.quant.g_scale, **kw),
+                     neural_dynamics=cfg.neuron_dynamics(dtype=torch.float32),
+                     norm_fn=nn.BatchNorm(use_running_average=True, momentum=0.9, epsilon=1e-5), return_state=True)
+  variables = nn.tree_from_numpy({"params": {"connection_fn": leaf, "norm_fn": {"scale": bn["scale"], "bias": bn["bias"]}},
+                                  "batch_stats": {"norm_fn": {"mean": bn["mean"], "var": bn["var"]}}}, dev)
+  xs = rng.integers(0, 2, size=(T, B, D, H, W, C)).astype(np.uint8)
+  u0 = (rng.standard_normal(e_int.shape) * 0.3).astype(F32)
+  ckw = dict(padding=kw["padding"], strides=kw.get("strides"))
+  if G == 1 and "input_dilation" not in kw:
+    eu, es = oracle.conv_block(xs.astype(F32), qw, bn, None, "int", u0=u0, **ckw)
+    for xin in (_t(xs, dev), _t(xs.astype(F32), dev), ops.pack_bits(_t(xs, dev))):
+      u, sp = blk.apply(variables, _t(u0, dev), xin)
+      got = _np(sp) if not isinstance(sp, ops.PackedSpikes) else _np(sp.to_dense())
+      np.testing.assert_array_equal(got.astype(np.uint8), es.astype(np.uint8))
+      np.testing.assert_array_equal(_np(u), eu)
+    xf = xs.astype(F32)
+    xf[2, 1, 0, 1, 1, 0] = 1.5
+    eu, es = oracle.conv_block(xf, qw, bn, None, "fseq", u0=u0, **ckw)
+    u, sp = blk.apply(variables, _t(u0, dev), _t(xf, dev))
+    got = _np(sp) if not isinstance(sp, ops.PackedSpikes) else _np(sp.to_dense())
+    np.testing.assert_array_equal(got.astype(np.uint8), es.astype(np.uint8))
+    np.testing.assert_array_equal(_np(u), eu)
+  assert ops.device_status() == 0
