@@ -119,6 +119,13 @@ typedef struct {
                           with bound = abs_sum_max (bit-packed inputs);
                           lets the conv kernels run u + (x - u) / tau as one fused
                           multiply-add when that is provably bit-identical.  0 = unknown */
+  int32_t ch_stack_max; /* W_I8, the 2-channel event layer, 0 = unknown: with range(c) = the sum of
+                          |code| of output channel c, the largest sum of the ranges of the four
+                          channels 128 g + 32 w + n, w = 0..3 (over g and n < 32).  Sizes the
+                          per-channel dequantisation tables (a channel's table covers its own
+                          accumulator range; the four channels of an LDS bank are stacked);
+                          unknown: 8 x abs_sum_max.  A value below the codes' is reported
+                          (SNNQP_STATUS_BOUND) */
 } snnqp_weight_t;
 
 /* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),
@@ -182,9 +189,9 @@ typedef struct {
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
  * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if,
- * snnqp_conv3d_*).  A binding compares snnqp_version()
+ * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
-#define SNNQP_VERSION 500
+#define SNNQP_VERSION 501
 int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build

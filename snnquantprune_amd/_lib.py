@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
 
 # include/snnqp.h SNNQP_VERSION the prototypes below were written against
-ABI_VERSION = 500
+ABI_VERSION = 501
 
 # enums of include/snnqp.h
 F32, U8, BITS, EV1, EV4 = 0, 1, 2, 3, 4
@@ -33,7 +33,7 @@ STATUS_QUEUE_CORRUPT, STATUS_TICKET, STATUS_BOUND = 1, 2, 4
 class WeightT(Structure):
   _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
               ("abs_sum_max", c_int32), ("code_max", c_int32), ("col_sum", c_void_p),
-              ("wt_fp6", c_void_p), ("min_current_bits", c_uint32)]
+              ("wt_fp6", c_void_p), ("min_current_bits", c_uint32), ("ch_stack_max", c_int32)]
 
 
 BN_MEAN_ZERO, BN_BIAS_ZERO = 1, 2

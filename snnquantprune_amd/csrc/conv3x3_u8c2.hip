@@ -61,9 +61,8 @@ typedef int v2i_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((address_space(3))) const v2i_a4 lds_cv2i_t;
 
 // LDS bytes of the u8c2 kernel: images | table | spike words
-__host__ __device__ inline int u8c2_table_bytes(int lutm, int bound) {
-  const int b = lutm == LUT_CHANNEL ? 128 * lut_channel_rows(bound) * 4
-                : lutm == LUT_SHARED ? (2 * bound + 2) * 4 : 0;
+__host__ __device__ inline int u8c2_table_bytes(int lutm, int bound, int rows) {
+  const int b = lutm == LUT_CHANNEL ? rows * 128 : lutm == LUT_SHARED ? (2 * bound + 2) * 4 : 0;
   return (b + 15) & ~15;
 }
 
@@ -85,7 +84,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tc = a.tchunk;                       // <= TCHUNK
   const int lut_off = tc * HIMG2;
-  uint32_t *obuf = (uint32_t *)(lds + lut_off + u8c2_table_bytes(LUTM, a.lut_bound));
+  uint32_t *obuf = (uint32_t *)(lds + lut_off + u8c2_table_bytes(LUTM, a.lut_bound, a.lut_rows));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
@@ -121,10 +120,44 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
                                      blockIdx.y * 128, a.Cout, tid, 256));
     }
   }
+  int ch_row0 = 0;                  // LUT_CHANNEL: the table row of this lane's entry of acc = 0
   if (LUTM == LUT_CHANNEL) {
-    const uint32_t mb = build_lut_channel((float *)(lds + lut_off), a.lut_bound, a.dq, a.bn,
+    // what this lane's channel can accumulate: the sums of its positive and |negative| codes
+    // (the lane halves hold k 0..15 and 16..23 of the same channel), times the largest input
+    int pos = 0, neg = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = 16 * h + j, dy = k >> 3, b = k & 7;
+      if (k < 24 && b < 6 && wave_on && cout < a.Cout) {      // (a wave beyond Cout: one row per lane)
+        const int code = a.w[(int64_t)(6 * dy + b) * a.Cout + cout];
+        pos += code > 0 ? code : 0;
+        neg += code < 0 ? -code : 0;
+      }
+    }
+    pos += __shfl_xor(pos, 32);
+    neg += __shfl_xor(neg, 32);
+    uint32_t *scr = obuf;            // (the spike-word ring is not in use before the first patch)
+    if (h == 0) {
+      scr[wave * 32 + n] = (uint32_t)((pos + neg) * a.x_limit + 1);
+      scr[128 + wave * 32 + n] = (uint32_t)(neg * a.x_limit);
+    }
+    lds_barrier();
+    int start = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int r = (int)scr[w2 * 32 + n];
+      start += w2 < wave ? r : 0;
+      total += r;
+    }
+    ch_row0 = start + neg * a.x_limit;
+    // a column taller than the launch reserved: snnqp_weight_t.ch_stack_max is below the codes it
+    // came with.  Its entries are not written (reads beyond the allocation return zeros): wrong
+    // currents, reported -- the next call fails until the status is reset (snnqp.h).
+    if (total > a.lut_rows && a.status) *(volatile uint32_t *)a.status = SNNQP_STATUS_BOUND;
+    const uint32_t mb = build_lut_channel((float *)(lds + lut_off), scr, a.lut_rows, a.dq, a.bn,
                                           blockIdx.y * 128, a.Cout, tid);
     atomicMin(wgw, mb);
+    lds_barrier();                   // the scratch becomes the spike-word ring again
   }
   if (tid < tc) {
     *(uint32_t *)(lds + tid * HIMG2 + HCONST2) = 0x7F7F7F7Fu;
@@ -142,9 +175,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   {
     int bias = 0;
     if (LUTM == LUT_SHARED) bias = (int)lds_addr(lds) + lut_off + 4 * a.lut_bound;
-    if (LUTM == LUT_CHANNEL)     // the wave's block, row of acc = 0, this lane's channel
-      bias = (int)lds_addr(lds) + lut_off +
-             4 * ((wave * lut_channel_rows(a.lut_bound) + a.lut_bound) * 32 + n);
+    if (LUTM == LUT_CHANNEL)     // row of acc = 0 of this lane's channel, column n
+      bias = (int)lds_addr(lds) + lut_off + 4 * (ch_row0 * 32 + n);
     int q = bias / 127;
     const int r = bias - 127 * q;
     int wsum = 0;
@@ -755,11 +787,15 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   // images | table | spike-word ring | 4 workgroup words | EV1: byte -> 8-byte table
   const size_t lds_fixed = (size_t)a.tchunk * HIMG2 + 16 + (ev1 ? 2048 : 0) +
                            (pl ? OutStage<true>::BYTES : OutStage<false>::BYTES);
-  // per-channel tables (BatchNorm folded in) while the workgroup stays within 64 KiB of LDS
-  // (there the accumulator counts table rows of 128 B: A = 16 x input, B = 8 x code)
-  const bool lutc = lut && in_type != SNNQP_BITS && bound <= LUT2_CAP && xm <= 7 &&
-                    w->code_max > 0 && w->code_max <= 15 &&
-                    lds_fixed + u8c2_table_bytes(LUT_CHANNEL, (int)bound) <= 65536;
+  // per-channel tables (BatchNorm folded in; the accumulator counts table rows of 128 B: A = 16 x
+  // input, B = 8 x code), every channel over its own accumulator range, stacked per LDS bank
+  // (conv_tile.h build_lut_channel): ch_stack_max x the largest input + 4 rows -- 8 x abs_sum_max
+  // bounds it when the caller does not know
+  const int64_t stack = w->ch_stack_max > 0 ? (int64_t)w->ch_stack_max : 8 * (int64_t)w->abs_sum_max;
+  const int64_t crows = stack * xm + 4;
+  const bool lutc = lut && in_type != SNNQP_BITS && crows <= LUT2_ROWS && xm <= 7 &&
+                    w->code_max > 0 && w->code_max <= 15;
+  a.lut_rows = lutc ? (int32_t)crows : 0;
 #define SNNQP_CONV_LAUNCH_IN(KERN, NFV, PL, LM, LDS)                               \
   do {                                                                             \
     if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
@@ -811,7 +847,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
     // works (the staging loops test every timestep against it), so the chunk is the largest
     // that fits: at T = 20 all of it in ONE pass (5.35 ms against 5.57 for 16 + 4: a staging
     // phase, a flush and three barriers fewer per patch), at T = 50 20 + 20 + 10.
-    const size_t lds_rest = lds_fixed - (size_t)a.tchunk * HIMG2 + u8c2_table_bytes(lm, a.lut_bound);
+    const size_t lds_rest = lds_fixed - (size_t)a.tchunk * HIMG2 + u8c2_table_bytes(lm, a.lut_bound, a.lut_rows);
     for (int wgs = 4; wgs >= 2; --wgs) {
       const size_t per_wg = (size_t)(160 * 1024) / wgs - 512;
       int tc = a.tchunk;

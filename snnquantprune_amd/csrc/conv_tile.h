@@ -35,20 +35,18 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
 // of acc = 0, so ds_read_b32 takes the MFMA result as is (no index arithmetic).
 //   LUT_SHARED : one table, entry = fl(fl(acc / L) * m), |acc| <= LUT_CAP
 //   LUT_CHANNEL: one table per output channel with BatchNorm applied to the entry
-//                as well (conv0: |acc| <= LUT2_CAP), so the epilogue starts at the
-//                membrane update
+//                as well (conv0: each channel over its own accumulator range), so the
+//                epilogue starts at the membrane update
 enum { LUT_NONE = 0, LUT_SHARED = 1, LUT_CHANNEL = 2 };
 // 4095: a 32 KiB table.  conv0 on event counts with 8-bit codes (|acc| <= sum|w| * x_max, a few
 // thousand) then still dequantises by table and keeps three workgroups per CU; in the bits
 // kernel the entry of acc = 0 stays an instruction immediate (< 64 KiB from the LDS base).
 constexpr int LUT_CAP = 4095;
-constexpr int LUT2_CAP = 40;
+// LUT_CHANNEL: at most 32 KiB of tables -- three workgroups per CU still fit; taller tables cost
+// an occupancy step that the shared table does not (headline layer, count frames, hint 3 / 229 rows:
+// 6.68 ms; hint 4 / 304 rows at two workgroups per CU: 8.58; shared table: 7.03)
+constexpr int LUT2_ROWS = 256;
 constexpr int LUT_XMAX = 31;                    // 4 * x must stay an int8
-template <int LUTM>
-struct LutBytes {
-  static constexpr int value = LUTM == LUT_CHANNEL ? 128 * (2 * LUT2_CAP + 1) * 4
-                               : LUTM == LUT_SHARED ? (2 * LUT_CAP + 2) * 4 : 0;
-};
 
 constexpr int HALO = 10;
 // LDS image of one timestep's halo for the int8 kernels: four planes (the 32-channel
@@ -76,6 +74,7 @@ struct ConvMfmaArgs {
   int32_t tiles_y, tiles_x;
   int64_t npatch;
   int32_t lut_bound;  // > 0: |acc| <= lut_bound while inputs <= x_limit, dequant by LDS table
+  int32_t lut_rows;   // u8c2 kernel, LUT_CHANNEL: rows (of 32 entries) the launch reserved for the tables
   int32_t x_limit;    // u8c2 kernel: largest input value the table mode is sized for
   int32_t *x_seen;    // u8c2 kernel: (nullable) atomically max-ed with the largest input seen
   int32_t *x_flags;   // u8c2 kernel, float32 frames: OR-ed with SNNQP_FLAG_NOT_INTEGER (snnqp.h)
@@ -260,20 +259,29 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
 // accumulator is: the table reads of a wave never conflict (the channel-major order
 // [channel][acc] lost half of its LDS cycles to conflicts of the lanes with acc != 0).
 // The accumulator must then count 128 B per unit: A carries 16 x input, B 8 x code.
-__host__ __device__ inline int lut_channel_rows(int bound) { return 2 * bound + 1; }
+// LUT_CHANNEL tables (conv3x3_u8c2.hip): channel c = 32 w + n of the workgroup's 128 keeps the
+// entries of acc = -neg_c x_limit .. +pos_c x_limit (pos_c / neg_c = the sums of its positive /
+// |negative| codes: what its accumulator can reach with inputs 0 .. x_limit) in column n of a
+// table of 128-byte rows, below the tables of the channels n, 32 + n, .. of the waves before it:
+// lane n reads bank n whatever its accumulator is, and the table is as tall as the tallest
+// column -- not four times the widest channel's symmetric range.
+//   scr[0..127]   rows of channel c      scr[128..255]  neg_c x_limit (the row of acc = 0)
 // Returns the bits of the smallest non-zero |entry| this thread wrote (+inf if none).
-__device__ __forceinline__ uint32_t build_lut_channel(float *lut, int bound, const Dequant &dq,
-                                                      const BnP &bn, int cout0, int Cout,
-                                                      int tid) {
-  const int rows = lut_channel_rows(bound);
+__device__ __forceinline__ uint32_t build_lut_channel(float *lut, const uint32_t *scr, int max_rows,
+                                                      const Dequant &dq, const BnP &bn, int cout0,
+                                                      int Cout, int tid) {
   uint32_t minbits = 0x7F800000u;
-  for (int i = tid; i < 128 * rows; i += 256) {
-    const int wv = i / (rows * 32), rem = i - wv * rows * 32;
-    const int v = (rem >> 5) - bound, c = wv * 32 + (rem & 31);
-    const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
-    float y = dequant_acc_nb(v, dq);
-    y = bn.mean ? bn_apply(y, bn.mean[co], bn.mul[co], bn.bias[co]) : bn_apply(y, 0.f, 1.f, 0.f);
-    lut[i] = y;
+  const int c = tid & 127, hf = tid >> 7, cw = c >> 5, cn = c & 31;
+  int st = 0;
+  for (int w2 = 0; w2 < cw; ++w2) st += (int)scr[w2 * 32 + cn];
+  const int rows = (int)scr[c], negx = (int)scr[128 + c];
+  if (st + rows > max_rows) return minbits;                    // (reported by the caller)
+  const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
+  float bm = 0.f, bmul = 1.f, bb = 0.f;
+  if (bn.mean) { bm = bn.mean[co]; bmul = bn.mul[co]; bb = bn.bias[co]; }
+  for (int i = hf; i < rows; i += 2) {
+    const float y = bn_apply(dequant_acc_nb(i - negx, dq), bm, bmul, bb);
+    lut[(st + i) * 32 + cn] = y;
     const uint32_t mag = __float_as_uint(y) & 0x7FFFFFFFu;
     if (mag != 0u && mag < minbits) minbits = mag;
   }

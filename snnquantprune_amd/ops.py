@@ -278,6 +278,7 @@ class Weight:
   min_current_bits: int = 0  # smallest non-zero |BN(dequant(acc))| as float bits (current_min)
   col_sum: Optional[torch.Tensor] = None   # dense: int32 [N] column sums of the codes (uint8 input)
   wt6: Optional[torch.Tensor] = None       # dense, code_max <= 7: fp6 MFMA tiles (pack_codes_fp6)
+  ch_stack_max: int = 0     # event layer: largest stacked per-channel code range (snnqp.h), 0 = unknown
 
   def struct(self) -> L.WeightT:
     # (built once per object: a Weight is not modified after the pack step made it --
@@ -288,7 +289,7 @@ class Weight:
                      int(self.abs_sum_max), int(self.code_max),
                      None if self.col_sum is None else self.col_sum.data_ptr(),
                      None if self.wt6 is None else self.wt6.data_ptr(),
-                     int(self.min_current_bits))
+                     int(self.min_current_bits), int(self.ch_stack_max))
       self.__dict__["_cstruct"] = st
     return st
 

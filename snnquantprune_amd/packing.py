@@ -87,11 +87,17 @@ class PackedKernel:
     # accumulator lies in [-sum of |negative codes|, +sum of positive codes] * x_max: the
     # larger one-sided sum over the outputs bounds |acc| (about half of sum |code|)
     side = torch.maximum(c2.clamp(min=0).sum(0).max(), (-c2).clamp(min=0).sum(0).max())
-    stats = torch.stack([side, c2.abs().max()]).tolist()             # one readback
+    # the event layer's per-channel tables (snnqp.h ch_stack_max): the ranges sum |code| of the
+    # four channels that share an LDS bank (128 g + 32 w + n), the largest such sum
+    rng = c2.abs().sum(0)
+    n128 = (rng.numel() + 127) // 128 * 128
+    stack = torch.nn.functional.pad(rng, (0, n128 - rng.numel())).reshape(-1, 4, 32).sum(1).max()
+    stats = torch.stack([side, c2.abs().max(), stack]).tolist()      # one readback
     # dense kernels: column sums of the codes, for uint8 rows read as x - 128 (snnqp.h col_sum)
     col = c2.sum(0).to(torch.int32).contiguous() if self.kernel.ndim == 2 else None
     self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=int(stats[0]),
-                           code_max=int(stats[1]), col_sum=col)
+                           code_max=int(stats[1]), col_sum=col,
+                           ch_stack_max=int(stats[2]) if self.kernel.ndim == 4 and self.kernel.shape[2] == 2 else 0)
     return self._int
 
   def gated_codes(self):
@@ -170,7 +176,7 @@ class PackedKernel:
       if self.kernel.ndim == 2 and 0 < base.code_max <= 7:
         wt6 = ops.pack_codes_fp6(codes, n_pad)
       w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max,
-                     code_max=base.code_max, col_sum=base.col_sum, wt6=wt6)
+                     code_max=base.code_max, col_sum=base.col_sum, wt6=wt6, ch_stack_max=base.ch_stack_max)
       self._wt[key] = w
     return w
 

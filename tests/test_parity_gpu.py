@@ -3573,3 +3573,37 @@ def test_quant_conv_3d(dev, oracle, case):
     np.testing.assert_array_equal(got.astype(np.uint8), es.astype(np.uint8))
     np.testing.assert_array_equal(_np(u), eu)
   assert ops.device_status() == 0
+
+
+def test_per_channel_tables_cover_count_frames_and_report_a_short_stack(dev, oracle):
+  """conv0's per-channel dequantisation tables (BatchNorm folded in) hold every channel over its OWN
+  accumulator range, the four channels of an LDS bank stacked (snnqp_weight_t.ch_stack_max): event
+  COUNTS up to 7 with 4-bit codes stay on them (round 4: binary frames only; counts went to the
+  shared table and a separate BatchNorm).  Bit-exact against the oracle for hints 1..7 on count
+  frames, with the caller's stack bound, without one (0: 8 x abs_sum_max) and -- understated -- the
+  report through the device status word."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=7, B=3, hw=16, cin=2, seed=977, gain=4.0)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  assert w.ch_stack_max > 0 and w.code_max <= 7
+  bn, nrn = _bn(c["bn"], dev), _mslif()
+  g = ops.ConvGeom(16, 16, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  rng = np.random.Generator(np.random.PCG64(6))
+  for xmax in (1, 2, 4, 7):
+    x = np.minimum(rng.poisson(0.5, (7, 3, 16, 16, 2)), xmax).astype(np.uint8)
+    x[0, 0, 0, 0, 0] = xmax
+    e = cases.conv_block_expected(oracle, dict(c, x=x))
+    for wv in (w, dataclasses.replace(w, ch_stack_max=0)):
+      for pool in (1, 2):
+        u, s = ops.conv_lif_forward(_t(x, dev), g, wv, nrn, bn=bn, want_u=True, packed_out=True,
+                                    pool=pool, impl=L.IMPL_MFMA, x_max=xmax)
+        np.testing.assert_array_equal(_np(s), e["pooled_bits"] if pool == 2 else e["s_bits"], err_msg="x_max %d" % xmax)
+        np.testing.assert_array_equal(_np(u), e["u"])
+  assert ops.device_status() == 0
+  bad = dataclasses.replace(w, ch_stack_max=max(1, w.ch_stack_max // 3))
+  ops.conv_lif_forward(_t(x, dev), g, bad, nrn, bn=bn, want_u=False, packed_out=True, pool=2,
+                       impl=L.IMPL_MFMA, x_max=7)
+  torch.cuda.synchronize()
+  assert ops.device_status(reset=True) == L.STATUS_BOUND

@@ -14,7 +14,7 @@ a, c = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
 pk = packing.PackedKernel(torch.from_numpy(leaf["kernel"]).to(dev), QuantDesc(L.Q_DUQ, 4, a, c, 7.0, c),
                           torch.from_numpy(leaf["prune_0"]["mask"]).to(dev))
 w = pk.int_weight_mfma(128)
-print("abs_sum_max", w.abs_sum_max, "code_max", w.code_max)
+print("abs_sum_max", w.abs_sum_max, "code_max", w.code_max, "ch_stack_max", w.ch_stack_max)
 from tests.helpers import bn_of
 bn = bn_of(v, 0)
 mul = (np.float32(1) / np.sqrt(bn["var"] + np.float32(1e-5))) * bn["scale"]
@@ -41,6 +41,6 @@ def run(x, hint, n=5):
   b.record(); torch.cuda.synchronize()
   return a.elapsed_time(b) / n, (seen.cpu().numpy() // n).tolist()
 for name, x in (("binary", binary), ("counts", counts)):
-  for hint in (1, 2, 3, 7, 15):
+  for hint in (1, 2, 3, 4, 5, 7, 15):
     ms, st = run(x, hint)
     print("%-7s hint %2d: %.3f ms   images by max (<=1, 2, <=7, <=31, >31): %s" % (name, hint, ms, st[1:6]))
