@@ -2,7 +2,7 @@
 // scan at :446-462) and eval-mode BatchNorm (models.py:101-107).  Used when a
 // SpikingBlock's connection is not one of the fused kinds.  HBM-bound: each
 // current is read once, each spike written once, u stays in a register.
-#include "common.h"
+#include "kernels.h"
 
 namespace snnqp {
 
@@ -79,7 +79,8 @@ int snnqp_lif_forward(const float *x, int32_t T, int64_t R, int32_t C,
   if (n == 0 || T == 0) return SNNQP_OK;
   hipStream_t st = (hipStream_t)stream;
   if (s_type == SNNQP_BITS && (C & 31) != 0)
-    SNNQP_HIP(hipMemsetAsync(s_out, 0, (int64_t)T * R * ((C + 31) / 32) * 4, st));
+    // (a kernel of the library, not a memset node: kernels.h zero_words_async)
+    if (int rc = zero_words_async((uint32_t *)s_out, (int64_t)T * R * ((C + 31) / 32), st)) return rc;
   const int64_t blocks = ceil_div64(n, 256);
   SNNQP_REQUIRE(blocks < (1ll << 31), SNNQP_EINVAL, "lif_forward: grid too large");
   hipLaunchKernelGGL(lif_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x,

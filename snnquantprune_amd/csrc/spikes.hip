@@ -1,7 +1,7 @@
 // Activation-format helpers and the small element-wise ops around the blocks:
 // float32 <-> u8 / bit-packed spikes, 2x2 max-pool (models.py:145-147), rate
 // vote (models.py:253-255).  All HBM-bound single-pass kernels.
-#include "common.h"
+#include "kernels.h"
 
 namespace snnqp {
 
@@ -509,7 +509,7 @@ int snnqp_events_to_frames(const int32_t *ex, const int32_t *ey, const int32_t *
   SNNQP_REQUIRE(counts, SNNQP_EINVAL, "events_to_frames: null counts buffer");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)T * H * W * 2;
-  SNNQP_HIP(hipMemsetAsync(counts, 0, n * 4, st));
+  if (int rc = zero_words_async((uint32_t *)counts, n, st)) return rc;
   if (N > 0) {
     SNNQP_REQUIRE(ex && ey && ep, SNNQP_EINVAL, "events_to_frames: null events");
     hipLaunchKernelGGL(events_to_frames_kernel, dim3(grid_for(N)), dim3(256), 0, st, ex, ey,
@@ -532,7 +532,7 @@ int snnqp_density(const void *x, int type, int64_t NB, int64_t n, int32_t C, int
   if (NB == 0) return SNNQP_OK;
   SNNQP_REQUIRE(x && nnz, SNNQP_EINVAL, "density: null argument");
   hipStream_t st = (hipStream_t)stream;
-  SNNQP_HIP(hipMemsetAsync(nnz, 0, NB * 4, st));
+  if (int rc = zero_words_async((uint32_t *)nnz, NB, st)) return rc;
   const int64_t units = type == SNNQP_BITS ? (n / C) * ((C + 31) / 32) : n;
   if (type == SNNQP_BITS)
     hipLaunchKernelGGL(density_kernel<SNNQP_BITS>, dim3(grid_for(NB * units)), dim3(256), 0, st, x,

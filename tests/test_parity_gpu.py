@@ -3607,3 +3607,33 @@ def test_per_channel_tables_cover_count_frames_and_report_a_short_stack(dev, ora
                        impl=L.IMPL_MFMA, x_max=7)
   torch.cuda.synchronize()
   assert ops.device_status(reset=True) == L.STATUS_BOUND
+
+
+def test_scan_with_a_ragged_feature_count_replays_in_a_graph(dev, oracle):
+  """snnqp_lif_forward assembles a packed raster whose feature count is no multiple of 32 with
+  atomicOr into zeroed words; the zeroing is a kernel of the library (a kernel node under capture,
+  kernels.h zero_words_async), so a captured scan starts from zeros at every replay."""
+  from snnquantprune_amd import ops
+  rng = np.random.Generator(np.random.PCG64(909))
+  T, R, C = 6, 9, 40
+  xs = torch.zeros((T, R, C), dtype=torch.float32, device=dev)
+  nrn = _mslif()
+  side = torch.cuda.Stream(device=dev)
+  with torch.cuda.stream(side):
+    ops.lif_forward(xs, nrn, want_u=True, packed_out=True)            # warm up outside the capture
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    u_g, s_g = ops.lif_forward(xs, nrn, want_u=True, packed_out=True)
+  for k in range(4):
+    x = (rng.standard_normal((T, R, C)) * 1.5).astype(F32)
+    xs.copy_(_t(x, dev))
+    g.replay()
+    torch.cuda.synchronize()
+    u = np.zeros((R, C), F32)
+    es = []
+    for t in range(T):
+      u, sp = oracle.multi_step_lif(u, x[t])
+      es.append(sp)
+    np.testing.assert_array_equal(_np(s_g), packbits_lastaxis(np.stack(es)), err_msg="replay %d" % k)
+    np.testing.assert_array_equal(_np(u_g), u)
