@@ -377,8 +377,9 @@ int snnqp_dense_gated_forward(const uint32_t *s, const float *gate, int64_t NB, 
  *       to 255, arithmetic dequantisation) for a chunk that exceeds it -- same results, slower.
  * x_seen nullable, EIGHT device words the caller zeroes: [0] is atomically max-ed with the
  *       largest U8 input value the launch met, [1..5] receive the number of staged chunks (a
- *       patch x up to 32 timesteps) whose largest value was <= 1, 2, <= 7, <= 31, above; [6..7]
- *       are reserved.  From these the caller refines its next hint asynchronously -- a hint
+ *       patch x up to 32 timesteps) whose largest value was <= 1, 2, <= 7, <= 31, above; [6] the
+ *       number of those whose largest value was exactly 3 (part of [3]: the per-channel tables
+ *       reach a hint of 3 on typical pruned layers, not 7); [7] is reserved.  From these the caller refines its next hint asynchronously -- a hint
  *       that covers MOST chunks is the fast one: a hot pixel then costs its own few chunks the
  *       general path instead of the whole batch the slower tables.  Nothing ever waits for it.
  * FLOAT32 INPUT INTO INTEGER CODES (the reference casts every input to float32, flax_qconv.py:101,

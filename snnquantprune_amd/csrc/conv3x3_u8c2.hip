@@ -237,7 +237,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   uint32_t seen = 0;                       // largest input value this thread's waves met
   // staged chunks by their largest value: <= 1, <= 2, <= 7, <= 31, above (workgroup-uniform
   // counters; they reach x_seen[1..5] once, at the end of the launch)
-  uint32_t hist[5] = {0, 0, 0, 0, 0};
+  uint32_t hist[6] = {0, 0, 0, 0, 0, 0};
   // staging tasks: waves 0-1 take the even timesteps of a chunk, waves 2-3 the odd ones; the
   // first 100 threads of each pair take one halo pixel each.  The timestep is uniform over a
   // wave, so a load is a scalar frame address plus this thread's 32-bit pixel offset.
@@ -398,6 +398,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
       hist[2] += cmax > 2u && cmax <= 7u;
       hist[3] += cmax > 7u && cmax <= 31u;
       hist[4] += cmax > 31u;
+      hist[5] += cmax == 3u;
       general = LUTM == LUT_NONE || cmax > (uint32_t)a.x_limit;
       if (LUTM != LUT_NONE && general) {
         // the rare chunk: its values again (an L2 hit; nothing was kept in registers for it)
@@ -484,7 +485,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   if (a.x_seen && tid == 0) {
     if (seen != 0) atomicMax(a.x_seen, seen);
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
       if (hist[k] != 0) atomicAdd((uint32_t *)a.x_seen + 1 + k, hist[k]);
   }
   if (pw.queue && tid == 0) pw.finish(processed, a.npatch, a.status);

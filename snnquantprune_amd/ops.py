@@ -492,7 +492,7 @@ class CountHint:
   its staged chunks will hold on this device (1 = binary frames).  The kernel never trusts it
   -- it checks every chunk of input it stages and falls back per chunk (snnqp.h, x_max) -- and
   reports into `word` (eight int32 words: the largest value it saw and the number of chunks by
-  their largest value, <= 1, 2, <= 7, <= 31, above); the words are copied back with a
+  their largest value, <= 1, 2, <= 7, <= 31, above, exactly 3); the words are copied back with a
   non-blocking copy and looked at on a later call, when the copy has long finished, so the host
   never waits for the device to learn about its input.
 
@@ -502,9 +502,12 @@ class CountHint:
   few chunks that hold it, not the batch (a hint that followed the maximum would put every
   chunk on the slowest path)."""
 
-  BOUNDS = (1, 2, 7, 31)                    # the buckets' upper bounds; above 31: no table
-  COST = (1.0, 1.15, 1.25, 1.25)            # relative time of a chunk in the table mode of a bound
-  GENERAL = 2.3                             # ... and on the general path (x - 128, arithmetic)
+  BOUNDS = (1, 2, 3, 7, 31)                 # the buckets' upper bounds; above 31: no table
+  # relative time of a chunk in the table mode of a bound (headline layer, tools/conv0_hint_time.py:
+  # per-channel tables 5.90 / 5.82 ms, at three workgroups per CU 6.61, shared table 7.03) and on the
+  # general path (x - 128, arithmetic: 10.9)
+  COST = (1.0, 1.0, 1.12, 1.19, 1.19)
+  GENERAL = 1.85
 
   def __init__(self, device):
     self.value = 1
@@ -522,8 +525,11 @@ class CountHint:
     return torch.cuda.is_current_stream_capturing()
 
   @classmethod
-  def choose(cls, hist) -> int:
-    """hist = chunks with largest value <= 1, 2, <= 7, <= 31, above -> the hint."""
+  def choose(cls, words) -> int:
+    """words = x_seen[1..6]: chunks with largest value <= 1, 2, <= 7, <= 31, above, and (part of
+    the third) exactly 3 -> the hint."""
+    w = list(words) + [0] * (6 - len(words))
+    hist = [w[0], w[1], w[5], w[2] - w[5], w[3], w[4]]           # <= 1, 2, 3, 4..7, <= 31, above
     total = sum(hist)
     if total == 0:
       return 1
@@ -546,7 +552,7 @@ class CountHint:
       if sum(words[1:6]) > 0:
         # (never above what was seen: the tables are sized by abs_sum_max * hint, and a bucket
         # bound of 7 where the data stops at 4 can push 8-bit codes past the table's capacity)
-        self.value = max(1, min(self.choose(words[1:6]), self.max_seen))
+        self.value = max(1, min(self.choose(words[1:7]), self.max_seen))
     return self.value
 
   def seen_word(self):
