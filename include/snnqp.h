@@ -121,11 +121,19 @@ typedef struct {
                           multiply-add when that is provably bit-identical.  0 = unknown */
   int32_t ch_stack_max; /* W_I8, the 2-channel event layer, 0 = unknown: with range(c) = the sum of
                           |code| of output channel c, the largest sum of the ranges of the four
-                          channels 128 g + 32 w + n, w = 0..3 (over g and n < 32).  Sizes the
-                          per-channel dequantisation tables (a channel's table covers its own
-                          accumulator range; the four channels of an LDS bank are stacked);
-                          unknown: 8 x abs_sum_max.  A value below the codes' is reported
+                          channels that share an LDS bank column (ch_slots; without it the
+                          channels 128 g + 32 w + n, w = 0..3).  Sizes the per-channel
+                          dequantisation tables (a channel's table covers its own accumulator
+                          range; the four channels of a column are stacked); unknown:
+                          8 x abs_sum_max.  A value below the codes' is reported
                           (SNNQP_STATUS_BOUND) */
+  const int32_t *ch_slots; /* W_I8, the event layer, nullable: device int32 [ceil(Cout / 128) * 128],
+                          for every channel 4 * column + position: which of the 32 bank columns
+                          of its 128-channel group holds its table and where in the column's
+                          stack of four.  The 32 channels of a wave (32 w .. 32 w + 31) must name
+                          32 different columns and no slot twice -- a balanced assignment keeps
+                          the tallest column, hence the table, small.  NULL: column n = c mod 32,
+                          position w */
 } snnqp_weight_t;
 
 /* Eval-mode BatchNorm folded on the host: y = fl(fl(fl(x - mean) * mul) + bias),
@@ -189,7 +197,7 @@ typedef struct {
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
  * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if,
- * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max).  A binding compares snnqp_version()
+ * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max / ch_slots).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 501
 int snnqp_version(void);

@@ -33,7 +33,8 @@ STATUS_QUEUE_CORRUPT, STATUS_TICKET, STATUS_BOUND = 1, 2, 4
 class WeightT(Structure):
   _fields_ = [("wtype", c_int32), ("w", c_void_p), ("L", c_float), ("m", c_float),
               ("abs_sum_max", c_int32), ("code_max", c_int32), ("col_sum", c_void_p),
-              ("wt_fp6", c_void_p), ("min_current_bits", c_uint32), ("ch_stack_max", c_int32)]
+              ("wt_fp6", c_void_p), ("min_current_bits", c_uint32), ("ch_stack_max", c_int32),
+              ("ch_slots", c_void_p)]
 
 
 BN_MEAN_ZERO, BN_BIAS_ZERO = 1, 2

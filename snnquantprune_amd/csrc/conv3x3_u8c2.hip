@@ -120,7 +120,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
                                      blockIdx.y * 128, a.Cout, tid, 256));
     }
   }
-  int ch_row0 = 0;                  // LUT_CHANNEL: the table row of this lane's entry of acc = 0
+  int ch_row0 = 0, ch_col = 0;      // LUT_CHANNEL: the table row and column of this lane's entry of acc = 0
   if (LUTM == LUT_CHANNEL) {
     // what this lane's channel can accumulate: the sums of its positive and |negative| codes
     // (the lane halves hold k 0..15 and 16..23 of the same channel), times the largest input
@@ -137,18 +137,20 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     pos += __shfl_xor(pos, 32);
     neg += __shfl_xor(neg, 32);
     uint32_t *scr = obuf;            // (the spike-word ring is not in use before the first patch)
+    // the bank column of this channel's table and its place in the column's stack (conv_tile.h)
+    int slot = 4 * n + wave;
+    if (a.ch_slots) slot = a.ch_slots[blockIdx.y * 128 + wave * 32 + n] & 127;
     if (h == 0) {
-      scr[wave * 32 + n] = (uint32_t)((pos + neg) * a.x_limit + 1);
+      scr[slot] = (uint32_t)((pos + neg) * a.x_limit + 1);
       scr[128 + wave * 32 + n] = (uint32_t)(neg * a.x_limit);
+      scr[256 + wave * 32 + n] = (uint32_t)slot;
     }
     lds_barrier();
-    int start = 0, total = 0;
+    ch_col = slot >> 2;
+    const int start = lut_column_start(scr, slot);
+    int total = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const int r = (int)scr[w2 * 32 + n];
-      start += w2 < wave ? r : 0;
-      total += r;
-    }
+    for (int k = 0; k < 4; ++k) total += (int)scr[(slot & ~3) + k];
     ch_row0 = start + neg * a.x_limit;
     // a column taller than the launch reserved: snnqp_weight_t.ch_stack_max is below the codes it
     // came with.  Its entries are not written (reads beyond the allocation return zeros): wrong
@@ -175,8 +177,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   {
     int bias = 0;
     if (LUTM == LUT_SHARED) bias = (int)lds_addr(lds) + lut_off + 4 * a.lut_bound;
-    if (LUTM == LUT_CHANNEL)     // row of acc = 0 of this lane's channel, column n
-      bias = (int)lds_addr(lds) + lut_off + 4 * (ch_row0 * 32 + n);
+    if (LUTM == LUT_CHANNEL)     // row of acc = 0 of this lane's channel, its column
+      bias = (int)lds_addr(lds) + lut_off + 4 * (ch_row0 * 32 + ch_col);
     int q = bias / 127;
     const int r = bias - 127 * q;
     int wsum = 0;
@@ -797,6 +799,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   const bool lutc = lut && in_type != SNNQP_BITS && crows <= LUT2_ROWS && xm <= 7 &&
                     w->code_max > 0 && w->code_max <= 15;
   a.lut_rows = lutc ? (int32_t)crows : 0;
+  a.ch_slots = lutc && w->ch_stack_max > 0 ? w->ch_slots : nullptr;
 #define SNNQP_CONV_LAUNCH_IN(KERN, NFV, PL, LM, LDS)                               \
   do {                                                                             \
     if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \

@@ -75,6 +75,7 @@ struct ConvMfmaArgs {
   int64_t npatch;
   int32_t lut_bound;  // > 0: |acc| <= lut_bound while inputs <= x_limit, dequant by LDS table
   int32_t lut_rows;   // u8c2 kernel, LUT_CHANNEL: rows (of 32 entries) the launch reserved for the tables
+  const int32_t *ch_slots;  // u8c2 kernel, LUT_CHANNEL: table slot of every channel (snnqp_weight_t), or null
   int32_t x_limit;    // u8c2 kernel: largest input value the table mode is sized for
   int32_t *x_seen;    // u8c2 kernel: (nullable) atomically max-ed with the largest input seen
   int32_t *x_flags;   // u8c2 kernel, float32 frames: OR-ed with SNNQP_FLAG_NOT_INTEGER (snnqp.h)
@@ -259,29 +260,37 @@ __device__ __forceinline__ void build_lut(float *lut, int bound, const Dequant &
 // accumulator is: the table reads of a wave never conflict (the channel-major order
 // [channel][acc] lost half of its LDS cycles to conflicts of the lanes with acc != 0).
 // The accumulator must then count 128 B per unit: A carries 16 x input, B 8 x code.
-// LUT_CHANNEL tables (conv3x3_u8c2.hip): channel c = 32 w + n of the workgroup's 128 keeps the
-// entries of acc = -neg_c x_limit .. +pos_c x_limit (pos_c / neg_c = the sums of its positive /
-// |negative| codes: what its accumulator can reach with inputs 0 .. x_limit) in column n of a
-// table of 128-byte rows, below the tables of the channels n, 32 + n, .. of the waves before it:
-// lane n reads bank n whatever its accumulator is, and the table is as tall as the tallest
-// column -- not four times the widest channel's symmetric range.
-//   scr[0..127]   rows of channel c      scr[128..255]  neg_c x_limit (the row of acc = 0)
+// LUT_CHANNEL tables (conv3x3_u8c2.hip): every channel of the workgroup's 128 keeps the entries of
+// acc = -neg_c x_limit .. +pos_c x_limit (pos_c / neg_c = the sums of its positive / |negative|
+// codes: what its accumulator can reach with inputs 0 .. x_limit) in ONE of the 32 bank columns of
+// a table of 128-byte rows, stacked with the three other channels of that column: slot = 4 x column
+// + position (snnqp_weight_t.ch_slots; default column = c mod 32, position = wave).  The 32 channels
+// of a wave sit in 32 different columns, so its lanes never collide whatever their accumulators
+// are, and the table is as tall as the tallest column -- not four times the widest channel's
+// symmetric range.
+//   scr[0..127]    rows by slot           scr[128..255]  neg_c x_limit by channel
+//   scr[256..383]  slot by channel
 // Returns the bits of the smallest non-zero |entry| this thread wrote (+inf if none).
+__device__ __forceinline__ int lut_column_start(const uint32_t *scr, int slot) {
+  int st = 0;
+  for (int k = 0; k < (slot & 3); ++k) st += (int)scr[(slot & ~3) + k];
+  return st;
+}
 __device__ __forceinline__ uint32_t build_lut_channel(float *lut, const uint32_t *scr, int max_rows,
                                                       const Dequant &dq, const BnP &bn, int cout0,
                                                       int Cout, int tid) {
   uint32_t minbits = 0x7F800000u;
-  const int c = tid & 127, hf = tid >> 7, cw = c >> 5, cn = c & 31;
-  int st = 0;
-  for (int w2 = 0; w2 < cw; ++w2) st += (int)scr[w2 * 32 + cn];
-  const int rows = (int)scr[c], negx = (int)scr[128 + c];
+  const int c = tid & 127, hf = tid >> 7;
+  const int slot = (int)scr[256 + c], col = slot >> 2;
+  const int st = lut_column_start(scr, slot);
+  const int rows = (int)scr[slot], negx = (int)scr[128 + c];
   if (st + rows > max_rows) return minbits;                    // (reported by the caller)
   const int co = cout0 + c < Cout ? cout0 + c : Cout - 1;
   float bm = 0.f, bmul = 1.f, bb = 0.f;
   if (bn.mean) { bm = bn.mean[co]; bmul = bn.mul[co]; bb = bn.bias[co]; }
   for (int i = hf; i < rows; i += 2) {
     const float y = bn_apply(dequant_acc_nb(i - negx, dq), bm, bmul, bb);
-    lut[(st + i) * 32 + cn] = y;
+    lut[(st + i) * 32 + col] = y;
     const uint32_t mag = __float_as_uint(y) & 0x7FFFFFFFu;
     if (mag != 0u && mag < minbits) minbits = mag;
   }

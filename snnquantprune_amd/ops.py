@@ -279,6 +279,7 @@ class Weight:
   col_sum: Optional[torch.Tensor] = None   # dense: int32 [N] column sums of the codes (uint8 input)
   wt6: Optional[torch.Tensor] = None       # dense, code_max <= 7: fp6 MFMA tiles (pack_codes_fp6)
   ch_stack_max: int = 0     # event layer: largest stacked per-channel code range (snnqp.h), 0 = unknown
+  ch_slots: Optional[torch.Tensor] = None  # event layer: int32 [padded Cout] table slots (packing.table_slots)
 
   def struct(self) -> L.WeightT:
     # (built once per object: a Weight is not modified after the pack step made it --
@@ -289,7 +290,8 @@ class Weight:
                      int(self.abs_sum_max), int(self.code_max),
                      None if self.col_sum is None else self.col_sum.data_ptr(),
                      None if self.wt6 is None else self.wt6.data_ptr(),
-                     int(self.min_current_bits), int(self.ch_stack_max))
+                     int(self.min_current_bits), int(self.ch_stack_max),
+                     None if self.ch_slots is None else self.ch_slots.data_ptr())
       self.__dict__["_cstruct"] = st
     return st
 
@@ -504,9 +506,9 @@ class CountHint:
 
   BOUNDS = (1, 2, 3, 7, 31)                 # the buckets' upper bounds; above 31: no table
   # relative time of a chunk in the table mode of a bound (headline layer, tools/conv0_hint_time.py:
-  # per-channel tables 5.90 / 5.82 ms, at three workgroups per CU 6.61, shared table 7.03) and on the
+  # per-channel tables 5.96 / 5.82 / 5.82 ms for hints 1 / 2 / 3, shared table 7.02) and on the
   # general path (x - 128, arithmetic: 10.9)
-  COST = (1.0, 1.0, 1.12, 1.19, 1.19)
+  COST = (1.0, 1.0, 1.0, 1.19, 1.19)
   GENERAL = 1.85
 
   def __init__(self, device):

@@ -59,6 +59,31 @@ def integer_inputs(enabled: bool):
     AUTO_INTEGER_INPUTS = old
 
 
+def table_slots(ranges):
+  """The event layer's per-channel dequantisation tables (snnqp.h ch_slots / ch_stack_max): channel
+  c of a 128-channel group keeps a table over its own accumulator range (range_c = sum |code|) in
+  one of the 32 LDS bank columns; the 32 channels of a wave (32 w .. 32 w + 31) must sit in 32
+  different columns (a wave's lanes then never collide), four channels stack per column, and the
+  tallest column sizes the table.  Greedy balance: wave by wave, the widest channel goes to the
+  emptiest column.  Returns (int32 slots [padded Cout]: 4 * column + position in the column, the
+  largest column sum of ranges)."""
+  import numpy as np
+  r = np.asarray(ranges, np.int64)
+  n128 = (r.size + 127) // 128 * 128
+  r = np.concatenate([r, np.zeros(n128 - r.size, np.int64)])
+  slots = np.zeros(n128, np.int32)
+  worst = 0
+  for g in range(n128 // 128):
+    col = np.zeros(32, np.int64)
+    for w in range(4):
+      ch = 128 * g + 32 * w + np.argsort(-r[128 * g + 32 * w:128 * g + 32 * w + 32], kind="stable")
+      banks = np.argsort(col, kind="stable")
+      slots[ch] = 4 * banks + w
+      col[banks] += r[ch]
+    worst = max(worst, int(col.max()))
+  return slots, worst
+
+
 class PackedKernel:
   def __init__(self, kernel: torch.Tensor, desc: Optional[QuantDesc],
                mask: Optional[torch.Tensor]):
@@ -87,17 +112,15 @@ class PackedKernel:
     # accumulator lies in [-sum of |negative codes|, +sum of positive codes] * x_max: the
     # larger one-sided sum over the outputs bounds |acc| (about half of sum |code|)
     side = torch.maximum(c2.clamp(min=0).sum(0).max(), (-c2).clamp(min=0).sum(0).max())
-    # the event layer's per-channel tables (snnqp.h ch_stack_max): the ranges sum |code| of the
-    # four channels that share an LDS bank (128 g + 32 w + n), the largest such sum
-    rng = c2.abs().sum(0)
-    n128 = (rng.numel() + 127) // 128 * 128
-    stack = torch.nn.functional.pad(rng, (0, n128 - rng.numel())).reshape(-1, 4, 32).sum(1).max()
-    stats = torch.stack([side, c2.abs().max(), stack]).tolist()      # one readback
+    stats = torch.stack([side, c2.abs().max()]).tolist()             # one readback
     # dense kernels: column sums of the codes, for uint8 rows read as x - 128 (snnqp.h col_sum)
     col = c2.sum(0).to(torch.int32).contiguous() if self.kernel.ndim == 2 else None
+    slots, stack = None, 0
+    if self.kernel.ndim == 4 and self.kernel.shape[2] == 2:
+      slots, stack = table_slots(c2.abs().sum(0).cpu().numpy())
+      slots = torch.from_numpy(slots).to(codes.device)
     self._int = ops.Weight(L.W_I8, codes, d.L, d.m, abs_sum_max=int(stats[0]),
-                           code_max=int(stats[1]), col_sum=col,
-                           ch_stack_max=int(stats[2]) if self.kernel.ndim == 4 and self.kernel.shape[2] == 2 else 0)
+                           code_max=int(stats[1]), col_sum=col, ch_stack_max=stack, ch_slots=slots)
     return self._int
 
   def gated_codes(self):
@@ -176,7 +199,8 @@ class PackedKernel:
       if self.kernel.ndim == 2 and 0 < base.code_max <= 7:
         wt6 = ops.pack_codes_fp6(codes, n_pad)
       w = ops.Weight(L.W_I8, codes, base.L, base.m, wt=wt, abs_sum_max=base.abs_sum_max,
-                     code_max=base.code_max, col_sum=base.col_sum, wt6=wt6, ch_stack_max=base.ch_stack_max)
+                     code_max=base.code_max, col_sum=base.col_sum, wt6=wt6, ch_stack_max=base.ch_stack_max,
+                     ch_slots=base.ch_slots)
       self._wt[key] = w
     return w
 

@@ -726,3 +726,34 @@ def test_compute_dtype_policy():
     nn.set_compute_dtype_policy("strict")
   with pytest.raises(ValueError):
     nn.set_compute_dtype_policy("bf16")
+
+
+def test_table_slots_balance_the_bank_columns():
+  """packing.table_slots (snnqp_weight_t.ch_slots): every wave's 32 channels in 32 different bank
+  columns, every slot once, the reported stack = the tallest column; balanced far below the
+  default stacking (column = c mod 32) on ranges as skewed as a 90 %-pruned event layer's."""
+  import numpy as np
+  from snnquantprune_amd import packing
+  rng = np.random.Generator(np.random.PCG64(12))
+  for cout in (128, 200, 32):
+    ranges = (rng.poisson(1.8, cout) * rng.integers(1, 8, cout)).astype(np.int64)
+    slots, stack = packing.table_slots(ranges)
+    n128 = (cout + 127) // 128 * 128
+    assert slots.shape == (n128,) and slots.dtype == np.int32
+    r = np.concatenate([ranges, np.zeros(n128 - cout, np.int64)])
+    worst = 0
+    for g in range(n128 // 128):
+      sl = slots[128 * g:128 * g + 128]
+      assert sorted(sl.tolist()) == list(range(128))                       # every slot once
+      for w in range(4):
+        assert sorted((sl[32 * w:32 * w + 32] >> 2).tolist()) == list(range(32))   # a wave: 32 columns
+        assert set((sl[32 * w:32 * w + 32] & 3).tolist()) == {w}
+      col = np.zeros(32, np.int64)
+      np.add.at(col, sl >> 2, r[128 * g:128 * g + 128])
+      worst = max(worst, int(col.max()))
+      default = r[128 * g:128 * g + 128].reshape(4, 32).sum(0).max()
+      assert col.max() <= default
+    assert stack == worst
+  ranges = (rng.poisson(1.8, 128) * rng.integers(1, 8, 128)).astype(np.int64)
+  _, stack = packing.table_slots(ranges)
+  assert stack <= 1.35 * ranges.sum() / 32 + ranges.max() / 2 < ranges.reshape(4, 32).sum(0).max()

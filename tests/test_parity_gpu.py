@@ -3589,7 +3589,7 @@ def test_per_channel_tables_cover_count_frames_and_report_a_short_stack(dev, ora
   from snnquantprune_amd import ops
   c = cases.conv_block_case(T=7, B=3, hw=16, cin=2, seed=977, gain=4.0)
   w = _weight(c["leaf"], c["bits"], dev, transposed=True)
-  assert w.ch_stack_max > 0 and w.code_max <= 7
+  assert w.ch_stack_max > 0 and w.ch_slots is not None and w.code_max <= 7
   bn, nrn = _bn(c["bn"], dev), _mslif()
   g = ops.ConvGeom(16, 16, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
   rng = np.random.Generator(np.random.PCG64(6))
