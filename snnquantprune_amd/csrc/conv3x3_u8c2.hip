@@ -742,7 +742,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
                      int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st) {
-  SNNQP_REQUIRE(x && w->w && s_out, SNNQP_EINVAL, "conv3x3 mfma: null pointer");
+  SNNQP_REQUIRE(w->w && ((x && s_out) || T == 0 || B == 0), SNNQP_EINVAL, "conv3x3 mfma: null pointer");   // (an empty batch has no buffers)
   SNNQP_REQUIRE(in_type != SNNQP_BITS || wt, SNNQP_EINVAL,
                 "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "conv3x3 mfma: negative T/B");

@@ -240,7 +240,8 @@ extern "C" int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, in
                                         const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                                         const void *packed, float *y, snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(s && gate && g && w && packed && y && NB >= 0, SNNQP_EINVAL, "conv_gated_forward: bad argument");
+  SNNQP_REQUIRE(g && w && packed && NB >= 0 && ((s && gate && y) || NB == 0), SNNQP_EINVAL,
+                "conv_gated_forward: bad argument");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   const char *why = conv_gated_unsupported(g, w);
   SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "conv_gated_forward: %s", why);

@@ -482,7 +482,7 @@ int run_dense_fp6(const void *x, int64_t xs_t, int64_t xs_b, int32_t T, int32_t 
                   int32_t N, const snnqp_weight_t *w, const snnqp_bn_t *bn,
                   const snnqp_neuron_t *nrn, const float *u0, float *u_out, uint32_t *s_out,
                   int row_tiles, void *ws, int64_t ws_bytes, hipStream_t st) {
-  SNNQP_REQUIRE(x && s_out && w->wt_fp6, SNNQP_EINVAL, "dense fp6: null pointer");
+  SNNQP_REQUIRE(w->wt_fp6 && ((x && s_out) || T == 0 || B == 0), SNNQP_EINVAL, "dense fp6: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense fp6: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   SNNQP_CHECK_BN(bn);

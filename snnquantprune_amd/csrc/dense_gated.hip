@@ -204,7 +204,8 @@ extern "C" int snnqp_dense_gated_forward(const uint32_t *s, const float *gate, i
                                          int32_t C, int32_t N, const snnqp_weight_t *w,
                                          const void *packed, float *y, snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(s && gate && w && packed && y && NB >= 0, SNNQP_EINVAL, "dense_gated_forward: bad argument");
+  SNNQP_REQUIRE(w && packed && NB >= 0 && ((s && gate && y) || NB == 0), SNNQP_EINVAL,
+                "dense_gated_forward: bad argument");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   const char *why = dense_gated_unsupported(HW, C, N, w);
   SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "dense_gated_forward: %s", why);

@@ -380,7 +380,7 @@ int run_dense_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
                    int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, hipStream_t st) {
-  SNNQP_REQUIRE(x && s_out, SNNQP_EINVAL, "dense mfma: null pointer");
+  SNNQP_REQUIRE((x && s_out) || T == 0 || B == 0, SNNQP_EINVAL, "dense mfma: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense mfma: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   SNNQP_CHECK_BN(bn);

@@ -875,7 +875,7 @@ int run_dense_wide(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32
                    int32_t K, int32_t N, const snnqp_weight_t *w, const int8_t *wt,
                    const snnqp_bn_t *bn, const snnqp_neuron_t *nrn, const float *u0,
                    float *u_out, uint32_t *s_out, int32_t *x_flags, hipStream_t st) {
-  SNNQP_REQUIRE(x && s_out, SNNQP_EINVAL, "dense wide: null pointer");
+  SNNQP_REQUIRE((x && s_out) || T == 0 || B == 0, SNNQP_EINVAL, "dense wide: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "dense wide: negative T/B");
   SNNQP_REQUIRE(w->L >= 1.0f, SNNQP_EINVAL, "dequant L must be >= 1");
   SNNQP_CHECK_BN(bn);
@@ -903,7 +903,8 @@ extern "C" int snnqp_dense_head_forward(const void *x, int in_type, int64_t x_st
                                         int32_t *x_flags, void *ws, int64_t ws_bytes,
                                         snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(x && w1 && w2 && nrn1 && nrn2 && logits, SNNQP_EINVAL, "dense_head_forward: null argument");
+  SNNQP_REQUIRE(w1 && w2 && nrn1 && nrn2 && ((x && logits) || T == 0 || B == 0), SNNQP_EINVAL,
+                "dense_head_forward: null argument");
   if (const uint32_t code = device_status_read(stream_device((hipStream_t)stream))) {
     set_error("dense_head_forward: device status 0x%x: %s (snnqp_device_status(..., reset = 1) clears it)",
               (unsigned)code, device_status_text(code));

@@ -65,8 +65,8 @@ int snnqp_lif_forward(const float *x, int32_t T, int64_t R, int32_t C,
                       const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                       const float *u0, float *u_out, void *s_out, int s_type,
                       snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && s_out && nrn, SNNQP_EINVAL, "lif_forward: null argument");
   SNNQP_REQUIRE(T >= 0 && R >= 0 && C > 0, SNNQP_EINVAL, "lif_forward: bad shape");
+  SNNQP_REQUIRE(nrn && ((x && s_out) || T == 0 || R == 0), SNNQP_EINVAL, "lif_forward: null argument");
   SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF &&
                     nrn->kind <= SNNQP_NEURON_LIF,
                 SNNQP_EINVAL, "lif_forward: unknown neuron kind %d", nrn->kind);
@@ -93,7 +93,7 @@ int snnqp_lif_forward(const float *x, int32_t T, int64_t R, int32_t C,
 int snnqp_batchnorm_forward(const float *x, int64_t rows, int32_t C,
                             const snnqp_bn_t *bn, float *y,
                             snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && y && bn, SNNQP_EINVAL, "batchnorm_forward: null argument");
+  SNNQP_REQUIRE(bn && ((x && y) || rows == 0), SNNQP_EINVAL, "batchnorm_forward: null argument");
   SNNQP_CHECK_BN(bn);
   SNNQP_REQUIRE(rows >= 0 && C > 0, SNNQP_EINVAL, "batchnorm_forward: bad shape");
   const int64_t n = rows * C;

@@ -205,7 +205,7 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
   SNNQP_REQUIRE(!dz || pool == 1, SNNQP_EINVAL, "generic block: the fused pool is 2-D");
   SNNQP_REQUIRE(pool == 1 || (pool == 2 && nrn && nrn->kind != SNNQP_NEURON_NONE), SNNQP_EINVAL,
                 "generic block: pool must be 1, or 2 with a neuron");
-  SNNQP_REQUIRE(x && w && w->w && s_out, SNNQP_EINVAL, "generic block: null pointer");
+  SNNQP_REQUIRE(w && w->w && ((x && s_out) || T == 0 || B == 0), SNNQP_EINVAL, "generic block: null pointer");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "generic block: negative T/B");
   GenericArgs a;
   a.x = x; a.xs_t = xs_t; a.xs_b = xs_b; a.T = T; a.B = B; a.g = *g;

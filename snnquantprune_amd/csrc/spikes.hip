@@ -435,7 +435,7 @@ int snnqp_unpack_bits(const uint32_t *bits, int64_t rows, int32_t C, float *y,
 
 int snnqp_maxpool2x2(const void *x, int type, int64_t NB, int32_t H, int32_t W,
                      int32_t C, void *y, snnqp_stream_t stream) {
-  SNNQP_REQUIRE(x && y && NB >= 0 && H >= 0 && W >= 0 && C > 0, SNNQP_EINVAL,
+  SNNQP_REQUIRE(NB >= 0 && H >= 0 && W >= 0 && C > 0 && ((x && y) || NB * (H / 2) * (W / 2) == 0), SNNQP_EINVAL,
                 "maxpool2x2: bad argument");
   SNNQP_REQUIRE(type == SNNQP_F32 || type == SNNQP_BITS, SNNQP_EINVAL,
                 "maxpool2x2: type must be F32 or BITS");
@@ -554,7 +554,7 @@ int snnqp_vote(const void *s, int type, int32_t T, int32_t B, int32_t N,
 
 int snnqp_vote_if(const int32_t *pred, const void *s, int type, int32_t T, int32_t B, int32_t N,
                   int32_t group, float *logits, snnqp_stream_t stream) {
-  SNNQP_REQUIRE(s && logits && T > 0 && B >= 0 && N > 0 && group > 0,
+  SNNQP_REQUIRE(((s && logits) || B == 0) && T > 0 && B >= 0 && N > 0 && group > 0,
                 SNNQP_EINVAL, "vote: bad argument");
   SNNQP_REQUIRE(N % group == 0, SNNQP_EINVAL,
                 "vote: N=%d not divisible by group=%d", N, group);

@@ -41,13 +41,13 @@ def flatten_channel_major(x):
   if isinstance(x, ops.PackedSpikes):
     T, B, H, W, C = x.shape
     if C % 32:
-      d = x.to_dense().permute(0, 1, 4, 2, 3).reshape(T, B, -1)
+      d = x.to_dense().permute(0, 1, 4, 2, 3).reshape(T, B, C * H * W)
       return ops.pack_bits(d.contiguous())
     out = ops.PackedSpikes(x.bits.reshape(T, B, H * W * (C // 32)), H * W * C)
     out.flat_perm = (C, H, W)
     return out
   x = x.permute(0, 1, 4, 2, 3)
-  return x.reshape(x.shape[0], x.shape[1], -1).contiguous()
+  return x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3] * x.shape[4]).contiguous()   # (no -1: B may be 0)
 
 
 def _layer_bits(cfg, i):

@@ -159,7 +159,7 @@ class GatedSpikes:
     x = apply_gate(self.spikes, self.gate)
     if self.flat:
       x = x.permute(0, 1, 4, 2, 3)
-      x = x.reshape(x.shape[0], x.shape[1], -1).contiguous()
+      x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3] * x.shape[4]).contiguous()
     return x
 
 

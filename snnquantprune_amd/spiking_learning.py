@@ -366,7 +366,7 @@ class SpikingBlock(nn.Module):
       c, h, ww = flat
       d = x.to_dense() if isinstance(x, ops.PackedSpikes) else x.to(torch.float32)
       d = d.reshape(d.shape[0], d.shape[1], h, ww, c).permute(0, 1, 4, 2, 3)
-      x = d.reshape(d.shape[0], d.shape[1], -1).contiguous()
+      x = d.reshape(d.shape[0], d.shape[1], c * h * ww).contiguous()
     nrn = self.neural_dynamics.neuron(conn.features)
     bn = norm.coeffs(conn.features) if norm is not None else None
 
@@ -509,7 +509,7 @@ class SpikingBlock(nn.Module):
     per_sample = 4 * T * geom.H * geom.W * N              # bytes of float32 currents
     step = max(1, min(B, (1 << 30) // max(per_sample, 1)))
     us, ss = [], []
-    for b0 in range(0, B, step):
+    for b0 in range(0, max(B, 1), step):      # (an empty batch: one empty slice)
       b1 = min(B, b0 + step)
       xs = x if (b0 == 0 and b1 == B) else ops.GatedSpikes(
           ops.PackedSpikes(x.spikes.bits[:, b0:b1].contiguous(), x.spikes.channels), x.gate[:, b0:b1].contiguous())
@@ -594,7 +594,7 @@ class SpikingBlock(nn.Module):
     step = max(1, min(B, (1 << 30) // max(per_sample, 1)))
     tag = "%s[f32 %s]" % ("dense" if is_dense else "conv", geom.tag())
     us, ss = [], []
-    for b0 in range(0, B, step):
+    for b0 in range(0, max(B, 1), step):      # (an empty batch: one empty slice)
       b1 = min(B, b0 + step)
       if tm:
         xs = x[(slice(None), slice(b0, b1))]

@@ -3639,3 +3639,70 @@ def test_scan_with_a_ragged_feature_count_replays_in_a_graph(dev, oracle):
       es.append(sp)
     np.testing.assert_array_equal(_np(s_g), packbits_lastaxis(np.stack(es)), err_msg="replay %d" % k)
     np.testing.assert_array_equal(_np(u_g), u)
+
+
+def test_empty_batches_and_zero_timesteps(dev, oracle):
+  """B = 0 and T = 0 through the fused blocks, the dense head, the gated connections, the 3-D
+  convolution and the stand-alone connections: nothing is launched out of range, shapes are the
+  reference's (a scan over zero steps returns the carry, spiking_learning.py:446-462), nothing is
+  reported."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, packing, synthetic as syn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  from snnquantprune_amd.flax_qdense import QuantDense
+  from snnquantprune_amd.quant import QuantDesc
+  c = cases.conv_block_case(T=3, B=2, hw=8)
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  g = ops.ConvGeom(8, 8, 128, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  nrn, bn = _mslif(), _bn(c["bn"], dev)
+  for T, B in ((0, 2), (3, 0), (0, 0)):
+    x = ops.pack_bits(torch.zeros((T, B, 8, 8, 128), dtype=torch.uint8, device=dev))
+    u, s = ops.conv_lif_forward(x, g, w, nrn, bn=bn, want_u=True, packed_out=True, pool=2)
+    assert tuple(s.shape) == (T, B, 4, 4, 128) and tuple(u.shape) == (B, 8, 8, 128)
+    xf = torch.zeros((T, B, 8, 8, 128), dtype=torch.float32, device=dev)
+    y = ops.conv_forward(xf.reshape(T * B, 8, 8, 128), g, packing.PackedKernel(
+        _t(c["leaf"]["kernel"], dev), None, None).float_weight())
+    assert tuple(y.shape) == (T * B, 8, 8, 128)
+  # dense head and blocks
+  cfg = syn.make_config(bits=8, prune_percentage=0.5, hidden=512)
+  model = models.DenseSNN(num_classes=11, config=cfg)
+  variables = nn.tree_from_numpy(syn.dense_net_variables(2048, 512, 110, True, 0.5), dev)
+  for dt in (torch.uint8, torch.float32):
+    logits, _ = model.apply(variables, torch.zeros((0, 20, 2048), dtype=dt, device=dev), trgt=None, train=False,
+                            rng=None)
+    assert tuple(logits.shape) == (0, 11)
+  # gated connections
+  leaf = syn.quant_leaf((3, 3, 128, 128), 5.0, 971, True, 0.9)
+  a, cc = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
+  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, 4, a, cc, 7.0, cc), _t(leaf["prune_0"]["mask"], dev))
+  xg = ops.GatedSpikes(ops.pack_bits(torch.zeros((2, 0, 8, 8, 128), dtype=torch.uint8, device=dev)),
+                       torch.zeros((2, 0, 128), dtype=torch.float32, device=dev))
+  assert tuple(ops.conv_gated_forward(xg, g, pk.int_weight(), pk.gated_codes()).shape) == (2, 0, 8, 8, 128)
+  leafd = syn.quant_leaf((128 * 16, 512), 5.0, 981, True, 0.9)
+  a, cc = float(leafd["DuQ_0"]["a"][0]), float(leafd["DuQ_0"]["c"][0])
+  pkd = packing.PackedKernel(_t(leafd["kernel"], dev), QuantDesc(L.Q_DUQ, 4, a, cc, 7.0, cc), _t(leafd["prune_0"]["mask"], dev))
+  xd = ops.GatedSpikes(ops.pack_bits(torch.zeros((2, 0, 4, 4, 128), dtype=torch.uint8, device=dev)),
+                       torch.zeros((2, 0, 128), dtype=torch.float32, device=dev)).flattened()
+  assert tuple(ops.dense_gated_forward(xd, pkd.int_weight(), pkd.gated_dense_codes(128, 16)).shape) == (2, 0, 512)
+  # 3-D convolution and the stand-alone connections on float32 inputs
+  cfg4 = syn.make_config(bits=4, prune_percentage=0.9)
+  leaf3 = syn.quant_leaf((2, 3, 3, 4, 8), 5.0, 77, True, 0.9)
+  m3 = QuantConv(8, (2, 3, 3), padding="SAME", use_bias=False, config=cfg4.quant, bits=4, g_scale=cfg4.quant.g_scale)
+  v3 = nn.tree_from_numpy({"params": leaf3}, dev)
+  assert tuple(m3.apply(v3, torch.zeros((0, 3, 5, 5, 4), dtype=torch.float32, device=dev)).shape) == (0, 3, 5, 5, 8)
+  leaf2 = syn.quant_leaf((70, 45), 5.0, 31, True, 0.9)
+  md = QuantDense(45, use_bias=False, config=cfg4.quant, bits=4, g_scale=cfg4.quant.g_scale)
+  vd = nn.tree_from_numpy({"params": leaf2}, dev)
+  assert tuple(md.apply(vd, torch.zeros((0, 70), dtype=torch.float32, device=dev)).shape) == (0, 45)
+  # whole models on an empty batch (the tail of a sharded eval split)
+  mc3 = models.ConvDenseSNN(num_classes=11, config=cfg4)
+  vc3 = nn.tree_from_numpy(syn.conv_net_variables(prune_p=0.9, out=110), dev)
+  for dt in (torch.uint8, torch.float32):
+    out = mc3.apply(vc3, torch.zeros((0, 4, 128, 128, 2), dtype=dt, device=dev), trgt=None, train=False, rng=None)
+    assert tuple(out[0].shape) == (0, 11)
+  mcx = models.CextNet(num_classes=11, config=cfg4)
+  vcx = nn.tree_from_numpy(syn.cextnet_variables(frames=4, prune_p=0.9), dev)
+  out = mcx.apply(vcx, torch.zeros((0, 4, 128, 128, 2), dtype=torch.uint8, device=dev), trgt=None, train=False, rng=None)
+  assert tuple(out[0].shape) == (0, 11)
+  assert ops.device_status() == 0
