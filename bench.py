@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 # dense peaks, MI355X_MICROARCH.md: int8 MFMA 2x the ~2.5 PF bf16 rate; block-scaled
 # fp6/fp4 MFMA ~10 PF; HBM3E 8 TB/s
+F32_MFMA_PEAK_TOPS = 157.3       # v_mfma_f32_32x32x2_f32: 78.6 T fma/s (MI355X_MICROARCH.md)
 INT8_MFMA_PEAK_TOPS = 5000.0
 FP6_MFMA_PEAK_TOPS = 10000.0
 HBM_PEAK_GBS = 8000.0
@@ -143,6 +144,8 @@ def layer_bits(args):
 def issued_dtype(args, lb):
   """The operand formats of the instruction the dominant kernel issues (not a precision claim:
   every sum is an exact integer)."""
+  if args.bits < 0 and not args.layer_bits:        # unquantised kernels (config C1): the float32 chain
+    return "f32*f32->f32 (fmaf chain on the f32 MFMA)"
   if args.model == "dense":
     return "int8*int8->int32"
   conv = [b for b in lb[1:3]]
@@ -912,6 +915,12 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
       # config C2 as ONE launch (snnqp_dense_head_forward): the uint8 rows as the kernel reads them
       # (2048 B per sample-step, in place), both code matrices once, the logits; the hidden
       # raster never leaves the CU
+      # unquantised dense blocks (config C1): float32 connection on the f32 MFMA + the scan; rows in
+      # the format they arrive in, float32 currents out and back, float32 kernels once
+      "dense[f32 1x1x2048->512]": (B * T * 2048 * 512, B * T * (row_bytes + 2 * 512 * 4 + 64) + 2048 * 512 * 4,
+                                   F32_MFMA_PEAK_TOPS),
+      "dense[f32 1x1x512->%d]" % nout: (B * T * 512 * nout, B * T * (64 + 2 * nout * 4 + 16) + 512 * nout * 4,
+                                        F32_MFMA_PEAK_TOPS),
       "dense_head[2048->512->%d]" % nout: (B * T * (2048 * 512 + 512 * nout),
                                            B * T * row_bytes + 2048 * 512
                                            + 512 * 128 + B * 4 * args.classes, INT8_MFMA_PEAK_TOPS),
@@ -982,7 +991,8 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
     dense_tag = "dense_head[2048->512->%d]" % nout
   groups = {conv_kernel: ["conv3x3[64x64x128->128]", "conv3x3[32x32x128->128]"],
             "conv3x3_u8c2_kernel": ["conv3x3[128x128x2->128]"],
-            "dense kernel": [dense_tag] + (["dense[512->%d]" % nout] if args.model == "dense" else [])}
+            "dense kernel": [dense_tag] + (["dense[512->%d]" % nout] if args.model == "dense" else []),
+            "fseq_gemm_kernel": ["dense[f32 1x1x2048->512]", "dense[f32 1x1x512->%d]" % nout]}
   gtime = {g: sum(kern[t]["avg_ms"] * kern[t]["launches"] for t in tags if t in kern)
            for g, tags in groups.items()}
   out = {"kernels": kern}

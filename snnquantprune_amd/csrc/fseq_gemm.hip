@@ -26,9 +26,18 @@ namespace snnqp {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int FG_BM = 128, FG_BN = 128, FG_KC = 16;
-constexpr int FG_LD = 160;      // LDS row stride (floats) of one k: 128 + 32, so the two lane
-                                // halves (k, k + 1) of an MFMA operand read disjoint banks
+constexpr int FG_KC = 16;
+// TM: 32 x 32 MFMA tiles per wave and direction.  2: a workgroup owns 128 x 128 outputs (the
+// throughput shape: every operand read from LDS feeds two MFMAs); 1: 64 x 64 -- for problems of a
+// few hundred rows (config C1: 320 x 512 outputs are 12 workgroups of the large tile on 256 CUs,
+// and K is one dependent chain per output whatever the tile): four times the workgroups, a
+// quarter of the chain work per wave.
+template <int TM> struct FgTile {
+  static constexpr int BM = 64 * TM, BN = 64 * TM;
+  static constexpr int LD = BM + 32;     // LDS row stride (floats) of one k: the two lane halves
+                                         // (k, k + 1) of an MFMA operand read disjoint banks
+  static constexpr int EPT = 4 * TM;     // elements of a k chunk a thread stages per operand
+};
 
 struct FseqGemmArgs {
   const void *x;        // [NB][H][W][Cin] float32 / uint8, or [NB][H][W][Cin/32] spike words
@@ -44,6 +53,9 @@ struct FseqGemmArgs {
 // MODE 0: float32, Cin % 16 == 0 (a k chunk lies in one tap: one address computation)
 //      1: float32, Cin % 4 == 0 (runs of 4 channels)
 //      2: any type and Cin, element by element (the 2-channel event input; uint8; bits)
+//      3: uint8 rows / spike words into a 1 x 1 kernel (dense layers: k = channel, the pixel is
+//         the row): eight bytes or eight bits per load, no tap arithmetic -- unquantised dense
+//         blocks on integer-typed rows (config C1) spent their time in MODE 2's divisions
 template <int IN> __device__ __forceinline__ float fg_load(const void *x, int64_t pix, int c, int Cin) {
   if (IN == SNNQP_F32) return ((const float *)x)[pix * Cin + c];
   if (IN == SNNQP_U8) return (float)((const uint8_t *)x)[pix * Cin + c];
@@ -51,19 +63,21 @@ template <int IN> __device__ __forceinline__ float fg_load(const void *x, int64_
   return (float)((w >> (c & 31)) & 1u);
 }
 
-template <int MODE, int IN>
+template <int MODE, int IN, int TM = 2>
 __global__ void __launch_bounds__(256)
 fseq_gemm_kernel(FseqGemmArgs a) {
+  constexpr int FG_BM = FgTile<TM>::BM, FG_BN = FgTile<TM>::BN, FG_LD = FgTile<TM>::LD, EPT = FgTile<TM>::EPT;
   __shared__ __attribute__((aligned(16))) float lds[2][2][FG_KC * FG_LD];   // [buf][A|B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * FG_BM;
   const int n0 = blockIdx.y * FG_BN;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TM;
 
-  // staging tasks.  A: row ar of the tile, 8 consecutive k (two float4); B: k row bk,
-  // 8 consecutive columns
-  const int ar = tid >> 1, ak = (tid & 1) * 8;
+  // staging tasks.  A: row ar of the tile, EPT consecutive k (TM float4); B: k row bk,
+  // EPT consecutive columns
+  constexpr int TPR = FG_KC / EPT;           // threads per A row
+  const int ar = tid / TPR, ak = (tid % TPR) * EPT;
   const int64_t am = m0 + ar;
   const bool arow = am < a.M;
   int oy = 0, ox = 0;
@@ -75,8 +89,8 @@ fseq_gemm_kernel(FseqGemmArgs a) {
     oy = p / a.W;
     ox = p - oy * a.W;
   }
-  const int bk = tid >> 4, bc = (tid & 15) * 8;
-  v4f ra[2], rb[2];
+  const int bk = tid >> 4, bc = (tid & 15) * EPT;
+  v4f ra[TM], rb[TM];
   auto load_chunk = [&](int kc) {          // global -> registers
     const int k0 = kc * FG_KC;
     if (MODE == 0) {
@@ -85,11 +99,30 @@ fseq_gemm_kernel(FseqGemmArgs a) {
       const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
       const bool ok = arow && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       const float *src = (const float *)a.x + ((img * a.H + iy) * a.W + ix) * a.Cin + c0 + ak;
-      ra[0] = ok ? *(const v4f *)src : v4f{0.f, 0.f, 0.f, 0.f};
-      ra[1] = ok ? *(const v4f *)(src + 4) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < TM; ++j) ra[j] = ok ? *(const v4f *)(src + 4 * j) : v4f{0.f, 0.f, 0.f, 0.f};
+    } else if (MODE == 3) {
+      const int kk = k0 + ak;                    // a multiple of EPT; Cin % 8 == 0 (U8) / any (BITS)
+      uint32_t q[TM];                            // EPT values, a byte each
+#pragma unroll
+      for (int j = 0; j < TM; ++j) q[j] = 0;
+      if (arow && kk < a.K) {
+        if (IN == SNNQP_U8) {
+#pragma unroll
+          for (int j = 0; j < TM; ++j) q[j] = *(const uint32_t *)((const uint8_t *)a.x + am * a.Cin + kk + 4 * j);
+        } else {
+          const uint32_t w = ((const uint32_t *)a.x)[am * ((a.Cin + 31) >> 5) + (kk >> 5)] >> (kk & 31);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) q[j] = (((w >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[j][e] = (float)((q[j] >> (8 * e)) & 0xFFu);
     } else if (MODE == 2) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int kk = k0 + ak + 4 * j + e;
@@ -101,7 +134,7 @@ fseq_gemm_kernel(FseqGemmArgs a) {
         }
     } else
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TM; ++j) {
       const int kk = k0 + ak + 4 * j;          // 4 consecutive k = 4 channels of one tap
       const int tap = kk / a.Cin, c0 = kk - tap * a.Cin;
       const int kh = tap / a.KW, kw = tap - kh * a.KW;
@@ -112,7 +145,7 @@ fseq_gemm_kernel(FseqGemmArgs a) {
     }
     const int kb = k0 + bk;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TM; ++j) {
       const int col = n0 + bc + 4 * j;
       v4f v = {0.f, 0.f, 0.f, 0.f};
       if (kb < a.K) {
@@ -131,18 +164,18 @@ fseq_gemm_kernel(FseqGemmArgs a) {
   auto store_chunk = [&](int buf) {        // registers -> LDS (A transposed to k-major)
     float *la = lds[buf][0], *lb = lds[buf][1];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) la[(ak + 4 * j + e) * FG_LD + ar] = ra[j][e];
-    *(v4f *)(lb + bk * FG_LD + bc) = rb[0];
-    *(v4f *)(lb + bk * FG_LD + bc + 4) = rb[1];
+      *(v4f *)(lb + bk * FG_LD + bc + 4 * j) = rb[j];
+    }
   };
 
-  v16f acc[2][2];
+  v16f acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -156,16 +189,16 @@ fseq_gemm_kernel(FseqGemmArgs a) {
     const float *la = lds[buf][0], *lb = lds[buf][1];
 #pragma unroll
     for (int s = 0; s < FG_KC / 2; ++s) {          // k pairs, ascending
-      float av[2], bv[2];
+      float av[TM], bv[TM];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TM; ++i) {
         av[i] = la[(2 * s + h) * FG_LD + wm + 32 * i + r];
         bv[i] = lb[(2 * s + h) * FG_LD + wn + 32 * i + r];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (kc + 1 < nchunks) store_chunk(buf ^ 1);
@@ -174,9 +207,9 @@ fseq_gemm_kernel(FseqGemmArgs a) {
 
   // C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TM; ++j) {
       const int col = n0 + wn + 32 * j + r;
       if (col >= a.N) continue;
 #pragma unroll
@@ -209,19 +242,26 @@ int run_fseq_gemm(const void *x, int in_type, int64_t NB, const snnqp_conv_geom_
   a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.KH = g->KH; a.KW = g->KW;
   a.pad_h = g->pad_h_lo; a.pad_w = g->pad_w_lo;
   if (a.M == 0 || a.N == 0) return SNNQP_OK;
-  const int64_t gx = ceil_div64(a.M, FG_BM);
+  // the small tile when the large one would leave most of the chip idle
+  const int64_t big = ceil_div64(a.M, 128) * ((a.N + 127) / 128);
+  const int tm = big < 192 ? 1 : 2;
+  const int64_t gx = ceil_div64(a.M, 64 * tm);
   SNNQP_REQUIRE(gx < (1ll << 31), SNNQP_EINVAL, "fseq gemm: grid too large");
-  const dim3 grid((unsigned)gx, (unsigned)((a.N + FG_BN - 1) / FG_BN));
-  if (in_type == SNNQP_U8)
-    hipLaunchKernelGGL((fseq_gemm_kernel<2, SNNQP_U8>), grid, dim3(256), 0, st, a);
-  else if (in_type == SNNQP_BITS)
-    hipLaunchKernelGGL((fseq_gemm_kernel<2, SNNQP_BITS>), grid, dim3(256), 0, st, a);
-  else if (a.Cin % FG_KC == 0)
-    hipLaunchKernelGGL((fseq_gemm_kernel<0, SNNQP_F32>), grid, dim3(256), 0, st, a);
-  else if (a.Cin % 4 == 0)
-    hipLaunchKernelGGL((fseq_gemm_kernel<1, SNNQP_F32>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((fseq_gemm_kernel<2, SNNQP_F32>), grid, dim3(256), 0, st, a);
+  const dim3 grid((unsigned)gx, (unsigned)((a.N + 64 * tm - 1) / (64 * tm)));
+  const bool one = a.KH == 1 && a.KW == 1 && a.pad_h == 0 && a.pad_w == 0;    // k = channel, pixel = row
+#define SNNQP_FG_LAUNCH(MODE, IN)                                                                  \
+  do {                                                                                             \
+    if (tm == 1) hipLaunchKernelGGL((fseq_gemm_kernel<MODE, IN, 1>), grid, dim3(256), 0, st, a);   \
+    else hipLaunchKernelGGL((fseq_gemm_kernel<MODE, IN, 2>), grid, dim3(256), 0, st, a);           \
+  } while (0)
+  if (in_type == SNNQP_U8 && one && a.Cin % 8 == 0 && ((uintptr_t)x & 7) == 0) SNNQP_FG_LAUNCH(3, SNNQP_U8);
+  else if (in_type == SNNQP_BITS && one) SNNQP_FG_LAUNCH(3, SNNQP_BITS);
+  else if (in_type == SNNQP_U8) SNNQP_FG_LAUNCH(2, SNNQP_U8);
+  else if (in_type == SNNQP_BITS) SNNQP_FG_LAUNCH(2, SNNQP_BITS);
+  else if (a.Cin % FG_KC == 0) SNNQP_FG_LAUNCH(0, SNNQP_F32);
+  else if (a.Cin % 4 == 0) SNNQP_FG_LAUNCH(1, SNNQP_F32);
+  else SNNQP_FG_LAUNCH(2, SNNQP_F32);
+#undef SNNQP_FG_LAUNCH
   SNNQP_CHECK_LAUNCH("fseq_gemm_kernel");
   return SNNQP_OK;
 }
