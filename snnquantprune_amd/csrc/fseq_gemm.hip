@@ -53,9 +53,10 @@ struct FseqGemmArgs {
 // MODE 0: float32, Cin % 16 == 0 (a k chunk lies in one tap: one address computation)
 //      1: float32, Cin % 4 == 0 (runs of 4 channels)
 //      2: any type and Cin, element by element (the 2-channel event input; uint8; bits)
-//      3: uint8 rows / spike words into a 1 x 1 kernel (dense layers: k = channel, the pixel is
-//         the row): eight bytes or eight bits per load, no tap arithmetic -- unquantised dense
-//         blocks on integer-typed rows (config C1) spent their time in MODE 2's divisions
+//      3: uint8 / spike words, one tap per chunk -- a 1 x 1 kernel (dense layers: k = channel, the
+//         pixel is the row) or Cin % 16 == 0: four or eight bytes / bits per load, at most one tap
+//         decode per chunk -- unquantised blocks on integer-typed activations (config C1, the
+//         float32 baseline nets) spent their time in MODE 2's two divisions per element
 template <int IN> __device__ __forceinline__ float fg_load(const void *x, int64_t pix, int c, int Cin) {
   if (IN == SNNQP_F32) return ((const float *)x)[pix * Cin + c];
   if (IN == SNNQP_U8) return (float)((const uint8_t *)x)[pix * Cin + c];
@@ -102,16 +103,28 @@ fseq_gemm_kernel(FseqGemmArgs a) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) ra[j] = ok ? *(const v4f *)(src + 4 * j) : v4f{0.f, 0.f, 0.f, 0.f};
     } else if (MODE == 3) {
-      const int kk = k0 + ak;                    // a multiple of EPT; Cin % 8 == 0 (U8) / any (BITS)
+      // one tap per chunk: a 1 x 1 kernel (k = channel, the pixel is the row; any Cin), or
+      // Cin % 16 == 0 (a chunk of 16 k lies in one tap, as MODE 0)
+      int64_t pix = am;
+      int kk = k0 + ak;                          // channel of the thread's first element, a multiple of EPT
+      bool ok = arow && kk < a.K;
+      if (!(a.KH == 1 && a.KW == 1)) {
+        const int tap = k0 / a.Cin;
+        kk = k0 - tap * a.Cin + ak;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int iy = oy + kh - a.pad_h, ix = ox + kw - a.pad_w;
+        ok = arow && k0 < a.K && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        pix = (img * a.H + iy) * a.W + ix;
+      }
       uint32_t q[TM];                            // EPT values, a byte each
 #pragma unroll
       for (int j = 0; j < TM; ++j) q[j] = 0;
-      if (arow && kk < a.K) {
+      if (ok) {
         if (IN == SNNQP_U8) {
 #pragma unroll
-          for (int j = 0; j < TM; ++j) q[j] = *(const uint32_t *)((const uint8_t *)a.x + am * a.Cin + kk + 4 * j);
+          for (int j = 0; j < TM; ++j) q[j] = *(const uint32_t *)((const uint8_t *)a.x + pix * a.Cin + kk + 4 * j);
         } else {
-          const uint32_t w = ((const uint32_t *)a.x)[am * ((a.Cin + 31) >> 5) + (kk >> 5)] >> (kk & 31);
+          const uint32_t w = ((const uint32_t *)a.x)[pix * ((a.Cin + 31) >> 5) + (kk >> 5)] >> (kk & 31);
 #pragma unroll
           for (int j = 0; j < TM; ++j) q[j] = (((w >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u;
         }
@@ -254,8 +267,9 @@ int run_fseq_gemm(const void *x, int in_type, int64_t NB, const snnqp_conv_geom_
     if (tm == 1) hipLaunchKernelGGL((fseq_gemm_kernel<MODE, IN, 1>), grid, dim3(256), 0, st, a);   \
     else hipLaunchKernelGGL((fseq_gemm_kernel<MODE, IN, 2>), grid, dim3(256), 0, st, a);           \
   } while (0)
-  if (in_type == SNNQP_U8 && one && a.Cin % 8 == 0 && ((uintptr_t)x & 7) == 0) SNNQP_FG_LAUNCH(3, SNNQP_U8);
-  else if (in_type == SNNQP_BITS && one) SNNQP_FG_LAUNCH(3, SNNQP_BITS);
+  const bool tapwise = a.Cin % FG_KC == 0;     // a k chunk lies in one tap
+  if (in_type == SNNQP_U8 && ((one && a.Cin % 8 == 0) || tapwise) && ((uintptr_t)x & 7) == 0) SNNQP_FG_LAUNCH(3, SNNQP_U8);
+  else if (in_type == SNNQP_BITS && (one || tapwise)) SNNQP_FG_LAUNCH(3, SNNQP_BITS);
   else if (in_type == SNNQP_U8) SNNQP_FG_LAUNCH(2, SNNQP_U8);
   else if (in_type == SNNQP_BITS) SNNQP_FG_LAUNCH(2, SNNQP_BITS);
   else if (a.Cin % FG_KC == 0) SNNQP_FG_LAUNCH(0, SNNQP_F32);
