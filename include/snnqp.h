@@ -197,7 +197,7 @@ typedef struct {
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
  * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if,
- * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max / ch_slots).  A binding compares snnqp_version()
+ * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max / ch_slots, the *_gated_*_ex pack calls).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 501
 int snnqp_version(void);
@@ -326,14 +326,23 @@ int snnqp_conv3d_lif_forward(const int32_t *pred, const void *x, int in_type, in
  *     acc[p][o]  = fmaf(gate[c], I[p][c][o], acc[p][o])   for c = 0 .. Cin - 1, from +0
  *     y[p][o]    = fl(fl(acc / L) * m)
  * s     [NB][H][W][ceil(Cin / 32)] spike words (SNNQP_BITS), gate [NB][Cin] float32,
- * y     float32 [NB][H][W][Cout].  w: SNNQP_W_I8 codes with code_max <= 7 (DuQ up to 4 bits),
- * HWIO; packed: the same codes as snnqp_pack_codes_gated lays them out
+ * y     float32 [NB][H][W][Cout].  w: SNNQP_W_I8 codes with code_max <= 7 (DuQ up to 4 bits; up to
+ * 127 with the _ex pack below), HWIO; packed: the same codes as snnqp_pack_codes_gated lays them out
  * (snnqp_conv_gated_packed_bytes bytes).  Cin in {32, 64, 96, 128}; any H, W, Cout.
  * SNNQP_EUNSUPPORTED otherwise: the caller multiplies (snnqp_apply_gate) and takes the float32
  * connection (snnqp_conv_forward). */
 int64_t snnqp_conv_gated_packed_bytes(int32_t Cin, int32_t Cout);
 int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *packed,
                            snnqp_stream_t stream);
+/* Codes beyond fp6 (code_max = max |code| up to 127: DuQ up to 8 bits, the reference's shipped TCJA
+ * configs): packed as two fp8 digits, code = 16 hi + lo, in the two K blocks of the matrix
+ * instruction with a block scale of 2^4 on the second -- one instruction still returns the exact
+ * integer sum of a channel's taps.  The _ex forms take code_max (<= 7: the fp6 layout above);
+ * snnqp_conv_gated_forward picks the kernel by w->code_max, `packed` must come from the pack call
+ * with the same code_max. */
+int64_t snnqp_conv_gated_packed_bytes_ex(int32_t Cin, int32_t Cout, int32_t code_max);
+int snnqp_pack_codes_gated_ex(const int8_t *w, int32_t Cin, int32_t Cout, int32_t code_max,
+                              void *packed, snnqp_stream_t stream);
 int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
                              const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
                              const void *packed, float *y, snnqp_stream_t stream);
@@ -351,6 +360,10 @@ int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
 int64_t snnqp_dense_gated_packed_bytes(int32_t C, int32_t N);
 int snnqp_pack_codes_dense_gated(const int8_t *w, int32_t C, int32_t HW, int32_t N, void *packed,
                                  snnqp_stream_t stream);
+/* (codes up to 127 as two fp8 digits, as snnqp_pack_codes_gated_ex: the _ex forms take code_max) */
+int64_t snnqp_dense_gated_packed_bytes_ex(int32_t C, int32_t N, int32_t code_max);
+int snnqp_pack_codes_dense_gated_ex(const int8_t *w, int32_t C, int32_t HW, int32_t N, int32_t code_max,
+                                    void *packed, snnqp_stream_t stream);
 int snnqp_dense_gated_forward(const uint32_t *s, const float *gate, int64_t NB, int32_t HW,
                               int32_t C, int32_t N, const snnqp_weight_t *w,
                               const void *packed, float *y, snnqp_stream_t stream);

@@ -99,10 +99,14 @@ _PROTOTYPES = {
         POINTER(WeightT), POINTER(BnT), POINTER(NeuronT), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snnqp_conv_gated_packed_bytes": (c_int64, [c_int32, c_int32]),
     "snnqp_pack_codes_gated": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "snnqp_conv_gated_packed_bytes_ex": (c_int64, [c_int32, c_int32, c_int32]),
+    "snnqp_pack_codes_gated_ex": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_conv_gated_forward": (c_int, [c_void_p, c_void_p, c_int64, POINTER(ConvGeomT),
                                          POINTER(WeightT), c_void_p, c_void_p, c_void_p]),
     "snnqp_dense_gated_packed_bytes": (c_int64, [c_int32, c_int32]),
     "snnqp_pack_codes_dense_gated": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "snnqp_dense_gated_packed_bytes_ex": (c_int64, [c_int32, c_int32, c_int32]),
+    "snnqp_pack_codes_dense_gated_ex": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "snnqp_dense_gated_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                           POINTER(WeightT), c_void_p, c_void_p, c_void_p]),
     "snnqp_conv_lif_forward": (c_int, [

@@ -20,6 +20,8 @@
 //     MFMA from C = 0, then acc = fmaf(gate[c], result, acc) -- gate[c] is a scalar register;
 //  3. dequantise, store float32 currents [NB][H][W][Cout] (BatchNorm and the neuron follow as
 //     the stand-alone scan, as behind the float32 connection).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace snnqp {
@@ -77,11 +79,49 @@ pack_codes_gated_kernel(const int8_t *w, int32_t C, int32_t Cout, int32_t OT, ui
   }
 }
 
+// integer -8..8 -> OCP fp8 e4m3 (bias 7: 1 = 0x38, 2 = 0x40, 3 = 0x44, 4 = 0x48, 5 = 0x4A, 6 = 0x4C,
+// 7 = 0x4E, 8 = 0x50)
+__device__ __forceinline__ uint32_t enc8(int v) {
+  const uint32_t mag = (uint32_t)(v < 0 ? -v : v);
+  const uint32_t tab[9] = {0x00u, 0x38u, 0x40u, 0x44u, 0x48u, 0x4Au, 0x4Cu, 0x4Eu, 0x50u};
+  return tab[mag] | (v < 0 ? 0x80u : 0u);
+}
+// Codes beyond fp6 (|code| <= 127: up to 8 bits) as TWO fp8 digits, code = 16 hi + lo with lo in
+// [-8, 7], hi in [-8, 8], one digit per 32-deep K block of the 64-deep instruction: the block scale
+// of the second block is 2^4 (v_mfma_scale: an E8M0 scale per lane half = per block), so ONE
+// instruction returns sum(lo s) + 16 sum(hi s): the exact integer, and no vector instruction more
+// than with fp6.  With a 4-bit and an 8-bit operand the two count k differently
+// (tools/ubench/mfma_fp8_kmap.hip): fp4 lane (r, h) position j is k = 32 h + j, fp8 lane (r, h)
+// byte j is k = 32 (j >> 4) + 16 h + (j & 15) -- K block 0 is bytes 0..15 of both lane halves.  The
+// nine taps sit at k = 0..8 and k = 32..40: fp4 nibbles 0..8 of BOTH lane halves, fp8 bytes 0..8
+// (lo) and 16..24 (hi) of the lanes of half 0; the lanes of half 1 hold zeros.
+// bp8 = 8 zero dwords (what the lanes of half 1 read), then [c][ot][n][8 dwords].
+__global__ void __launch_bounds__(256)
+pack_codes_gated_wide_kernel(const int8_t *w, int32_t C, int32_t Cout, int32_t OT, uint32_t *bp) {
+  const int64_t total = (int64_t)C * OT * 32;
+  if (blockIdx.x == 0 && threadIdx.x < 8) bp[threadIdx.x] = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i & 31);
+    const int ot = (int)((i >> 5) % OT), c = (int)((i >> 5) / OT);
+    const int o = ot * 32 + n;
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (o < Cout) {
+      for (int tap = 0; tap < 9; ++tap) {
+        const int code = w[((int64_t)tap * C + c) * Cout + o];
+        const int lo = ((code + 8) & 15) - 8, hi = (code - lo) / 16;
+        d[tap >> 2] |= enc8(lo) << (8 * (tap & 3));
+        d[4 + (tap >> 2)] |= enc8(hi) << (8 * (tap & 3));
+      }
+    }
+    for (int j = 0; j < 8; ++j) bp[8 + i * 8 + j] = d[j];
+  }
+}
+
 // NT: output tiles (of 32) this launch's workgroups hold -- a template parameter, so that the four
 // matrix instructions of a channel and their 64 fmaf are one basic block the scheduler can
 // overlap (with a run-time count every instruction sat in a block of its own, waited for alone:
 // 1.48 ms for CextNet's layer, against ... with this)
-template <int NT>
+template <int NT, bool WIDE = false>
 __global__ void __launch_bounds__(CG_WAVES * 64, 2)
 conv_gated_kernel(ConvGatedArgs a) {
   __shared__ uint32_t At[CG_WAVES][CG_CMAX][32];
@@ -134,21 +174,40 @@ conv_gated_kernel(ConvGatedArgs a) {
   for (int t = 0; t < 4; ++t) acc[t] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float *grow = a.gate + img * a.C;             // wave-uniform: scalar loads
-  const uint32_t *bpl = a.bp + ((int64_t)ot0 * 64 + lane) * 2;
-  // four channels per group; the codes of the next group are requested before this group's
-  // matrix instructions (an L2 round trip per group would otherwise sit in front of every one)
+  // four channels per group (one with the wide codes: eight operand dwords per lane); the codes of
+  // the next group are requested before this group's matrix instructions (an L2 round trip per
+  // group would otherwise sit in front of every one)
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-  constexpr int GC = 4;
-  u2 bcur[GC][4], bnxt[GC][4];
-  auto load_group = [&](u2 (&dst)[GC][4], int c0) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  struct u8w { u4 lo, hi; };
+  typedef typename std::conditional<WIDE, u8w, u2>::type bvec;
+  constexpr int GC = WIDE ? 1 : 4;
+  // fp6: lane (n, h) reads its two dwords; wide: the lanes of half 0 read their record of eight, the
+  // lanes of half 1 the zero block at the head of the buffer (stride 0)
+  const uint32_t *bpl = WIDE ? (h ? a.bp : a.bp + 8 + ((int64_t)ot0 * 32 + n) * 8)
+                             : a.bp + ((int64_t)ot0 * 64 + lane) * 2;
+  const int64_t cstride = WIDE ? (h ? 0 : (int64_t)a.OT * 256) : (int64_t)a.OT * 128;
+  const int tstride = WIDE ? (h ? 0 : 256) : 128;
+  bvec bcur[GC][4], bnxt[GC][4];
+  auto load_group = [&](bvec (&dst)[GC][4], int c0) {
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       const int c = min(c0 + j, a.C - 1);
-      const uint32_t *bc = bpl + (int64_t)c * a.OT * 128;
+      const uint32_t *bc = bpl + (int64_t)c * cstride;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) dst[j][t] = *(const u2 *)(bc + (t < nt ? t : 0) * 128);
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t *bt = bc + (t < nt ? t : 0) * tstride;
+        if constexpr (WIDE) {
+          dst[j][t].lo = *(const u4 *)bt;
+          dst[j][t].hi = *(const u4 *)(bt + 4);
+        } else {
+          dst[j][t] = *(const u2 *)bt;
+        }
+      }
     }
   };
+  // WIDE: the E8M0 scale of B's K block h comes from the lanes of half h: 2^0 (lo digits), 2^4 (hi)
+  const int sb = WIDE ? (h ? 131 : 127) : 127;
   load_group(bcur, 0);
   // the gates of a group are requested a group ahead as well (scalar loads: their latency would
   // otherwise sit in front of the group's first fmaf)
@@ -166,13 +225,24 @@ conv_gated_kernel(ConvGatedArgs a) {
       const uint32_t d0 = At[wave][c][n];
       // lanes of half 1 hold k = 32 ..: tap 8 in nibble 0 (fp4 1.0 = 0b0010)
       const uint32_t t8 = ((w8[(c >> 5) & (CG_CMAX / 32 - 1)] >> (c & 31)) & 1u) << 1;
-      const v8i A = {(int)(h ? t8 : d0), 0, 0, 0, 0, 0, 0, 0};
+      // fp6: tap 8 is k = 32 (lane half 1); WIDE: both halves hold the nine taps (k = 0..8 of
+      // their block), against the lo and the hi digits
+      const v8i A = WIDE ? v8i{(int)d0, (int)t8, 0, 0, 0, 0, 0, 0} : v8i{(int)(h ? t8 : d0), 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (t < nt) {
-          const v8i B = {(int)bcur[j][t].x, (int)bcur[j][t].y, 0, 0, 0, 0, 0, 0};
-          const v16f I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 4 /* fp4 */, 2 /* fp6 */,
-                                                                           0, 127, 0, 127);
+          v8i B;
+          v16f I;
+          if constexpr (WIDE) {
+            B = v8i{(int)bcur[j][t].lo.x, (int)bcur[j][t].lo.y, (int)bcur[j][t].lo.z, 0,
+                    (int)bcur[j][t].hi.x, (int)bcur[j][t].hi.y, (int)bcur[j][t].hi.z, 0};
+            I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 4 /* fp4 */, 0 /* fp8 e4m3 */,
+                                                                0, 127, 0, sb);
+          } else {
+            B = v8i{(int)bcur[j][t].x, (int)bcur[j][t].y, 0, 0, 0, 0, 0, 0};
+            I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 4 /* fp4 */, 2 /* fp6 */,
+                                                                0, 127, 0, 127);
+          }
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(g[j], I[i], acc[t][i]);
         }
@@ -206,7 +276,7 @@ conv_gated_kernel(ConvGatedArgs a) {
 
 const char *conv_gated_unsupported(const snnqp_conv_geom_t *g, const snnqp_weight_t *w) {
   if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
-  if (!(w->code_max > 0 && w->code_max <= 7)) return "codes beyond +-7 (fp6)";
+  if (!(w->code_max > 0 && w->code_max <= 127)) return "unknown code range (code_max)";
   if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1) return "not 3x3 / stride 1";
   if (g->pad_h_lo != 1 || g->pad_h_hi != 1 || g->pad_w_lo != 1 || g->pad_w_hi != 1) return "padding is not 1";
   if (g->in_dil_h != 1 || g->in_dil_w != 1 || g->k_dil_h != 1 || g->k_dil_w != 1 || g->groups != 1)
@@ -218,22 +288,35 @@ const char *conv_gated_unsupported(const snnqp_conv_geom_t *g, const snnqp_weigh
 
 }  // namespace snnqp
 
+extern "C" int64_t snnqp_conv_gated_packed_bytes_ex(int32_t Cin, int32_t Cout, int32_t code_max) {
+  if (Cin <= 0 || Cout <= 0 || code_max <= 0 || code_max > 127) return 0;
+  if (code_max <= 7) return (int64_t)Cin * ((Cout + 31) / 32) * 64 * 2 * 4;
+  return 32 + (int64_t)Cin * ((Cout + 31) / 32) * 32 * 8 * 4;
+}
 extern "C" int64_t snnqp_conv_gated_packed_bytes(int32_t Cin, int32_t Cout) {
-  if (Cin <= 0 || Cout <= 0) return 0;
-  return (int64_t)Cin * ((Cout + 31) / 32) * 64 * 2 * 4;
+  return snnqp_conv_gated_packed_bytes_ex(Cin, Cout, 7);
 }
 
-extern "C" int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *packed,
-                                      snnqp_stream_t stream) {
+extern "C" int snnqp_pack_codes_gated_ex(const int8_t *w, int32_t Cin, int32_t Cout, int32_t code_max,
+                                         void *packed, snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(w && packed && Cin > 0 && Cout > 0, SNNQP_EINVAL, "pack_codes_gated: bad argument");
+  SNNQP_REQUIRE(w && packed && Cin > 0 && Cout > 0 && code_max > 0 && code_max <= 127, SNNQP_EINVAL,
+                "pack_codes_gated: bad argument");
   const int OT = (Cout + 31) / 32;
   const int64_t total = (int64_t)Cin * OT * 64;
   const int64_t blocks = (total + 255) / 256;
-  hipLaunchKernelGGL(pack_codes_gated_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
-                     (hipStream_t)stream, w, Cin, Cout, OT, (uint32_t *)packed);
+  if (code_max <= 7)
+    hipLaunchKernelGGL(pack_codes_gated_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, Cin, Cout, OT, (uint32_t *)packed);
+  else
+    hipLaunchKernelGGL(pack_codes_gated_wide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, Cin, Cout, OT, (uint32_t *)packed);
   SNNQP_CHECK_LAUNCH("pack_codes_gated_kernel");
   return SNNQP_OK;
+}
+extern "C" int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *packed,
+                                      snnqp_stream_t stream) {
+  return snnqp_pack_codes_gated_ex(w, Cin, Cout, 7, packed, stream);
 }
 
 extern "C" int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
@@ -258,16 +341,23 @@ extern "C" int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, in
   SNNQP_REQUIRE(gx < ((int64_t)1 << 31), SNNQP_EUNSUPPORTED, "conv_gated_forward: more than 2^31 workgroups");
   // full groups of four output tiles, then the remainder (its blockIdx.y = 0 is tile group OT / 4)
   const int full = a.OT / 4, rest = a.OT % 4;
-  if (full > 0)
-    hipLaunchKernelGGL(conv_gated_kernel<4>, dim3((unsigned)gx, (unsigned)full), dim3(CG_WAVES * 64), 0,
-                       (hipStream_t)stream, a);
+  const bool wide = w->code_max > 7;          // two fp8 digits per code (packed by snnqp_pack_codes_gated_ex)
+#define SNNQP_CG_LAUNCH(NTV, ARGS, GY)                                                                  \
+  do {                                                                                                  \
+    if (wide) hipLaunchKernelGGL((conv_gated_kernel<NTV, true>), dim3((unsigned)gx, (unsigned)(GY)),     \
+                                 dim3(CG_WAVES * 64), 0, (hipStream_t)stream, ARGS);                    \
+    else hipLaunchKernelGGL((conv_gated_kernel<NTV, false>), dim3((unsigned)gx, (unsigned)(GY)),         \
+                            dim3(CG_WAVES * 64), 0, (hipStream_t)stream, ARGS);                         \
+  } while (0)
+  if (full > 0) SNNQP_CG_LAUNCH(4, a, full);
   if (rest > 0) {
     ConvGatedArgs b = a;
     b.ot_base = full * 4;
-    if (rest == 1) hipLaunchKernelGGL(conv_gated_kernel<1>, dim3((unsigned)gx, 1u), dim3(CG_WAVES * 64), 0, (hipStream_t)stream, b);
-    else if (rest == 2) hipLaunchKernelGGL(conv_gated_kernel<2>, dim3((unsigned)gx, 1u), dim3(CG_WAVES * 64), 0, (hipStream_t)stream, b);
-    else hipLaunchKernelGGL(conv_gated_kernel<3>, dim3((unsigned)gx, 1u), dim3(CG_WAVES * 64), 0, (hipStream_t)stream, b);
+    if (rest == 1) SNNQP_CG_LAUNCH(1, b, 1);
+    else if (rest == 2) SNNQP_CG_LAUNCH(2, b, 1);
+    else SNNQP_CG_LAUNCH(3, b, 1);
   }
+#undef SNNQP_CG_LAUNCH
   SNNQP_CHECK_LAUNCH("conv_gated_kernel");
   return SNNQP_OK;
 }

@@ -17,6 +17,8 @@
 // its images are transposed once into LDS as B-operand dwords (Bt[c][image] = the fp4 nibbles of
 // the positions of channel c) beside the gates (Gt[c][image]); the fp6 codes come pre-packed per
 // (channel, 32 outputs).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace snnqp {
@@ -73,6 +75,38 @@ pack_codes_dense_gated_kernel(const int8_t *w, int32_t C, int32_t HW, int32_t N,
   }
 }
 
+// Codes beyond fp6 (|code| <= 127) as two fp8 digits, code = 16 hi + lo (conv_gated.hip: the layout of
+// a 4-bit beside an 8-bit operand, the 2^4 block scale on the second K block): the sixteen positions
+// sit at k = 0..15 (lo) and k = 32..47 (hi) -- fp8 bytes 0..15 and 16..31 of the lanes of half 0 (the
+// codes are the A operand here), fp4 nibbles 0..15 of BOTH lane halves of the spike operand.
+// ap8 = 8 zero dwords (what the lanes of half 1 read), then [c][ot][n][8 dwords].
+__device__ __forceinline__ uint32_t dg_enc8(int v) {      // integer -8..8 -> OCP fp8 e4m3
+  const uint32_t mag = (uint32_t)(v < 0 ? -v : v);
+  const uint32_t tab[9] = {0x00u, 0x38u, 0x40u, 0x44u, 0x48u, 0x4Au, 0x4Cu, 0x4Eu, 0x50u};
+  return tab[mag] | (v < 0 ? 0x80u : 0u);
+}
+__global__ void __launch_bounds__(256)
+pack_codes_dense_gated_wide_kernel(const int8_t *w, int32_t C, int32_t HW, int32_t N, int32_t OT, uint32_t *ap) {
+  const int64_t total = (int64_t)C * OT * 32;
+  if (blockIdx.x == 0 && threadIdx.x < 8) ap[threadIdx.x] = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i & 31);
+    const int ot = (int)((i >> 5) % OT), c = (int)((i >> 5) / OT);
+    const int o = ot * 32 + n;
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (o < N) {
+      for (int p = 0; p < HW; ++p) {
+        const int code = w[((int64_t)c * HW + p) * N + o];
+        const int lo = ((code + 8) & 15) - 8, hi = (code - lo) / 16;
+        d[p >> 2] |= dg_enc8(lo) << (8 * (p & 3));
+        d[4 + (p >> 2)] |= dg_enc8(hi) << (8 * (p & 3));
+      }
+    }
+    for (int j = 0; j < 8; ++j) ap[8 + i * 8 + j] = d[j];
+  }
+}
+
+template <bool WIDE>
 __global__ void __launch_bounds__(256, 2)
 dense_gated_kernel(DenseGatedArgs a) {
   __shared__ u2 Bt[DG_CMAX][32];
@@ -116,15 +150,30 @@ dense_gated_kernel(DenseGatedArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const v4i *apl = (const v4i *)a.ap + (int64_t)ot0 * 64 + lane;
-  constexpr int GC = 4;
-  v4i acur[GC][4], anxt[GC][4];
-  auto load_group = [&](v4i (&dst)[GC][4], int c0) {
+  struct v8w { v4i lo, hi; };
+  typedef typename std::conditional<WIDE, v8w, v4i>::type avec;
+  // fp6: lane (o, h) reads its four dwords; wide: the lanes of half 0 their record of eight, the lanes
+  // of half 1 the zero block at the head of the buffer (stride 0)
+  const v4i *apl = WIDE ? (const v4i *)(h ? a.ap : a.ap + 8 + ((int64_t)ot0 * 32 + n) * 8)
+                        : (const v4i *)a.ap + (int64_t)ot0 * 64 + lane;
+  const int64_t tstride = WIDE ? (h ? 0 : 64) : 64;       // v4i units between output tiles
+  const int sa = WIDE ? (h ? 131 : 127) : 127;             // E8M0 scale of A's K block h: 2^0 / 2^4
+  constexpr int GC = WIDE ? 1 : 4;
+  avec acur[GC][4], anxt[GC][4];
+  auto load_group = [&](avec (&dst)[GC][4], int c0) {
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       const int c = min(c0 + j, a.C - 1);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) dst[j][t] = apl[((int64_t)c * a.OT + min(t, a.OT - 1 - ot0)) * 64];
+      for (int t = 0; t < 4; ++t) {
+        const v4i *at = apl + ((int64_t)c * a.OT + min(t, a.OT - 1 - ot0)) * tstride;
+        if constexpr (WIDE) {
+          dst[j][t].lo = at[0];
+          dst[j][t].hi = at[1];
+        } else {
+          dst[j][t] = at[0];
+        }
+      }
     }
   };
   load_group(acur, 0);
@@ -135,12 +184,22 @@ dense_gated_kernel(DenseGatedArgs a) {
       const int c = c0 + j;
       const u2 bb = Bt[c][n];
       const float g = Gt[c][n];
-      const v8i B = {(int)(h ? 0u : bb.x), (int)(h ? 0u : bb.y), 0, 0, 0, 0, 0, 0};
+      // fp6: the positions are k = 0..15 (lane half 0); wide: k = 0..15 and k = 32..47 -- both halves
+      const v8i B = WIDE ? v8i{(int)bb.x, (int)bb.y, 0, 0, 0, 0, 0, 0}
+                         : v8i{(int)(h ? 0u : bb.x), (int)(h ? 0u : bb.y), 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const v8i A = {acur[j][t].x, acur[j][t].y, acur[j][t].z, 0, 0, 0, 0, 0};
-        const v16f I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 2 /* A: fp6 */, 4 /* B: fp4 */,
-                                                                         0, 127, 0, 127);
+        v16f I;
+        if constexpr (WIDE) {
+          const v8i A = {acur[j][t].lo.x, acur[j][t].lo.y, acur[j][t].lo.z, acur[j][t].lo.w,
+                         acur[j][t].hi.x, acur[j][t].hi.y, acur[j][t].hi.z, acur[j][t].hi.w};
+          I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 0 /* A: fp8 e4m3 */, 4 /* B: fp4 */,
+                                                              0, sa, 0, 127);
+        } else {
+          const v8i A = {acur[j][t].x, acur[j][t].y, acur[j][t].z, 0, 0, 0, 0, 0};
+          I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 2 /* A: fp6 */, 4 /* B: fp4 */,
+                                                              0, 127, 0, 127);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(g, I[i], acc[t][i]);
       }
@@ -172,7 +231,7 @@ dense_gated_kernel(DenseGatedArgs a) {
 
 const char *dense_gated_unsupported(int32_t HW, int32_t C, int32_t N, const snnqp_weight_t *w) {
   if (w->wtype != SNNQP_W_I8) return "weights are not int8 codes";
-  if (!(w->code_max > 0 && w->code_max <= 7)) return "codes beyond +-7 (fp6)";
+  if (!(w->code_max > 0 && w->code_max <= 127)) return "unknown code range (code_max)";
   if (HW < 1 || HW > DG_PMAX) return "more than 16 positions per channel";
   if (C < 32 || C > DG_CMAX || C % 32) return "channels not 32, 64, 96 or 128";
   if (N < 1) return "no outputs";
@@ -181,23 +240,35 @@ const char *dense_gated_unsupported(int32_t HW, int32_t C, int32_t N, const snnq
 
 }  // namespace snnqp
 
+extern "C" int64_t snnqp_dense_gated_packed_bytes_ex(int32_t C, int32_t N, int32_t code_max) {
+  if (C <= 0 || N <= 0 || code_max <= 0 || code_max > 127) return 0;
+  if (code_max <= 7) return (int64_t)C * ((N + 31) / 32) * 64 * 4 * 4;
+  return 32 + (int64_t)C * ((N + 31) / 32) * 32 * 8 * 4;
+}
 extern "C" int64_t snnqp_dense_gated_packed_bytes(int32_t C, int32_t N) {
-  if (C <= 0 || N <= 0) return 0;
-  return (int64_t)C * ((N + 31) / 32) * 64 * 4 * 4;
+  return snnqp_dense_gated_packed_bytes_ex(C, N, 7);
 }
 
-extern "C" int snnqp_pack_codes_dense_gated(const int8_t *w, int32_t C, int32_t HW, int32_t N, void *packed,
-                                            snnqp_stream_t stream) {
+extern "C" int snnqp_pack_codes_dense_gated_ex(const int8_t *w, int32_t C, int32_t HW, int32_t N, int32_t code_max,
+                                               void *packed, snnqp_stream_t stream) {
   using namespace snnqp;
-  SNNQP_REQUIRE(w && packed && C > 0 && HW > 0 && HW <= DG_PMAX && N > 0, SNNQP_EINVAL,
-                "pack_codes_dense_gated: bad argument");
+  SNNQP_REQUIRE(w && packed && C > 0 && HW > 0 && HW <= DG_PMAX && N > 0 && code_max > 0 && code_max <= 127,
+                SNNQP_EINVAL, "pack_codes_dense_gated: bad argument");
   const int OT = (N + 31) / 32;
   const int64_t total = (int64_t)C * OT * 64;
   const int64_t blocks = (total + 255) / 256;
-  hipLaunchKernelGGL(pack_codes_dense_gated_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
-                     (hipStream_t)stream, w, C, HW, N, OT, (uint32_t *)packed);
+  if (code_max <= 7)
+    hipLaunchKernelGGL(pack_codes_dense_gated_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, C, HW, N, OT, (uint32_t *)packed);
+  else
+    hipLaunchKernelGGL(pack_codes_dense_gated_wide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256),
+                       0, (hipStream_t)stream, w, C, HW, N, OT, (uint32_t *)packed);
   SNNQP_CHECK_LAUNCH("pack_codes_dense_gated_kernel");
   return SNNQP_OK;
+}
+extern "C" int snnqp_pack_codes_dense_gated(const int8_t *w, int32_t C, int32_t HW, int32_t N, void *packed,
+                                            snnqp_stream_t stream) {
+  return snnqp_pack_codes_dense_gated_ex(w, C, HW, N, 7, packed, stream);
 }
 
 extern "C" int snnqp_dense_gated_forward(const uint32_t *s, const float *gate, int64_t NB, int32_t HW,
@@ -216,8 +287,12 @@ extern "C" int snnqp_dense_gated_forward(const uint32_t *s, const float *gate, i
   a.L = w->L; a.m = w->m;
   const int64_t gx = (NB + 31) / 32;
   SNNQP_REQUIRE(gx < ((int64_t)1 << 31), SNNQP_EUNSUPPORTED, "dense_gated_forward: more than 2^31 workgroups");
-  hipLaunchKernelGGL(dense_gated_kernel, dim3((unsigned)gx, (unsigned)((a.OT + 15) / 16)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (w->code_max > 7)          // two fp8 digits per code (packed by snnqp_pack_codes_dense_gated_ex)
+    hipLaunchKernelGGL(dense_gated_kernel<true>, dim3((unsigned)gx, (unsigned)((a.OT + 15) / 16)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(dense_gated_kernel<false>, dim3((unsigned)gx, (unsigned)((a.OT + 15) / 16)), dim3(256), 0,
+                       (hipStream_t)stream, a);
   SNNQP_CHECK_LAUNCH("dense_gated_kernel");
   return SNNQP_OK;
 }

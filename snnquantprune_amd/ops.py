@@ -729,15 +729,16 @@ def conv_forward_speculative(x: torch.Tensor, geom: ConvGeom, int_weight: Weight
   return y
 
 
-def pack_codes_gated(codes: torch.Tensor) -> torch.Tensor:
-  """int8 HWIO codes [3, 3, Cin, Cout] of magnitude <= 7 -> the fp6 operand layout of
-  conv_gated_forward (snnqp_pack_codes_gated)."""
+def pack_codes_gated(codes: torch.Tensor, code_max: int = 7) -> torch.Tensor:
+  """int8 HWIO codes [3, 3, Cin, Cout] -> the operand layout of conv_gated_forward
+  (snnqp_pack_codes_gated_ex): fp6 for code_max <= 7, two fp8 digits per code up to 127."""
   _require_gpu(codes)
   assert codes.dtype == torch.int8 and codes.ndim == 4 and tuple(codes.shape[:2]) == (3, 3)
   codes = codes.contiguous()
   cin, cout = codes.shape[2], codes.shape[3]
-  out = torch.empty(int(L.lib().snnqp_conv_gated_packed_bytes(cin, cout)), dtype=torch.uint8, device=codes.device)
-  L.check(L.lib().snnqp_pack_codes_gated(_ptr(codes), cin, cout, _ptr(out), _stream()))
+  out = torch.empty(int(L.lib().snnqp_conv_gated_packed_bytes_ex(cin, cout, int(code_max))), dtype=torch.uint8,
+                    device=codes.device)
+  L.check(L.lib().snnqp_pack_codes_gated_ex(_ptr(codes), cin, cout, int(code_max), _ptr(out), _stream()))
   return out
 
 
@@ -756,15 +757,16 @@ def conv_gated_forward(x: GatedSpikes, geom: ConvGeom, weight: Weight, packed: t
   return y
 
 
-def pack_codes_dense_gated(codes: torch.Tensor, C: int, HW: int) -> torch.Tensor:
-  """int8 codes [C * HW, N] (rows channel-major) of magnitude <= 7 -> the fp6 operand layout of
-  dense_gated_forward (snnqp_pack_codes_dense_gated)."""
+def pack_codes_dense_gated(codes: torch.Tensor, C: int, HW: int, code_max: int = 7) -> torch.Tensor:
+  """int8 codes [C * HW, N] (rows channel-major) -> the operand layout of dense_gated_forward
+  (snnqp_pack_codes_dense_gated_ex): fp6 for code_max <= 7, two fp8 digits per code up to 127."""
   _require_gpu(codes)
   assert codes.dtype == torch.int8 and codes.ndim == 2 and codes.shape[0] == C * HW
   codes = codes.contiguous()
   N = codes.shape[1]
-  out = torch.empty(int(L.lib().snnqp_dense_gated_packed_bytes(C, N)), dtype=torch.uint8, device=codes.device)
-  L.check(L.lib().snnqp_pack_codes_dense_gated(_ptr(codes), C, HW, N, _ptr(out), _stream()))
+  out = torch.empty(int(L.lib().snnqp_dense_gated_packed_bytes_ex(C, N, int(code_max))), dtype=torch.uint8,
+                    device=codes.device)
+  L.check(L.lib().snnqp_pack_codes_dense_gated_ex(_ptr(codes), C, HW, N, int(code_max), _ptr(out), _stream()))
   return out
 
 

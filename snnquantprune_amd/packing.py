@@ -124,25 +124,25 @@ class PackedKernel:
     return self._int
 
   def gated_codes(self):
-    """The codes in the operand layout of ops.conv_gated_forward (3x3 kernels whose codes fit fp6),
-    or None."""
+    """The codes in the operand layout of ops.conv_gated_forward (3x3 kernels: fp6 for codes up to 7,
+    two fp8 digits per code up to 127), or None."""
     w = self.int_weight()
-    if w is None or self.kernel.ndim != 4 or tuple(self.kernel.shape[:2]) != (3, 3) or not (0 < w.code_max <= 7):
+    if w is None or self.kernel.ndim != 4 or tuple(self.kernel.shape[:2]) != (3, 3) or not (0 < w.code_max <= 127):
       return None
     if "_gated" not in self._wt:
-      self._wt["_gated"] = ops.pack_codes_gated(w.w)
+      self._wt["_gated"] = ops.pack_codes_gated(w.w, w.code_max)
     return self._wt["_gated"]
 
   def gated_dense_codes(self, C: int, HW: int):
     """The codes of a dense kernel [C * HW, N] in the operand layout of ops.dense_gated_forward
     (codes that fit fp6, HW <= 16), or None."""
     w = self.int_weight()
-    if (w is None or self.kernel.ndim != 2 or self.kernel.shape[0] != C * HW or not (0 < w.code_max <= 7)
+    if (w is None or self.kernel.ndim != 2 or self.kernel.shape[0] != C * HW or not (0 < w.code_max <= 127)
         or HW > 16 or C not in (32, 64, 96, 128)):
       return None
     key = ("_dgated", C, HW)
     if key not in self._wt:
-      self._wt[key] = ops.pack_codes_dense_gated(w.w, C, HW)
+      self._wt[key] = ops.pack_codes_dense_gated(w.w, C, HW, w.code_max)
     return self._wt[key]
 
   def float_weight(self) -> ops.Weight:

@@ -3297,8 +3297,9 @@ def test_float32_activations_through_the_narrowing_passes(dev, oracle):
 
 
 @pytest.mark.parametrize("shape", [(3, 2, 8, 8, 128, 128), (2, 3, 5, 11, 64, 70), (1, 2, 16, 16, 96, 160),
-                                   (2, 1, 4, 8, 32, 32)],
-                         ids=["cextnet_conv_t_1", "ragged_image_and_outputs", "96_in_160_out", "one_patch"])
+                                   (2, 1, 4, 8, 32, 32), (3, 2, 8, 8, 128, 128, 8), (2, 3, 5, 11, 64, 70, 6)],
+                         ids=["cextnet_conv_t_1", "ragged_image_and_outputs", "96_in_160_out", "one_patch",
+                              "cextnet_conv_t_1_8bit", "ragged_6bit"])
 def test_gated_conv_in_the_gint_form(dev, oracle, shape):
   """QuantConv 3x3 on gate x raster -- the conv block behind a TCJA gate
   (examples/tcja/models.py:95-97 -> :149-187) -- without multiplying the gate out: the nine taps of
@@ -3312,28 +3313,31 @@ def test_gated_conv_in_the_gint_form(dev, oracle, shape):
   from snnquantprune_amd.flax_qconv import QuantConv
   from snnquantprune_amd.quant import QuantDesc
   from snnquantprune_amd.spiking_learning import SpikingBlock
-  T, B, H, W, C, N = shape
-  leaf = syn.quant_leaf((3, 3, C, N), 5.0, 971, True, 0.9)
+  T, B, H, W, C, N = shape[:6]
+  bits = shape[6] if len(shape) > 6 else 4      # beyond 4 bits: two fp8 digits per code (code_max up to 127)
+  leaf = syn.quant_leaf((3, 3, C, N), 5.0, 971, True, 0.9 if bits == 4 else 0.3)
   bp, bs = syn.bn_leaf(N, True, 972)
   bn = dict(mean=bs["mean"], var=bs["var"], scale=bp["scale"], bias=bp["bias"])
-  qw = qweight_of(oracle, leaf, 4)
+  qw = qweight_of(oracle, leaf, bits)
   rng = np.random.Generator(np.random.PCG64(H * W + C))
   s = (rng.random((T, B, H, W, C)) < 0.2).astype(np.uint8)
   gate = (1.0 / (1.0 + np.exp(-rng.standard_normal((T, B, C)) * 1.5))).astype(F32)
   a, c = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
-  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, 4, a, c, 7.0, c), _t(leaf["prune_0"]["mask"], dev))
+  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, bits, a, c, float(2 ** (bits - 1) - 1), c),
+                            _t(leaf["prune_0"]["mask"], dev))
   w = pk.int_weight()
+  assert (w.code_max > 7) == (bits > 4)
   geom = ops.ConvGeom(H, W, C, N, 3, 3, (1, 1), ((1, 1), (1, 1)))
   x = ops.GatedSpikes(ops.pack_bits(_t(s, dev)), _t(gate, dev))
   y = ops.conv_gated_forward(x, geom, w, pk.gated_codes())
   ey = np.stack([oracle.gated_conv(s[t].astype(F32), gate[t], qw) for t in range(T)])
   np.testing.assert_array_equal(_np(y), ey)
-  assert 0.3 < np.abs(ey).max() < 50.0
+  assert 0.3 < np.abs(ey).max() < 200.0
   # the block, as the model calls it
-  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  cfg = syn.make_config(bits=bits, prune_percentage=0.9)
   for pool in (1, 2) if H % 2 == 0 and W % 2 == 0 else (1,):
     blk = SpikingBlock(connection_fn=QuantConv(features=N, kernel_size=(3, 3), padding=((1, 1), (1, 1)),
-                                               use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale),
+                                               use_bias=False, config=cfg.quant, bits=bits, g_scale=cfg.quant.g_scale),
                        neural_dynamics=cfg.neuron_dynamics(dtype=torch.float32),
                        norm_fn=nn.BatchNorm(use_running_average=True, momentum=0.9, epsilon=1e-5),
                        pool=pool, return_state=True)
@@ -3347,8 +3351,9 @@ def test_gated_conv_in_the_gint_form(dev, oracle, shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 5, 4, 4, 128, 512), (2, 33, 2, 3, 64, 70), (1, 2, 1, 1, 32, 32),
-                                   (2, 3, 4, 4, 96, 600)],
-                         ids=["cextnet_dense1", "ragged_rows_and_outputs", "one_position", "two_output_groups"])
+                                   (2, 3, 4, 4, 96, 600), (3, 5, 4, 4, 128, 512, 8), (2, 33, 2, 3, 64, 70, 6)],
+                         ids=["cextnet_dense1", "ragged_rows_and_outputs", "one_position", "two_output_groups",
+                              "cextnet_dense1_8bit", "ragged_6bit"])
 def test_gated_dense_in_the_gint_form(dev, oracle, shape):
   """QuantDense on the channel-major flattening of gate x raster -- the dense block behind the second
   TCJA gate (examples/tcja/models.py:97 -> :189-190 -> :200-216) -- without multiplying the gate
@@ -3363,28 +3368,31 @@ def test_gated_dense_in_the_gint_form(dev, oracle, shape):
   from snnquantprune_amd.flax_qdense import QuantDense
   from snnquantprune_amd.quant import QuantDesc
   from snnquantprune_amd.spiking_learning import SpikingBlock
-  T, B, H, W, C, N = shape
+  T, B, H, W, C, N = shape[:6]
+  bits = shape[6] if len(shape) > 6 else 4      # beyond 4 bits: two fp8 digits per code
   K = C * H * W
-  leaf = syn.quant_leaf((K, N), 5.0, 981, True, 0.9)
-  qw = qweight_of(oracle, leaf, 4)
+  leaf = syn.quant_leaf((K, N), 5.0, 981, True, 0.9 if bits == 4 else 0.5)
+  qw = qweight_of(oracle, leaf, bits)
   rng = np.random.Generator(np.random.PCG64(H * W + C + N))
   s = (rng.random((T, B, H, W, C)) < 0.3).astype(np.uint8)
   gate = (1.0 / (1.0 + np.exp(-rng.standard_normal((T, B, C)) * 1.5))).astype(F32)
   a, c = float(leaf["DuQ_0"]["a"][0]), float(leaf["DuQ_0"]["c"][0])
-  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, 4, a, c, 7.0, c), _t(leaf["prune_0"]["mask"], dev))
+  pk = packing.PackedKernel(_t(leaf["kernel"], dev), QuantDesc(L.Q_DUQ, bits, a, c, float(2 ** (bits - 1) - 1), c),
+                            _t(leaf["prune_0"]["mask"], dev))
   w = pk.int_weight()
+  assert (w.code_max > 7) == (bits > 4)
   x = ops.GatedSpikes(ops.pack_bits(_t(s, dev)), _t(gate, dev)).flattened()
   assert tuple(x.shape) == (T, B, K)
   y = ops.dense_gated_forward(x, w, pk.gated_dense_codes(C, H * W))
   ey = np.stack([oracle.gated_dense(s[t].astype(F32), gate[t], qw) for t in range(T)])
   np.testing.assert_array_equal(_np(y), ey)
-  assert 0.3 < np.abs(ey).max() < 200.0
+  assert 0.3 < np.abs(ey).max() < 2000.0
   # what the flattened product is, for every other consumer
   dense = (gate[:, :, None, None, :] * s).astype(F32).transpose(0, 1, 4, 2, 3).reshape(T, B, K)
   np.testing.assert_array_equal(_np(x.to_dense()), dense)
   # the block, as the model calls it
-  cfg = syn.make_config(bits=4, prune_percentage=0.9)
-  blk = SpikingBlock(connection_fn=QuantDense(N, use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale),
+  cfg = syn.make_config(bits=bits, prune_percentage=0.9)
+  blk = SpikingBlock(connection_fn=QuantDense(N, use_bias=False, config=cfg.quant, bits=bits, g_scale=cfg.quant.g_scale),
                      neural_dynamics=cfg.neuron_dynamics(dtype=torch.float32), return_state=True)
   variables = nn.tree_from_numpy({"params": {"connection_fn": leaf}}, dev)
   u, sp = blk.apply(variables, None, x)
