@@ -334,10 +334,10 @@ int snnqp_conv3d_lif_forward(const int32_t *pred, const void *x, int in_type, in
 int64_t snnqp_conv_gated_packed_bytes(int32_t Cin, int32_t Cout);
 int snnqp_pack_codes_gated(const int8_t *w, int32_t Cin, int32_t Cout, void *packed,
                            snnqp_stream_t stream);
-/* Codes beyond fp6 (code_max = max |code| up to 127: DuQ up to 8 bits, the reference's shipped TCJA
- * configs): packed as two fp8 digits, code = 16 hi + lo, in the two K blocks of the matrix
- * instruction with a block scale of 2^4 on the second -- one instruction still returns the exact
- * integer sum of a channel's taps.  The _ex forms take code_max (<= 7: the fp6 layout above);
+/* Codes beyond e2m3 (code_max = max |code| up to 127: DuQ up to 8 bits, the reference's shipped TCJA
+ * configs): packed as two six-bit digits in the e3m2 format, code = 16 hi + lo, in the two K blocks
+ * of the matrix instruction with a block scale of 2^4 on the second -- one instruction still
+ * returns the exact integer sum of a channel's taps, at the same rate.  The _ex forms take code_max (<= 7: the fp6 layout above);
  * snnqp_conv_gated_forward picks the kernel by w->code_max, `packed` must come from the pack call
  * with the same code_max. */
 int64_t snnqp_conv_gated_packed_bytes_ex(int32_t Cin, int32_t Cout, int32_t code_max);
@@ -360,7 +360,7 @@ int snnqp_conv_gated_forward(const uint32_t *s, const float *gate, int64_t NB,
 int64_t snnqp_dense_gated_packed_bytes(int32_t C, int32_t N);
 int snnqp_pack_codes_dense_gated(const int8_t *w, int32_t C, int32_t HW, int32_t N, void *packed,
                                  snnqp_stream_t stream);
-/* (codes up to 127 as two fp8 digits, as snnqp_pack_codes_gated_ex: the _ex forms take code_max) */
+/* (codes up to 127 as two e3m2 digits, as snnqp_pack_codes_gated_ex: the _ex forms take code_max) */
 int64_t snnqp_dense_gated_packed_bytes_ex(int32_t C, int32_t N, int32_t code_max);
 int snnqp_pack_codes_dense_gated_ex(const int8_t *w, int32_t C, int32_t HW, int32_t N, int32_t code_max,
                                     void *packed, snnqp_stream_t stream);

@@ -79,41 +79,41 @@ pack_codes_gated_kernel(const int8_t *w, int32_t C, int32_t Cout, int32_t OT, ui
   }
 }
 
-// integer -8..8 -> OCP fp8 e4m3 (bias 7: 1 = 0x38, 2 = 0x40, 3 = 0x44, 4 = 0x48, 5 = 0x4A, 6 = 0x4C,
-// 7 = 0x4E, 8 = 0x50)
-__device__ __forceinline__ uint32_t enc8(int v) {
+// integer -8..8 -> fp6 e3m2 (bias 3, three significant bits: every integer up to 8 is exact;
+// 1 = 0x0C, 2 = 0x10, 3 = 0x12, 4 = 0x14, 5 = 0x15, 6 = 0x16, 7 = 0x17, 8 = 0x18)
+__device__ __forceinline__ uint32_t enc6w(int v) {
   const uint32_t mag = (uint32_t)(v < 0 ? -v : v);
-  const uint32_t tab[9] = {0x00u, 0x38u, 0x40u, 0x44u, 0x48u, 0x4Au, 0x4Cu, 0x4Eu, 0x50u};
-  return tab[mag] | (v < 0 ? 0x80u : 0u);
+  const uint32_t tab[9] = {0x00u, 0x0Cu, 0x10u, 0x12u, 0x14u, 0x15u, 0x16u, 0x17u, 0x18u};
+  return tab[mag] | (v < 0 ? 0x20u : 0u);
 }
-// Codes beyond fp6 (|code| <= 127: up to 8 bits) as TWO fp8 digits, code = 16 hi + lo with lo in
-// [-8, 7], hi in [-8, 8], one digit per 32-deep K block of the 64-deep instruction: the block scale
-// of the second block is 2^4 (v_mfma_scale: an E8M0 scale per lane half = per block), so ONE
-// instruction returns sum(lo s) + 16 sum(hi s): the exact integer, and no vector instruction more
-// than with fp6.  With a 4-bit and an 8-bit operand the two count k differently
-// (tools/ubench/mfma_fp8_kmap.hip): fp4 lane (r, h) position j is k = 32 h + j, fp8 lane (r, h)
-// byte j is k = 32 (j >> 4) + 16 h + (j & 15) -- K block 0 is bytes 0..15 of both lane halves.  The
-// nine taps sit at k = 0..8 and k = 32..40: fp4 nibbles 0..8 of BOTH lane halves, fp8 bytes 0..8
-// (lo) and 16..24 (hi) of the lanes of half 0; the lanes of half 1 hold zeros.
-// bp8 = 8 zero dwords (what the lanes of half 1 read), then [c][ot][n][8 dwords].
+// Codes beyond e2m3 (|code| <= 127: up to 8 bits) as TWO six-bit digits, code = 16 hi + lo with lo in
+// [-8, 7], hi in [-8, 8] -- exact in the OTHER fp6 format, e3m2 -- one digit per 32-deep K block of
+// the 64-deep instruction: the block scale of the second block is 2^4 (v_mfma_scale: an E8M0 scale
+// per lane half = per K block), so ONE instruction returns sum(lo s) + 16 sum(hi s): the exact
+// integer, at the fp6 rate and with not one vector instruction more than the narrow form.  (fp8
+// digits work too -- tools/ubench/mfma_fp8_kmap.hip, mfma_fp8_digits.hip: an 8-bit operand beside a
+// 4-bit one counts k differently, the digits then sit in bytes 0..8 / 16..24 of the lanes of half 0
+// -- and were the first version: twice the matrix-pipe time and eight operand dwords, 2.09 ms for
+// CextNet's 8-bit layer against 1.38 with e3m2.)  bp[c][ot][lane][2]: lane (n, h = 0) holds the lo digits
+// of the nine taps at bits [6 j, 6 j + 6), lane (n, h = 1) the hi digits; the spike operand holds
+// the nine taps in both lane halves.
 __global__ void __launch_bounds__(256)
 pack_codes_gated_wide_kernel(const int8_t *w, int32_t C, int32_t Cout, int32_t OT, uint32_t *bp) {
-  const int64_t total = (int64_t)C * OT * 32;
-  if (blockIdx.x == 0 && threadIdx.x < 8) bp[threadIdx.x] = 0u;
+  const int64_t total = (int64_t)C * OT * 64;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int n = (int)(i & 31);
-    const int ot = (int)((i >> 5) % OT), c = (int)((i >> 5) / OT);
+    const int lane = (int)(i & 63), n = lane & 31, h = lane >> 5;
+    const int ot = (int)((i >> 6) % OT), c = (int)((i >> 6) / OT);
     const int o = ot * 32 + n;
-    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long bits = 0;
     if (o < Cout) {
       for (int tap = 0; tap < 9; ++tap) {
         const int code = w[((int64_t)tap * C + c) * Cout + o];
         const int lo = ((code + 8) & 15) - 8, hi = (code - lo) / 16;
-        d[tap >> 2] |= enc8(lo) << (8 * (tap & 3));
-        d[4 + (tap >> 2)] |= enc8(hi) << (8 * (tap & 3));
+        bits |= (unsigned long long)enc6w(h ? hi : lo) << (6 * tap);
       }
     }
-    for (int j = 0; j < 8; ++j) bp[8 + i * 8 + j] = d[j];
+    bp[i * 2] = (uint32_t)bits;
+    bp[i * 2 + 1] = (uint32_t)(bits >> 32);
   }
 }
 
@@ -174,36 +174,20 @@ conv_gated_kernel(ConvGatedArgs a) {
   for (int t = 0; t < 4; ++t) acc[t] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float *grow = a.gate + img * a.C;             // wave-uniform: scalar loads
-  // four channels per group (one with the wide codes: eight operand dwords per lane); the codes of
-  // the next group are requested before this group's matrix instructions (an L2 round trip per
-  // group would otherwise sit in front of every one)
+  // four channels per group; the codes of the next group are requested before this group's
+  // matrix instructions (an L2 round trip per group would otherwise sit in front of every one)
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  struct u8w { u4 lo, hi; };
-  typedef typename std::conditional<WIDE, u8w, u2>::type bvec;
-  constexpr int GC = WIDE ? 1 : 4;
-  // fp6: lane (n, h) reads its two dwords; wide: the lanes of half 0 read their record of eight, the
-  // lanes of half 1 the zero block at the head of the buffer (stride 0)
-  const uint32_t *bpl = WIDE ? (h ? a.bp : a.bp + 8 + ((int64_t)ot0 * 32 + n) * 8)
-                             : a.bp + ((int64_t)ot0 * 64 + lane) * 2;
-  const int64_t cstride = WIDE ? (h ? 0 : (int64_t)a.OT * 256) : (int64_t)a.OT * 128;
-  const int tstride = WIDE ? (h ? 0 : 256) : 128;
+  typedef u2 bvec;
+  constexpr int GC = 4;
+  const uint32_t *bpl = a.bp + ((int64_t)ot0 * 64 + lane) * 2;
   bvec bcur[GC][4], bnxt[GC][4];
   auto load_group = [&](bvec (&dst)[GC][4], int c0) {
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       const int c = min(c0 + j, a.C - 1);
-      const uint32_t *bc = bpl + (int64_t)c * cstride;
+      const uint32_t *bc = bpl + (int64_t)c * a.OT * 128;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t *bt = bc + (t < nt ? t : 0) * tstride;
-        if constexpr (WIDE) {
-          dst[j][t].lo = *(const u4 *)bt;
-          dst[j][t].hi = *(const u4 *)(bt + 4);
-        } else {
-          dst[j][t] = *(const u2 *)bt;
-        }
-      }
+      for (int t = 0; t < 4; ++t) dst[j][t] = *(const u2 *)(bc + (t < nt ? t : 0) * 128);
     }
   };
   // WIDE: the E8M0 scale of B's K block h comes from the lanes of half h: 2^0 (lo digits), 2^4 (hi)
@@ -234,9 +218,8 @@ conv_gated_kernel(ConvGatedArgs a) {
           v8i B;
           v16f I;
           if constexpr (WIDE) {
-            B = v8i{(int)bcur[j][t].lo.x, (int)bcur[j][t].lo.y, (int)bcur[j][t].lo.z, 0,
-                    (int)bcur[j][t].hi.x, (int)bcur[j][t].hi.y, (int)bcur[j][t].hi.z, 0};
-            I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 4 /* fp4 */, 0 /* fp8 e4m3 */,
+            B = v8i{(int)bcur[j][t].x, (int)bcur[j][t].y, 0, 0, 0, 0, 0, 0};
+            I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 4 /* fp4 */, 3 /* fp6 e3m2 */,
                                                                 0, 127, 0, sb);
           } else {
             B = v8i{(int)bcur[j][t].x, (int)bcur[j][t].y, 0, 0, 0, 0, 0, 0};
@@ -290,8 +273,7 @@ const char *conv_gated_unsupported(const snnqp_conv_geom_t *g, const snnqp_weigh
 
 extern "C" int64_t snnqp_conv_gated_packed_bytes_ex(int32_t Cin, int32_t Cout, int32_t code_max) {
   if (Cin <= 0 || Cout <= 0 || code_max <= 0 || code_max > 127) return 0;
-  if (code_max <= 7) return (int64_t)Cin * ((Cout + 31) / 32) * 64 * 2 * 4;
-  return 32 + (int64_t)Cin * ((Cout + 31) / 32) * 32 * 8 * 4;
+  return (int64_t)Cin * ((Cout + 31) / 32) * 64 * 2 * 4;       // (both layouts: two dwords per lane)
 }
 extern "C" int64_t snnqp_conv_gated_packed_bytes(int32_t Cin, int32_t Cout) {
   return snnqp_conv_gated_packed_bytes_ex(Cin, Cout, 7);

@@ -75,34 +75,35 @@ pack_codes_dense_gated_kernel(const int8_t *w, int32_t C, int32_t HW, int32_t N,
   }
 }
 
-// Codes beyond fp6 (|code| <= 127) as two fp8 digits, code = 16 hi + lo (conv_gated.hip: the layout of
-// a 4-bit beside an 8-bit operand, the 2^4 block scale on the second K block): the sixteen positions
-// sit at k = 0..15 (lo) and k = 32..47 (hi) -- fp8 bytes 0..15 and 16..31 of the lanes of half 0 (the
-// codes are the A operand here), fp4 nibbles 0..15 of BOTH lane halves of the spike operand.
-// ap8 = 8 zero dwords (what the lanes of half 1 read), then [c][ot][n][8 dwords].
-__device__ __forceinline__ uint32_t dg_enc8(int v) {      // integer -8..8 -> OCP fp8 e4m3
+// Codes beyond e2m3 (|code| <= 127) as two six-bit digits in the e3m2 format, code = 16 hi + lo
+// (conv_gated.hip: one digit per K block, the 2^4 block scale on the second): lane (o, h = 0) holds
+// the lo digits of the sixteen positions at bits [6 p, 6 p + 6) of dwords 0..2, lane (o, h = 1) the
+// hi digits; the spike operand holds the positions in both lane halves.  Same record as the narrow
+// form: ap[c][ot][lane][4 dwords].
+__device__ __forceinline__ uint32_t dg_enc6w(int v) {     // integer -8..8 -> fp6 e3m2
   const uint32_t mag = (uint32_t)(v < 0 ? -v : v);
-  const uint32_t tab[9] = {0x00u, 0x38u, 0x40u, 0x44u, 0x48u, 0x4Au, 0x4Cu, 0x4Eu, 0x50u};
-  return tab[mag] | (v < 0 ? 0x80u : 0u);
+  const uint32_t tab[9] = {0x00u, 0x0Cu, 0x10u, 0x12u, 0x14u, 0x15u, 0x16u, 0x17u, 0x18u};
+  return tab[mag] | (v < 0 ? 0x20u : 0u);
 }
 __global__ void __launch_bounds__(256)
 pack_codes_dense_gated_wide_kernel(const int8_t *w, int32_t C, int32_t HW, int32_t N, int32_t OT, uint32_t *ap) {
-  const int64_t total = (int64_t)C * OT * 32;
-  if (blockIdx.x == 0 && threadIdx.x < 8) ap[threadIdx.x] = 0u;
+  const int64_t total = (int64_t)C * OT * 64;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int n = (int)(i & 31);
-    const int ot = (int)((i >> 5) % OT), c = (int)((i >> 5) / OT);
+    const int lane = (int)(i & 63), n = lane & 31, h = lane >> 5;
+    const int ot = (int)((i >> 6) % OT), c = (int)((i >> 6) / OT);
     const int o = ot * 32 + n;
-    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t d[4] = {0, 0, 0, 0};
     if (o < N) {
       for (int p = 0; p < HW; ++p) {
         const int code = w[((int64_t)c * HW + p) * N + o];
         const int lo = ((code + 8) & 15) - 8, hi = (code - lo) / 16;
-        d[p >> 2] |= dg_enc8(lo) << (8 * (p & 3));
-        d[4 + (p >> 2)] |= dg_enc8(hi) << (8 * (p & 3));
+        const uint32_t e = dg_enc6w(h ? hi : lo);
+        const int bit = 6 * p;
+        d[bit >> 5] |= e << (bit & 31);
+        if ((bit & 31) > 26) d[(bit >> 5) + 1] |= e >> (32 - (bit & 31));
       }
     }
-    for (int j = 0; j < 8; ++j) ap[8 + i * 8 + j] = d[j];
+    for (int j = 0; j < 4; ++j) ap[i * 4 + j] = d[j];
   }
 }
 
@@ -150,30 +151,17 @@ dense_gated_kernel(DenseGatedArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  struct v8w { v4i lo, hi; };
-  typedef typename std::conditional<WIDE, v8w, v4i>::type avec;
-  // fp6: lane (o, h) reads its four dwords; wide: the lanes of half 0 their record of eight, the lanes
-  // of half 1 the zero block at the head of the buffer (stride 0)
-  const v4i *apl = WIDE ? (const v4i *)(h ? a.ap : a.ap + 8 + ((int64_t)ot0 * 32 + n) * 8)
-                        : (const v4i *)a.ap + (int64_t)ot0 * 64 + lane;
-  const int64_t tstride = WIDE ? (h ? 0 : 64) : 64;       // v4i units between output tiles
+  typedef v4i avec;
+  const v4i *apl = (const v4i *)a.ap + (int64_t)ot0 * 64 + lane;
   const int sa = WIDE ? (h ? 131 : 127) : 127;             // E8M0 scale of A's K block h: 2^0 / 2^4
-  constexpr int GC = WIDE ? 1 : 4;
+  constexpr int GC = 4;
   avec acur[GC][4], anxt[GC][4];
   auto load_group = [&](avec (&dst)[GC][4], int c0) {
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       const int c = min(c0 + j, a.C - 1);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const v4i *at = apl + ((int64_t)c * a.OT + min(t, a.OT - 1 - ot0)) * tstride;
-        if constexpr (WIDE) {
-          dst[j][t].lo = at[0];
-          dst[j][t].hi = at[1];
-        } else {
-          dst[j][t] = at[0];
-        }
-      }
+      for (int t = 0; t < 4; ++t) dst[j][t] = apl[((int64_t)c * a.OT + min(t, a.OT - 1 - ot0)) * 64];
     }
   };
   load_group(acur, 0);
@@ -190,13 +178,11 @@ dense_gated_kernel(DenseGatedArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         v16f I;
+        const v8i A = {acur[j][t].x, acur[j][t].y, acur[j][t].z, 0, 0, 0, 0, 0};
         if constexpr (WIDE) {
-          const v8i A = {acur[j][t].lo.x, acur[j][t].lo.y, acur[j][t].lo.z, acur[j][t].lo.w,
-                         acur[j][t].hi.x, acur[j][t].hi.y, acur[j][t].hi.z, acur[j][t].hi.w};
-          I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 0 /* A: fp8 e4m3 */, 4 /* B: fp4 */,
+          I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 3 /* A: fp6 e3m2 */, 4 /* B: fp4 */,
                                                               0, sa, 0, 127);
         } else {
-          const v8i A = {acur[j][t].x, acur[j][t].y, acur[j][t].z, 0, 0, 0, 0, 0};
           I = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, 2 /* A: fp6 */, 4 /* B: fp4 */,
                                                               0, 127, 0, 127);
         }
@@ -242,8 +228,7 @@ const char *dense_gated_unsupported(int32_t HW, int32_t C, int32_t N, const snnq
 
 extern "C" int64_t snnqp_dense_gated_packed_bytes_ex(int32_t C, int32_t N, int32_t code_max) {
   if (C <= 0 || N <= 0 || code_max <= 0 || code_max > 127) return 0;
-  if (code_max <= 7) return (int64_t)C * ((N + 31) / 32) * 64 * 4 * 4;
-  return 32 + (int64_t)C * ((N + 31) / 32) * 32 * 8 * 4;
+  return (int64_t)C * ((N + 31) / 32) * 64 * 4 * 4;        // (both layouts: four dwords per lane)
 }
 extern "C" int64_t snnqp_dense_gated_packed_bytes(int32_t C, int32_t N) {
   return snnqp_dense_gated_packed_bytes_ex(C, N, 7);

@@ -731,7 +731,7 @@ def conv_forward_speculative(x: torch.Tensor, geom: ConvGeom, int_weight: Weight
 
 def pack_codes_gated(codes: torch.Tensor, code_max: int = 7) -> torch.Tensor:
   """int8 HWIO codes [3, 3, Cin, Cout] -> the operand layout of conv_gated_forward
-  (snnqp_pack_codes_gated_ex): fp6 for code_max <= 7, two fp8 digits per code up to 127."""
+  (snnqp_pack_codes_gated_ex): e2m3 for code_max <= 7, two e3m2 digits per code up to 127."""
   _require_gpu(codes)
   assert codes.dtype == torch.int8 and codes.ndim == 4 and tuple(codes.shape[:2]) == (3, 3)
   codes = codes.contiguous()
@@ -759,7 +759,7 @@ def conv_gated_forward(x: GatedSpikes, geom: ConvGeom, weight: Weight, packed: t
 
 def pack_codes_dense_gated(codes: torch.Tensor, C: int, HW: int, code_max: int = 7) -> torch.Tensor:
   """int8 codes [C * HW, N] (rows channel-major) -> the operand layout of dense_gated_forward
-  (snnqp_pack_codes_dense_gated_ex): fp6 for code_max <= 7, two fp8 digits per code up to 127."""
+  (snnqp_pack_codes_dense_gated_ex): e2m3 for code_max <= 7, two e3m2 digits per code up to 127."""
   _require_gpu(codes)
   assert codes.dtype == torch.int8 and codes.ndim == 2 and codes.shape[0] == C * HW
   codes = codes.contiguous()

@@ -124,8 +124,8 @@ class PackedKernel:
     return self._int
 
   def gated_codes(self):
-    """The codes in the operand layout of ops.conv_gated_forward (3x3 kernels: fp6 for codes up to 7,
-    two fp8 digits per code up to 127), or None."""
+    """The codes in the operand layout of ops.conv_gated_forward (3x3 kernels: e2m3 for codes up to 7,
+    two e3m2 digits per code up to 127), or None."""
     w = self.int_weight()
     if w is None or self.kernel.ndim != 4 or tuple(self.kernel.shape[:2]) != (3, 3) or not (0 < w.code_max <= 127):
       return None
