@@ -20,6 +20,7 @@ run 8bit_counts --bits 8 --prune 0.3 --counts
 run counts --counts
 run counts_ev4 --counts --input ev4
 run cextnet --model cextnet
+run cextnet_8bit --model cextnet --bits 8 --prune 0.3
 run f32 --input f32
 run u8 --input u8
 run ev1_fed --input ev1 --feed host
