@@ -257,7 +257,9 @@ int run_fseq_gemm(const void *x, int in_type, int64_t NB, const snnqp_conv_geom_
   if (a.M == 0 || a.N == 0) return SNNQP_OK;
   // the small tile when the large one would leave most of the chip idle
   const int64_t big = ceil_div64(a.M, 128) * ((a.N + 127) / 128);
-  const int tm = big < 192 ? 1 : 2;
+  // ... or when at most 64 columns exist (the TCJA gate's convolution along the channels has
+  // N = T = 20 outputs: three quarters of a 128-column tile would multiply zeros)
+  const int tm = (big < 192 || a.N <= 64) ? 1 : 2;
   const int64_t gx = ceil_div64(a.M, 64 * tm);
   SNNQP_REQUIRE(gx < (1ll << 31), SNNQP_EINVAL, "fseq gemm: grid too large");
   const dim3 grid((unsigned)gx, (unsigned)((a.N + 64 * tm - 1) / (64 * tm)));
