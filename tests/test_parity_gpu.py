@@ -3714,3 +3714,33 @@ def test_empty_batches_and_zero_timesteps(dev, oracle):
   out = mcx.apply(vcx, torch.zeros((0, 4, 128, 128, 2), dtype=torch.uint8, device=dev), trgt=None, train=False, rng=None)
   assert tuple(out[0].shape) == (0, 11)
   assert ops.device_status() == 0
+
+
+@pytest.mark.parametrize("bits,prune", [(8, 0.3), (3, 0.7)], ids=["shipped_8bit_30pct", "shipped_3bit_70pct"])
+def test_full_cextnet_at_the_shipped_bit_widths(dev, oracle, bits, prune):
+  """The reference's TCJA model at the bit widths and pruning of its shipped configurations
+  (examples/tcja/configs/prune_quant_joint.py:53,60 -- 8 bits, 30 %; prune_quant_seq.py:53,60 -- 3
+  bits, 70 %) against the live oracle at 64 x 64: at 8 bits the blocks behind the gates run the
+  two-digit form of the `gint` kernels (codes up to 127), the conv blocks the int8 instruction; every
+  raster, both gates and the logits bit-exact."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, synthetic as syn
+  c = cases.cextnet_case(bits=bits, p=prune)
+  e = cases.cextnet_expected(oracle, c)
+  model = models.CextNet(num_classes=11, config=syn.make_config(bits=bits, prune_percentage=prune))
+  (logits, _), mut = model.apply(nn.tree_from_numpy(c["vars"], dev), _t(c["x"], dev), trgt=None, train=False,
+                                 rng=None, mutable=["intermediates"])
+  im = mut["intermediates"]
+  for i in range(3):
+    np.testing.assert_array_equal(_np(im["pool%d" % i][0]), e["pool%d_bits" % i])
+  for i in range(2):
+    np.testing.assert_array_equal(_np(im["tcja_gate_%d" % i][0]), e["gate%d" % i])
+    s = im["conv_t_%d" % i][0]
+    s = _np(s) if hasattr(s, "bits") else packbits_lastaxis(_np(s))
+    np.testing.assert_array_equal(s, e["conv_t_%d_bits" % i])
+  for key, name in (("dense1_out", "dense1_s"), ("dense2_out", "dense2_s")):
+    d = im[key][0]
+    d = d.to_dense() if hasattr(d, "to_dense") else d
+    np.testing.assert_array_equal(_np(d).astype(np.uint8), e[name])
+  np.testing.assert_array_equal(_np(logits), e["logits"])
+  assert 0.005 < e["dense1_s"].mean() < 0.7
