@@ -72,7 +72,14 @@ __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound, int rows) {
 // barrier less); a thread stages one halo ROW of one timestep -- 20 bits out of two words,
 // expanded through a 256-entry byte -> 8-byte LDS table -- instead of one pixel.
 template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8>
-__global__ void __launch_bounds__(256, U8C2_WPS)
+// Waves per SIMD the bit-packed variant is compiled for: five (96 registers, 31 spilled dwords
+// outside the timestep loop) measured 5.10-5.18 ms on the headline layer against 5.32-5.35 for four
+// (122 registers) on the same box; six (80 registers) spills inside the loop: 19.9 ms.  The byte
+// formats stay at four (their staging holds sixteen values per thread).
+#ifndef SNNQP_U8C2_EV1_WPS
+#define SNNQP_U8C2_EV1_WPS 5
+#endif
+__global__ void __launch_bounds__(256, IN == SNNQP_EV1 ? SNNQP_U8C2_EV1_WPS : U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
   constexpr bool EV1 = IN == SNNQP_EV1;
