@@ -71,11 +71,15 @@ __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound, int rows) {
 // table modes need no check of the chunk (and the chunk no reduction, no atomic and one
 // barrier less); a thread stages one halo ROW of one timestep -- 20 bits out of two words,
 // expanded through a 256-entry byte -> 8-byte LDS table -- instead of one pixel.
-template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8>
-// Waves per SIMD the bit-packed variant is compiled for: five (96 registers, 31 spilled dwords
-// outside the timestep loop) measured 5.10-5.18 ms on the headline layer against 5.32-5.35 for four
-// (122 registers) on the same box; six (80 registers) spills inside the loop: 19.9 ms.  The byte
-// formats stay at four (their staging holds sixteen values per thread).
+template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8, bool ONE = false>
+// Waves per SIMD the bit-packed variant is compiled for: five.  With the potentials' life starting
+// behind the staging code (template parameter ONE: nothing carried in or out, one chunk) the
+// headline variant needs 90 registers and spills nothing: 4.95 ms on the headline layer against
+// 5.32-5.35 for four waves (122 registers) on the same box; the general variant (potentials
+// carried, several chunks) spills 31 dwords around its staging code at five waves and is still the
+// faster one (5.10-5.18).  Six waves: 80 registers, 7 dwords spilled per patch -- 4.83 ms at 3 GB
+// of scratch traffic per launch (twice the layer's algorithmic bytes): not taken.  The byte formats
+// stay at four (their staging holds sixteen values per thread).
 #ifndef SNNQP_U8C2_EV1_WPS
 #define SNNQP_U8C2_EV1_WPS 5
 #endif
@@ -267,9 +271,14 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
     int b, y0, x0;
     pw.decode(a, r, b, y0, x0);
 
+    // ONE: no potentials carried in or out and all timesteps in one chunk -- the potentials then
+    // start their life behind the staging code instead of through it (32 registers the staging
+    // does not have to work around)
     float u[2][16];
-    if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
-    else zero_u(u);
+    if constexpr (!ONE) {
+      if (a.u0 && wave_on) u_io<true>(u, a, b, y0, x0, cout, h);
+      else zero_u(u);
+    }
     uint32_t pseen = 0;                  // largest input value of this patch so far
     const int s_gy = y0 + s_pix / HALO - 1, s_gx = x0 + s_pix % HALO - 1;
     const bool s_valid = s_task && s_gy >= 0 && s_gy < a.H && s_gx >= 0 && s_gx < a.W;
@@ -470,6 +479,7 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         lds_barrier();
       }
       };
+      if constexpr (ONE) zero_u(u);
       if (general) {
         run_chunk(std::integral_constant<int, LUT_NONE>{}, std::false_type{});
       } else if constexpr (LUTM != LUT_NONE) {
@@ -481,8 +491,9 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
         if (fma_ok) run_chunk(std::integral_constant<int, LUTM>{}, std::true_type{});
         else run_chunk(std::integral_constant<int, LUTM>{}, std::false_type{});
       }
+      if constexpr (ONE) break;          // (a.T <= tc: the launcher's condition for this variant)
     }
-    if (a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
+    if (!ONE && a.u_out && wave_on) u_io<false>(u, a, b, y0, x0, cout, h);
     int r_next = r + (int)pw.stride;
     if (pw.queue) {                      // the claimed patch, to the whole workgroup
       if (tid == 0) wgw[2] = (uint32_t)claimed;
@@ -809,7 +820,8 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.ch_slots = lutc && w->ch_stack_max > 0 ? w->ch_slots : nullptr;
 #define SNNQP_CONV_LAUNCH_IN(KERN, NFV, PL, LM, LDS)                               \
   do {                                                                             \
-    if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
+    if (ev1 && !a.u0 && !a.u_out && a.T <= a.tchunk) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1, true>, a, gy, st, LDS); \
+    else if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
     else if (in_type == SNNQP_EV4) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV4>, a, gy, st, LDS); \
     else if (in_type == SNNQP_F32) launch_persistent(KERN<NFV, PL, LM, SNNQP_F32>, a, gy, st, LDS); \
     else launch_persistent(KERN<NFV, PL, LM, SNNQP_U8>, a, gy, st, LDS);            \
