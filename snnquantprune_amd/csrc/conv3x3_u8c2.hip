@@ -83,7 +83,15 @@ template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8, bool ONE = false>
 #ifndef SNNQP_U8C2_EV1_WPS
 #define SNNQP_U8C2_EV1_WPS 5
 #endif
-__global__ void __launch_bounds__(256, IN == SNNQP_EV1 ? SNNQP_U8C2_EV1_WPS : U8C2_WPS)
+// The byte formats' ONE variants: 102-103 registers and no scratch at four waves (128 with 40 bytes of
+// scratch before the potentials moved behind the staging code): uint8 5.80 -> 5.56 ms, counts 5.85
+// -> 5.67, nibbles 6.18 -> 6.00, float32 6.06 -> 5.85.  At five waves they spill 6 dwords per patch:
+// 5.24 (uint8) / 5.51 (float32), counts unchanged (their tables leave LDS for four workgroups) --
+// not taken while it costs scratch traffic.
+#ifndef SNNQP_U8C2_ONE_WPS
+#define SNNQP_U8C2_ONE_WPS 4
+#endif
+__global__ void __launch_bounds__(256, IN == SNNQP_EV1 ? SNNQP_U8C2_EV1_WPS : ONE ? SNNQP_U8C2_ONE_WPS : U8C2_WPS)
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
   constexpr bool EV1 = IN == SNNQP_EV1;
@@ -820,10 +828,13 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.ch_slots = lutc && w->ch_stack_max > 0 ? w->ch_slots : nullptr;
 #define SNNQP_CONV_LAUNCH_IN(KERN, NFV, PL, LM, LDS)                               \
   do {                                                                             \
-    if (ev1 && !a.u0 && !a.u_out && a.T <= a.tchunk) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1, true>, a, gy, st, LDS); \
+    if (ev1 && one) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1, true>, a, gy, st, LDS); \
     else if (ev1) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV1>, a, gy, st, LDS);       \
+    else if (in_type == SNNQP_EV4 && one) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV4, true>, a, gy, st, LDS); \
     else if (in_type == SNNQP_EV4) launch_persistent(KERN<NFV, PL, LM, SNNQP_EV4>, a, gy, st, LDS); \
+    else if (in_type == SNNQP_F32 && one) launch_persistent(KERN<NFV, PL, LM, SNNQP_F32, true>, a, gy, st, LDS); \
     else if (in_type == SNNQP_F32) launch_persistent(KERN<NFV, PL, LM, SNNQP_F32>, a, gy, st, LDS); \
+    else if (one) launch_persistent(KERN<NFV, PL, LM, SNNQP_U8, true>, a, gy, st, LDS);            \
     else launch_persistent(KERN<NFV, PL, LM, SNNQP_U8>, a, gy, st, LDS);            \
   } while (0)
 #define SNNQP_CONV_LAUNCH_NF(KERN, NFV, LM, LDS)                                   \
@@ -881,6 +892,9 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
       }
     }
     const size_t ldsb = (size_t)a.tchunk * HIMG2 + lds_rest;
+    // nothing carried in or out and every timestep in one chunk: the variant whose potentials start
+    // their life behind the staging code (template parameter ONE)
+    const bool one = !a.u0 && !a.u_out && a.T <= a.tchunk;
     if (lutc) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_CHANNEL, ldsb);
     else if (lut) SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_SHARED, ldsb);
     else SNNQP_CONV_LAUNCH(conv3x3_u8c2_kernel, LUT_NONE, ldsb);
