@@ -71,15 +71,12 @@ __host__ __device__ inline int u8c2_table_bytes(int lutm, int bound, int rows) {
 // table modes need no check of the chunk (and the chunk no reduction, no atomic and one
 // barrier less); a thread stages one halo ROW of one timestep -- 20 bits out of two words,
 // expanded through a 256-entry byte -> 8-byte LDS table -- instead of one pixel.
-template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8, bool ONE = false>
-// Waves per SIMD the bit-packed variant is compiled for: five.  With the potentials' life starting
-// behind the staging code (template parameter ONE: nothing carried in or out, one chunk) the
-// headline variant needs 90 registers and spills nothing: 4.95 ms on the headline layer against
-// 5.32-5.35 for four waves (122 registers) on the same box; the general variant (potentials
-// carried, several chunks) spills 31 dwords around its staging code at five waves and is still the
-// faster one (5.10-5.18).  Six waves: 80 registers, 7 dwords spilled per patch -- 4.83 ms at 3 GB
-// of scratch traffic per launch (twice the layer's algorithmic bytes): not taken.  The byte formats
-// stay at four (their staging holds sixteen values per thread).
+// Waves per SIMD the variants are compiled for (profiles/r05_conv0_waves.txt).  The bit-packed
+// variants: five.  With the potentials' life starting behind the staging code (template parameter
+// ONE: nothing carried in or out, one chunk) they need about 90 registers and spill nothing: 4.95 ms
+// on the headline layer against 5.32-5.35 for four waves (122 registers) on the same box; the
+// general variant (potentials carried, several chunks) spills 31 dwords around its staging code at
+// five waves and is still the faster one (5.10-5.18).
 #ifndef SNNQP_U8C2_EV1_WPS
 #define SNNQP_U8C2_EV1_WPS 5
 #endif
@@ -91,7 +88,22 @@ template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8, bool ONE = false>
 #ifndef SNNQP_U8C2_ONE_WPS
 #define SNNQP_U8C2_ONE_WPS 4
 #endif
-__global__ void __launch_bounds__(256, IN == SNNQP_EV1 ? SNNQP_U8C2_EV1_WPS : ONE ? SNNQP_U8C2_ONE_WPS : U8C2_WPS)
+// SIX waves for the one variant that fits 80 registers without a spill -- bit-packed frames, ONE,
+// per-channel tables, the tau = 2^j neuron with reset to 0, fused pool: the headline's -- with its
+// table entries read in two halves (tile_epilogue_halves), tile 1's fragment and output word at
+// immediate offsets from tile 0's and the wave index a scalar: 4.82-4.83 ms against 4.96-4.98 at
+// five waves on the same box.  Its siblings would spill 2-6 dwords per patch at six: five.
+#ifndef SNNQP_U8C2_EV1_ONE_WPS
+#define SNNQP_U8C2_EV1_ONE_WPS 6
+#endif
+template <int NF, bool POOL, int LUTM, int IN, bool ONE>
+constexpr int u8c2_waves() {
+  if (IN == SNNQP_EV1 && ONE && LUTM == LUT_CHANNEL && NF == NF_MUL0 && POOL) return SNNQP_U8C2_EV1_ONE_WPS;
+  if (IN == SNNQP_EV1) return SNNQP_U8C2_EV1_WPS;
+  return ONE ? SNNQP_U8C2_ONE_WPS : U8C2_WPS;
+}
+template <int NF, bool POOL, int LUTM, int IN = SNNQP_U8, bool ONE = false>
+__global__ void __launch_bounds__(256, (u8c2_waves<NF, POOL, LUTM, IN, ONE>()))
 conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   constexpr int FL = OutStage<POOL>::FL;
   constexpr bool EV1 = IN == SNNQP_EV1;
@@ -104,7 +116,8 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   const int tc = a.tchunk;                       // <= TCHUNK
   const int lut_off = tc * HIMG2;
   uint32_t *obuf = (uint32_t *)(lds + lut_off + u8c2_table_bytes(LUTM, a.lut_bound, a.lut_rows));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: what hangs on it stays out of the VGPRs)
   const int n = lane & 31, h = lane >> 5;
   const int cout_base = blockIdx.y * 128 + wave * 32;
   const bool wave_on = cout_base < a.Cout;
@@ -468,18 +481,24 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
           uint32_t words[2];
 #pragma unroll
           for (int tl = 0; tl < 2; ++tl) {
-            const v2i_a4 lo = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offA[tl]);
+            // (tile 1 is four halo rows below tile 0: an immediate offset of the read, no register)
+            const v2i_a4 lo = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offA[0] + (uint32_t)(tl * 4 * HROW2));
             const v2i_a4 hi = *(lds_cv2i_t *)(uintptr_t)(img + (uint32_t)offB[tl]);
             v16i acc = splat16(0);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{lo.x, lo.y, hi.x, hi.y}, bw, acc,
                                                         0, 0, 0);
-            words[tl] = tile_epilogue<NF, POOL, MODE, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
-                                                                   lane, acc_off);
+            // (the six-wave build reads its table entries in two halves: eight in flight, not sixteen)
+            if constexpr (u8c2_waves<NF, POOL, LUTM, IN, ONE>() >= 6)
+              words[tl] = tile_epilogue_halves<NF, POOL, MODE, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
+                                                                            lane, acc_off);
+            else
+              words[tl] = tile_epilogue<NF, POOL, MODE, FMA, OFFS>(acc, u[tl], a.dq, lc, a.nrn,
+                                                                     lane, acc_off);
           }
           if (store_lane) {
             uint32_t *o = obuf + ((t0 + tt) % FL) * (OutStage<POOL>::NPIX * 4);
             o[ob0] = words[0] & cmask;
-            o[ob1] = words[1] & cmask;
+            o[ob0 + (POOL ? 32 : 128)] = words[1] & cmask;       // out_pix(1, lane) = out_pix(0, lane) + 8 / + 32
           }
         }
         lds_barrier();

@@ -452,6 +452,40 @@ __device__ __forceinline__ uint32_t tile_epilogue(const v16i &acc, float (&u)[16
   return tile_neurons<NF, POOL, LUTM == LUT_CHANNEL, FMA>(y, u, lc, nrn);
 }
 
+// The same in two halves of four pairs: eight table reads in flight instead of sixteen -- fewer
+// registers alive, for the build that buys a sixth wave per SIMD with them (conv3x3_u8c2.hip)
+template <int NF, bool POOL, int LUTM, bool FMA = false, bool OFFS = false>
+__device__ __forceinline__ uint32_t tile_epilogue_halves(const v16i &acc, float (&u)[16],
+                                                         const Dequant &dq, const LaneConsts &lc,
+                                                         const NeuronP &nrn, int lane, float off = 0.0f) {
+  uint32_t myw = 0;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    v2f y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = dequant_pair<LUTM, OFFS>(acc[8 * g + 2 * j], acc[8 * g + 2 * j + 1], dq, off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 8 * g + 2 * j;
+      unsigned long long m0, m1;
+      neuron_pair<NF, LUTM == LUT_CHANNEL, FMA>(y[j], u[i], u[i + 1], lc, nrn, m0, m1);
+      if (POOL) {
+        const unsigned long long o = m0 | m1;
+        const uint32_t pw = (uint32_t)o | (uint32_t)(o >> 32);
+        myw = writelane_u32(pw, i >> 1, myw);
+      } else {
+        const int r0 = (i & 3) + 8 * (i >> 2);
+        myw = writelane_u32((uint32_t)m0, r0, myw);
+        myw = writelane_u32((uint32_t)(m0 >> 32), r0 + 4, myw);
+        myw = writelane_u32((uint32_t)m1, r0 + 1, myw);
+        myw = writelane_u32((uint32_t)(m1 >> 32), r0 + 5, myw);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return myw;
+}
+
 // Spike words are staged in LDS, obuf[slot = t % FL][pixel][4 words of the 128-
 // channel block], and flushed with 16-byte stores: no global store sits in the
 // per-timestep loop (vmcnt stays a pure load counter there).
