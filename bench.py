@@ -37,8 +37,12 @@ F32_MFMA_PEAK_TOPS = 157.3       # v_mfma_f32_32x32x2_f32: 78.6 T fma/s (MI355X_
 INT8_MFMA_PEAK_TOPS = 5000.0
 FP6_MFMA_PEAK_TOPS = 10000.0
 HBM_PEAK_GBS = 8000.0
-# one wave64 VALU instruction per SIMD every 4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0 * 1e0   # G wave-instructions / s (x 64 lanes each)
+# one wave64 VALU instruction per SIMD every 2 cycles (32 lanes per cycle, MI355X_MICROARCH.md "issues
+# each VALU instruction over 2 cycles"; tools/ubench/pk_f32_rate.hip measures 2.3-2.6 for add / mul /
+# fma with two or more waves, 4.2 for compare / select): 256 CUs x 4 SIMDs x 2.4 GHz / 2.  Rounds 3-5
+# priced this at 4 cycles, which overstated `valu_issue.frac` two-fold; `measured_mix_frac` (the
+# tile's own instruction mix timed alone) is the figure to read.
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s (x 64 lanes each)
 # HBM bytes per launch measured with rocprofv3 --pmc (separate passes of this same
 # command: tools/pmc_profile.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed
 PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
@@ -113,6 +117,12 @@ def parse(argv=None):
                   help="capture model.apply into a hipGraph after the warm-up and replay it in the "
                        "timed steps (for launch-bound configurations such as --model dense; the "
                        "per-kernel times then come from the eager warm-up steps)")
+  ap.add_argument("--detail", type=str, default=None,
+                  help="where the full record goes (per-kernel blocks, per-rank accounts, every leg's "
+                       "rooflines ...): default bench_detail.json beside bench.py, and a copy under "
+                       "gpurun_out/ when that directory exists.  stdout carries ONE compact line (< 6 KB)")
+  ap.add_argument("--full-line", action="store_true",
+                  help="print the full record on stdout instead of the compact line (tools/*.sh)")
   ap.add_argument("--allow-diag", action="store_true",
                   help="accept a diagnostic libsnnqp (SNNQP_DIAG_LIB); the line is marked")
   # test plumbing: the same step / fence / all-reduce code on CPU tensors over gloo with a
@@ -158,8 +168,9 @@ def issued_dtype(args, lb):
 
 def metric_name(args):
   if args.model == "dense":
-    return "samples/sec/node (2-layer qdense 2048-512-%d, T=%d, %d-bit/%.4g%%-pruned)" % (
-        args.classes * 10, args.frames, args.bits, args.prune * 100)
+    how = ("f32 weights" if args.bits < 0 else "%d-bit" % args.bits) + "/" + \
+        ("unpruned" if args.prune < 0 else "%.4g%%-pruned" % (args.prune * 100))
+    return "samples/sec/node (2-layer qdense 2048-512-%d, T=%d, %s)" % (args.classes * 10, args.frames, how)
   lb = layer_bits(args)
   bits = "%d-bit" % lb[0] if len(set(lb)) == 1 else "mixed %s-bit" % "/".join(
       str(b) for b in sorted(set(lb)))
@@ -778,9 +789,11 @@ def main(argv=None):
               ", N(0,1/fan_in) weights, " +
               ("random BatchNorm statistics" if args.random_bn else "BatchNorm as initialised") +
               ", random seeds fixed",
-      "config": {"workload": ("C2: qdense(2048->512)+LIF -> qdense(512->%d)+LIF + vote, [B, T, 2048] "
-                              "binary spikes, T=%d, %d-bit, %.4g%% pruned"
-                              % (args.classes * 10, T, args.bits, args.prune * 100))
+      "config": {"workload": ("%s: qdense(2048->512)+LIF -> qdense(512->%d)+LIF + vote, [B, T, 2048] "
+                              "binary spikes, T=%d, %s"
+                              % ("C1" if args.bits < 0 else "C2", args.classes * 10, T,
+                                 ("float32 weights (no quantiser)" if args.bits < 0 else "%d-bit" % args.bits) + ", " +
+                                 ("no pruning" if args.prune < 0 else "%.4g%% pruned" % (args.prune * 100))))
                              if args.model == "dense" else
                              ("CextNet (reference TCJA model): 5x qconv3x3 blocks + 2 TCJA gates + "
                               "qdense(2048->512->%d) + vote, " % (args.classes * 10)
@@ -810,7 +823,7 @@ def main(argv=None):
     line["DIAGNOSTIC_BUILD"] = build_flags or os.environ.get("SNNQP_DIAG_LIB")
   if args.stand_in:
     line["stand_in"] = True
-    print(json.dumps(line))
+    emit(args, line)
     return
   if args.feed == "host":
     line["pcie_inclusive"] = True
@@ -874,7 +887,88 @@ def main(argv=None):
     }
   if world == 1 and not args.no_cpu_baseline and args.model == "c3":
     line["cpu_baseline"] = cpu_baseline(args, variables_np)
-  print(json.dumps(line))
+  emit(args, line)
+
+
+# the driver keeps the last 8 000 bytes of stdout and parses the final line out of them
+# (BENCH_r05.json: a 29 KB line left `parsed: null`); tests/test_host_cpu.py holds the line to this
+LINE_LIMIT = 6000
+_ROOFLINE_KEYS = ("kernel", "launches_per_step", "avg_launch_ms", "algorithmic_bytes", "traffic", "bound",
+                  "achieved", "peak", "unit", "frac")
+_DENSE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+               "algorithmic_bytes")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "cpu", "sample")
+
+
+def compact(line):
+  """The ONE stdout line: the contract's keys, the dominant kernel's roofline, the dense layer's,
+  the CPU baseline and one {value, ms_per_step, frac} per leg.  Everything else (per-kernel and
+  per-rank blocks, every leg's rooflines, the committed parity summary) is in the detail file."""
+  def pick(d, keys):
+    return {k: d[k] for k in keys if k in d}
+  out = pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                    "scaling", "vs_baseline", "dtype", "data"))
+  out["config"] = pick(line.get("config", {}), ("workload", "batch_per_gpu", "global_batch", "frames",
+                                                "parallelism", "launch"))
+  if line.get("roofline"):
+    out["roofline"] = pick(line["roofline"], _ROOFLINE_KEYS)
+  if line.get("roofline_dense"):
+    out["roofline_dense"] = pick(line["roofline_dense"], _DENSE_KEYS)
+  if line.get("cpu_baseline"):
+    out["cpu_baseline"] = pick(line["cpu_baseline"], _CPU_KEYS)
+  out.update(pick(line, ("ranks_seen", "rank_seconds", "fallbacks", "device_status", "stand_in",
+                         "pcie_inclusive", "DIAGNOSTIC_BUILD")))
+  if line.get("kernels"):
+    out["kernel_ms"] = {t: round(k["avg_ms"], 5) for t, k in line["kernels"].items()}
+
+  def leg_of(d, value_key):
+    r = d.get("roofline_dense") if (d.get("config") or {}).get("model") == "dense" else d.get("roofline")
+    leg = {"value": d[value_key], "ms_per_step": d["ms_per_step"]}
+    if r:
+      leg.update(frac=r["frac"], bound=r["bound"])
+    if d.get("captured"):
+      leg["captured_value"] = d["captured"]["samples_per_s"]
+    return leg
+  legs = {}
+  for name, key in (("fed", "samples_per_s_per_gpu"), ("resident_u8", "samples_per_s"),
+                    ("captured", "samples_per_s"), ("general", "samples_per_s_per_gpu")):
+    if line.get(name):
+      legs[name] = leg_of(line[name], key)
+  for name, d in (line.get("legs") or {}).items():
+    legs[name] = leg_of(d, "samples_per_s")
+  if legs:
+    out["legs"] = legs
+  if line.get("detail"):
+    out["detail"] = line["detail"]
+  return out
+
+
+def emit(args, line):
+  """Rank 0's output: the full record into the detail file(s), the compact line on stdout."""
+  paths = [args.detail] if args.detail else [os.path.join(ROOT, "bench_detail.json")]
+  if not args.detail and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+    paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+  written = []
+  for path in paths:
+    try:
+      with open(path, "w") as f:
+        json.dump(line, f)
+        f.write("\n")
+      written.append(os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)
+    except OSError:
+      pass
+  line["detail"] = written[0] if written else None
+  if args.full_line:
+    print(json.dumps(line), flush=True)
+    return
+  short = compact(line)
+  for drop in (None, "kernel_ms", "legs", "data", "rank_seconds"):     # never lose the line to its own length
+    if drop:
+      short.pop(drop, None)
+    text = json.dumps(short)
+    if len(text) < LINE_LIMIT:
+      break
+  print(text, flush=True)
 
 
 def rooflines_of(args, prof, B, T, lb, notes=None):

@@ -2381,7 +2381,7 @@ def test_dense_block_fp6_mfma(dev, oracle, shape):
   assert ops.fallback_counts()["dense_blocks"] == 0
 
 
-def test_bench_runs_its_collectives_through_rccl_on_one_gpu(dev):
+def test_bench_runs_its_collectives_through_rccl_on_one_gpu(dev, tmp_path):
   """The multi-GPU path's moving parts on the one GPU a test box has: bench.py with
   --single-rank-collective creates the RCCL process group (backend nccl), runs the step's
   all-gather of the logits, the device-bound barrier and the all-reduce of the timing through
@@ -2391,10 +2391,15 @@ def test_bench_runs_its_collectives_through_rccl_on_one_gpu(dev):
   env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
   env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
   p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "16", "--steps", "3",
-                      "--warmup", "1", "--no-cpu-baseline", "--no-fed-leg", "--single-rank-collective"],
+                      "--warmup", "1", "--no-cpu-baseline", "--no-fed-leg", "--single-rank-collective",
+                      "--detail", str(tmp_path / "detail.json")],
                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
   assert p.returncode == 0, p.stderr.decode()[-2000:]
-  d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+  last = p.stdout.decode().rstrip("\n").splitlines()[-1]
+  short = json.loads(last)                       # the compact line the driver parses, last on stdout
+  assert len(last) < 6000 and short["roofline"]["frac"] > 0 and short["device_status"] == 0
+  d = json.load(open(str(tmp_path / "detail.json")))
+  assert d["value"] == short["value"] and d["roofline"]["frac"] == short["roofline"]["frac"]
   assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["collective"].startswith("nccl process group")
   r = d["ranks"][0]
   assert r["rccl"] not in (None, "", "unknown") and r["pci"].count(":") == 2
