@@ -311,8 +311,270 @@ def summarize(c3, c2):
           "per_layer_forced_flip_rate": {k: v["forced_flip_rate"] for k, v in lay.items()}}
 
 
+# ---- the oracle's two free library choices: float32 logistic and reciprocal square root ---------
+#
+# jax.nn.sigmoid (TCJA gate examples/tcja/models.py:95; PLIF / LIF decay spiking_learning.py:381,432)
+# is 1 / (1 + exp(-x)) evaluated in float32 by XLA's CPU expf; flax 0.4.0's BatchNorm multiplies by
+# lax.rsqrt(var + eps) (configured examples/tcja/models.py:101-107).  Neither library is here, so
+# the oracle picked one evaluation of each (float64 expit rounded once; fl(1 / fl(sqrt(v)))).  The
+# families below are the other evaluations a float32 library can plausibly produce, including the
+# two adversarial ones -- EVERY value one ulp above / below the correctly rounded one -- which bound
+# any implementation that is accurate to an ulp.
+
+def _ulps(x, k):
+  x = np.asarray(x, F32)
+  to = F32(np.inf) if k > 0 else F32(-np.inf)
+  for _ in range(abs(k)):
+    x = np.nextafter(x, to)
+  return x.astype(F32)
+
+
+def _expf(x, off=0):
+  """Correctly rounded float32 exp (float64 exp rounded once), optionally `off` ulps away."""
+  return _ulps(np.exp(np.asarray(x, np.float64)).astype(F32), off)
+
+
+def _sig_cr(x):
+  return (1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))).astype(F32)
+
+
+SIGMOID_CHOICES = {
+    "f64_rounded_once": None,                                        # the oracle's choice
+    # jax 0.2.27 expit: lax.div(1, lax.add(1, lax.exp(lax.neg(x)))), every op rounded to float32
+    "f32_1_over_1p_exp": lambda x: (F32(1) / (F32(1) + _expf(-x))).astype(F32),
+    "f32_1_over_1p_exp_expf+1ulp": lambda x: (F32(1) / (F32(1) + _expf(-x, +1))).astype(F32),
+    "f32_1_over_1p_exp_expf-1ulp": lambda x: (F32(1) / (F32(1) + _expf(-x, -1))).astype(F32),
+    "f32_exp_over_1p_exp": lambda x: (_expf(x) / (F32(1) + _expf(x))).astype(F32),
+    "f32_half_tanh": lambda x: (F32(0.5) * np.tanh(F32(0.5) * np.asarray(x, np.float64)).astype(F32)
+                                + F32(0.5)).astype(F32),
+    "all+1ulp": lambda x: _ulps(_sig_cr(x), +1),
+    "all-1ulp": lambda x: _ulps(_sig_cr(x), -1),
+}
+
+
+def _rsqrt_cr(v):
+  return (1.0 / np.sqrt(np.asarray(v, np.float64))).astype(F32)
+
+
+def _rsqrt_newton(v):
+  """A 12-bit estimate refined by one float32 Newton step (the shape of a vectorised rsqrt)."""
+  v = np.asarray(v, F32)
+  y = _rsqrt_cr(v)
+  y = (y.view(np.uint32) & np.uint32(0xFFFFF000)).view(F32)        # keep 11 mantissa bits
+  return (y * (F32(1.5) - (F32(0.5) * v) * y * y)).astype(F32)
+
+
+RSQRT_CHOICES = {
+    "1_over_sqrt": None,                                             # the oracle's choice
+    "rsqrt_correctly_rounded": _rsqrt_cr,
+    "rsqrt_estimate_newton": _rsqrt_newton,
+    "all+1ulp": lambda v: _ulps(_rsqrt_cr(v), +1),
+    "all-1ulp": lambda v: _ulps(_rsqrt_cr(v), -1),
+}
+
+
+class _choice:
+  def __init__(self, sigmoid=None, rsqrt=None):
+    self.new = (sigmoid, rsqrt)
+
+  def __enter__(self):
+    self.old = (o.SIGMOID, o.RSQRT)
+    o.SIGMOID, o.RSQRT = self.new
+
+  def __exit__(self, *exc):
+    o.SIGMOID, o.RSQRT = self.old
+    return False
+
+
+def _ulp_distance(a, b):
+  """Largest distance in float32 ulps between two positive float32 arrays."""
+  a = np.asarray(a, F32).view(np.int32).astype(np.int64)
+  b = np.asarray(b, F32).view(np.int32).astype(np.int64)
+  return int(np.abs(a - b).max()) if a.size else 0
+
+
+_CEXT_RASTERS = ("pool0", "pool1", "pool2", "conv_t_0", "conv_t_1", "dense1_s", "dense2_s")
+
+
+def _cextnet_run(v, x, bits, neuron_cfg=None):
+  from tests.helpers import bn_of, qweight_of
+  p = v["params"]
+  return o.cextnet_forward(
+      x, [qweight_of(o, p["QuantConv_%d" % i], bits) for i in (0, 1, 2, 3, 6)],
+      [bn_of(v, i) for i in range(5)],
+      [(qweight_of(o, p["QuantConv_4"], bits), qweight_of(o, p["QuantConv_5"], bits)),
+       (qweight_of(o, p["QuantConv_7"], bits), qweight_of(o, p["QuantConv_8"], bits))],
+      [qweight_of(o, p["QuantDense_0"], bits), qweight_of(o, p["QuantDense_1"], bits)], neuron_cfg)
+
+
+def _against(base, other, acc):
+  for name in _CEXT_RASTERS:
+    d = acc["raster_flips"].setdefault(name, {"flips": 0, "neuron_steps": 0})
+    d["flips"] += int(np.count_nonzero(base[name] != other[name]))
+    d["neuron_steps"] += int(base[name].size)
+  for g in ("gate0", "gate1"):
+    acc["gate_max_ulps"][g] = max(acc["gate_max_ulps"].get(g, 0), _ulp_distance(base[g], other[g]))
+    acc["gate_values_changed"][g] = acc["gate_values_changed"].get(g, 0) + \
+        int(np.count_nonzero(base[g] != other[g]))
+    acc["gate_values"][g] = acc["gate_values"].get(g, 0) + int(base[g].size)
+  eq = np.all(base["logits"] == other["logits"], axis=1)
+  acc["logits_bit_equal"] += int(np.count_nonzero(eq))
+  acc["argmax_equal"] += int(np.count_nonzero(np.argmax(base["logits"], 1) == np.argmax(other["logits"], 1)))
+  acc["samples"] += int(eq.size)
+  acc["logits_max_abs_diff"] = max(acc["logits_max_abs_diff"], float(np.abs(base["logits"] - other["logits"]).max()))
+
+
+def _new_acc():
+  return {"raster_flips": {}, "gate_max_ulps": {}, "gate_values_changed": {}, "gate_values": {},
+          "logits_bit_equal": 0, "argmax_equal": 0, "samples": 0, "logits_max_abs_diff": 0.0}
+
+
+def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, lam=0.1, seed=991,
+                    neuron_cfg=None, sigmoids=None, rsqrts=None):
+  """Full CextNet (5 conv blocks + 2 TCJA gates + 2 dense, random BatchNorm statistics), run end to
+  end under every alternative evaluation of the logistic (gates; decay when `neuron_cfg` names a
+  PLIF / LIF neuron) and of BatchNorm's reciprocal square root, each against the oracle's own
+  choice on the same inputs: raster flips per layer (free-running: a flip propagates), how far
+  the gates move, and whether the logits stay bit-equal."""
+  from snnquantprune_amd import synthetic as syn
+  v = syn.cextnet_variables(frames=frames, hw=hw, prune_p=prune, random_bn=True)
+  sig = SIGMOID_CHOICES if sigmoids is None else sigmoids
+  rsq = RSQRT_CHOICES if rsqrts is None else rsqrts
+  runs = [("sigmoid", k, f, None) for k, f in sig.items() if f is not None] + \
+         [("rsqrt", k, None, f) for k, f in rsq.items() if f is not None]
+  accs = {(kind, name): _new_acc() for kind, name, _, _ in runs}
+  rates = {n: [] for n in _CEXT_RASTERS}
+  for b0 in range(0, samples, chunk):
+    nb = min(chunk, samples - b0)
+    x = syn.poisson_spikes((nb, frames, hw, hw, 2), lam, seed=seed + b0)
+    base = _cextnet_run(v, x, bits, neuron_cfg)
+    for n in _CEXT_RASTERS:
+      rates[n].append(float(np.mean(base[n])))
+    for kind, name, fs, fr in runs:
+      with _choice(fs, fr):
+        other = _cextnet_run(v, x, bits, neuron_cfg)
+      _against(base, other, accs[(kind, name)])
+  # how many of the 5 x C BatchNorm multipliers each rsqrt evaluation changes, and by how much
+  muls = {}
+  for name, f in rsq.items():
+    with _choice(None, f):
+      muls[name] = np.concatenate([o.bn_coeffs(**{k: a for k, a in _bn(v, i).items()})[1] for i in range(5)])
+  base_name = [k for k, f in rsq.items() if f is None][0]
+  out = {"config": "CextNet: 5x qconv3x3 + 2 TCJA gates + qdense(2048->512->110), %dx%dx2, T=%d, %d-bit, %g%% "
+                   "pruned, random BatchNorm statistics, Poisson(%g)>0 spikes%s"
+                   % (hw, hw, frames, bits, prune * 100, lam,
+                      "" if not neuron_cfg else ", neuron %s" % neuron_cfg.get("kind")),
+         "samples": samples, "firing_rate": {n: float(np.mean(r)) for n, r in rates.items()},
+         "sigmoid": {}, "rsqrt": {},
+         "bn_multipliers": {name: {"changed": int(np.count_nonzero(m != muls[base_name])), "of": int(m.size),
+                                   "max_ulps": _ulp_distance(m / np.sign(m), muls[base_name] / np.sign(muls[base_name]))}
+                            for name, m in muls.items() if name != base_name}}
+  for (kind, name), a in accs.items():
+    for d in a["raster_flips"].values():
+      d["rate"] = d["flips"] / max(d["neuron_steps"], 1)
+    a["logits_bit_equal"] = "%d/%d" % (a["logits_bit_equal"], a["samples"])
+    a["argmax_equal"] = "%d/%d" % (a["argmax_equal"], a["samples"])
+    out[kind][name] = a
+  return out
+
+
+def _bn(v, i):
+  from tests.helpers import bn_of
+  return bn_of(v, i)
+
+
+def decay_choices(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, seed=4343):
+  """PLIF (one learnt scalar, spiking_learning.py:381) and LIF (one per neuron, :432) decays
+  k = sigmoid(tau) under every logistic, on the C2 head at full size: how many decays change,
+  the rasters' flips and the logits."""
+  from snnquantprune_amd import synthetic as syn
+  from tests.helpers import qweight_of
+  v = syn.dense_net_variables(K, hidden, nout, True, prune)
+  q1 = qweight_of(o, v["params"]["QuantDense_0"], bits)
+  q2 = qweight_of(o, v["params"]["QuantDense_1"], bits)
+  x = np.swapaxes(syn.poisson_spikes((B, T, K), 0.1, seed=seed), 0, 1)
+  rng = np.random.Generator(np.random.PCG64(seed + 1))
+  taus = {"parametric_leaky_IF": [{"kind": "parametric_leaky_IF", "tau_param": np.array([t], F32)}
+                                  for t in (0.3, -0.7, 1.1, 2.3)],
+          "LIF": [None]}
+  out = {"config": "C2 head: qdense(%d->%d) -> qdense(%d->%d), T=%d, B=%d, %d-bit, %g%% pruned; PLIF with "
+                   "tau_param in {0.3, -0.7, 1.1, 2.3}; LIF with tau ~ N(0, 1) per neuron"
+                   % (K, hidden, hidden, nout, T, B, bits, prune * 100), "kinds": {}}
+  tv1, tv2 = rng.standard_normal(hidden).astype(F32), rng.standard_normal(nout).astype(F32)
+
+  def run(cfgs):
+    u1, s1 = o.dense_block(x, q1, cfgs[0], "int")
+    u2, s2 = o.dense_block(s1, q2, cfgs[1], "int")
+    return s1, s2, o.vote(s2)
+  for kind, plist in taus.items():
+    res = {}
+    for name, f in SIGMOID_CHOICES.items():
+      if f is None:
+        continue
+      a = {"decays_changed": 0, "decays": 0, "flips": {"dense1": 0, "dense2": 0},
+           "neuron_steps": {"dense1": 0, "dense2": 0}, "logits_bit_equal": 0, "samples": 0}
+      for pc in plist:
+        cfgs = (pc, pc) if pc is not None else ({"kind": "LIF", "tau_vec": tv1}, {"kind": "LIF", "tau_vec": tv2})
+        tau_all = np.concatenate([np.ravel(c.get("tau_param", c.get("tau_vec"))) for c in
+                                  (cfgs if pc is None else cfgs[:1])])
+        base = run(cfgs)
+        k0 = o.sigmoid_f32(tau_all)
+        with _choice(f, None):
+          other = run(cfgs)
+          k1 = o.sigmoid_f32(tau_all)
+        a["decays_changed"] += int(np.count_nonzero(k0 != k1)); a["decays"] += int(k0.size)
+        for li, ln in ((0, "dense1"), (1, "dense2")):
+          a["flips"][ln] += int(np.count_nonzero(base[li] != other[li]))
+          a["neuron_steps"][ln] += int(base[li].size)
+        a["logits_bit_equal"] += int(np.count_nonzero(np.all(base[2] == other[2], 1)))
+        a["samples"] += int(base[2].shape[0])
+      a["logits_bit_equal"] = "%d/%d" % (a["logits_bit_equal"], a["samples"])
+      res[name] = a
+    out["kinds"][kind] = res
+  return out
+
+
+def summarize_choices(cext, decay, cext_plif=None):
+  def worst(block):
+    w = {}
+    for name, a in block.items():
+      for layer, d in a["raster_flips"].items():
+        if d["rate"] >= w.get(layer, (-1.0, ""))[0]:
+          w[layer] = (d["rate"], name)
+    return {layer: {"max_flip_rate": r, "under": n} for layer, (r, n) in w.items()}
+  plausible = lambda block: {k: a for k, a in block.items() if not k.startswith("all")}
+  s = {"what": "the oracle's own evaluation of the float32 logistic (float64 expit rounded once) and of "
+               "BatchNorm's reciprocal square root (fl(1 / fl(sqrt(v)))) against the other evaluations a "
+               "float32 library can produce, full CextNet geometry end to end, CPU.  'all+-1ulp' move "
+               "EVERY value one ulp: a bound for any implementation accurate to one ulp, not a candidate",
+       "samples": cext["samples"],
+       "sigmoid_plausible_total_flips": int(sum(d["flips"] for a in plausible(cext["sigmoid"]).values()
+                                                for d in a["raster_flips"].values())),
+       "rsqrt_plausible_total_flips": int(sum(d["flips"] for a in plausible(cext["rsqrt"]).values()
+                                              for d in a["raster_flips"].values())),
+       "sigmoid_worst_per_layer": worst(cext["sigmoid"]), "rsqrt_worst_per_layer": worst(cext["rsqrt"]),
+       "sigmoid_logits_bit_equal": {k: a["logits_bit_equal"] for k, a in cext["sigmoid"].items()},
+       "rsqrt_logits_bit_equal": {k: a["logits_bit_equal"] for k, a in cext["rsqrt"].items()},
+       "sigmoid_argmax_equal": {k: a["argmax_equal"] for k, a in cext["sigmoid"].items()},
+       "rsqrt_argmax_equal": {k: a["argmax_equal"] for k, a in cext["rsqrt"].items()},
+       "gate_max_ulps": {k: a["gate_max_ulps"] for k, a in cext["sigmoid"].items()},
+       "bn_multipliers": cext["bn_multipliers"],
+       "decay": {kind: {k: {"decays_changed": "%d/%d" % (a["decays_changed"], a["decays"]),
+                            "flips": a["flips"], "logits_bit_equal": a["logits_bit_equal"]}
+                        for k, a in res.items()} for kind, res in decay["kinds"].items()}}
+  if cext_plif is not None:
+    s["cextnet_plif_sigmoid_logits_bit_equal"] = {k: a["logits_bit_equal"] for k, a in cext_plif["sigmoid"].items()}
+    s["cextnet_plif_total_flips"] = {k: int(sum(d["flips"] for d in a["raster_flips"].values()))
+                                     for k, a in cext_plif["sigmoid"].items()}
+  return s
+
+
 def main():
   ap = argparse.ArgumentParser()
+  ap.add_argument("--choices", action="store_true",
+                  help="instead of int-vs-float: the oracle's logistic / rsqrt choices against the "
+                       "alternatives (profiles/r06_oracle_choices.json)")
+  ap.add_argument("--plif-samples", type=int, default=4)
   ap.add_argument("--samples", type=int, default=8)
   ap.add_argument("--perms", type=int, default=8, help="random K permutations under BLAS")
   ap.add_argument("--seq-samples", type=int, default=2, help="C3 samples under the sequential order")
@@ -320,6 +582,22 @@ def main():
   ap.add_argument("--out", default=None)
   args = ap.parse_args()
   t0 = time.time()
+  if args.choices:
+    cext = cextnet_choices(args.samples)
+    decay = decay_choices()
+    plif = cextnet_choices(args.plif_samples, neuron_cfg={"kind": "parametric_leaky_IF",
+                                                          "tau_param": np.array([0.3], F32)},
+                           rsqrts={"1_over_sqrt": None}) if args.plif_samples > 0 else None
+    rep = {"summary": summarize_choices(cext, decay, plif), "cextnet": cext, "decay": decay,
+           "cextnet_plif": plif, "seconds": round(time.time() - t0, 1),
+           "generated_by": "python -m oracle.int_vs_float --choices --samples %d --plif-samples %d"
+                           % (args.samples, args.plif_samples)}
+    txt = json.dumps(rep, indent=1, sort_keys=True)
+    print(txt)
+    if args.out:
+      with open(args.out, "w") as f:
+        f.write(txt + "\n")
+    return
   orders = make_orders(args.perms, args.samples, args.seq_samples, args.tree_samples)
   c3 = c3_report(args.samples, orders=orders)
   c2 = c2_report(orders=orders)

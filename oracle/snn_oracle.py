@@ -636,8 +636,21 @@ def heaviside(x):
   return (np.asarray(x, dtype=F32) >= F32(0)).astype(F32)
 
 
+# Two float32 library functions of the reference's path live in jax / XLA, not under
+# /root/reference, and their last bit is not pinned by anything here: the logistic of the TCJA gate
+# and of the PLIF / LIF decay (jax.nn.sigmoid -> 1 / (1 + exp(-x)) in float32, XLA's expf), and the
+# reciprocal square root of BatchNorm (flax 0.4.0 _normalize: lax.rsqrt(var + eps)).  The oracle's
+# choice for each is below; oracle/int_vs_float.py (--choices) installs the other plausible
+# evaluations through these two hooks and counts what they change downstream.
+SIGMOID = None       # None: float64 expit rounded once to float32
+RSQRT = None         # None: fl(1 / fl(sqrt(v))), two float32 roundings
+
+
 def sigmoid_f32(x):
-  """Host-side sigmoid used for PLIF / LIF decay: float64 expit rounded once."""
+  """jax.nn.sigmoid on float32 (TCJA gate models.py:95, PLIF / LIF decay
+  spiking_learning.py:381,432): float64 expit rounded once, unless SIGMOID is installed."""
+  if SIGMOID is not None:
+    return np.asarray(SIGMOID(np.asarray(x, dtype=F32)), dtype=F32)
   return (1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))).astype(F32)
 
 
@@ -681,7 +694,8 @@ def bn_coeffs(mean, var, scale=None, bias=None, eps=1e-5):
   mul = fl(fl(1 / sqrt(var + eps)) * scale)  (models.py:101-107)."""
   mean = np.asarray(mean, dtype=F32)
   var = np.asarray(var, dtype=F32)
-  mul = F32(1) / np.sqrt(var + F32(eps))
+  v = (var + F32(eps)).astype(F32)
+  mul = F32(1) / np.sqrt(v) if RSQRT is None else np.asarray(RSQRT(v), dtype=F32)
   if scale is not None:
     mul = mul * np.asarray(scale, dtype=F32)
   b = np.zeros_like(mean) if bias is None else np.asarray(bias, dtype=F32)
@@ -878,7 +892,7 @@ def tcja(x_seq, qw_t: QWeight, qw_c: QWeight, probes: Optional[dict] = None, tag
   conv_t = np.transpose(conv_t, (2, 0, 1))               # [T, B, C]
   conv_c = np.transpose(conv_c, (1, 0, 2))               # [T, B, C]
   z = (conv_c * conv_t).astype(F32)
-  gate = (1.0 / (1.0 + np.exp(-z.astype(np.float64)))).astype(F32)
+  gate = sigmoid_f32(z)                                  # models.py:95
   return (x_seq * gate[:, :, None, None, :]).astype(F32), gate
 
 

@@ -601,8 +601,10 @@ __device__ __forceinline__ v16i splat16(int v) {
 // with itself -- every replay finds zeroed words.  (A memset node in front of the kernel node,
 // the obvious way, aborted on the replay of the second graph captured in a process in round 3,
 // and in round 5 a memset node in front of the dense hand-over never reached its target in the
-// second graph a framework captured -- profiles/r05_capture_memset.txt, DESIGN.md 4.4 / 4.6;
-// plain-HIP graphs show neither.  The library records no memset node: kernels zero.)  A word that is NOT zero at a replay makes workgroups skip
+// second graph a framework captured -- profiles/r05_capture_memset.txt; round 6 walked the nodes
+// (profiles/r06_capture_memset_nodes.txt): the node is there and correctly addressed, the runtime's
+// replay of it writes another memset node's fill-kernel arguments instead of zeros.  The library
+// records no memset node: kernels zero.)  A word that is NOT zero at a replay makes workgroups skip
 // patches: finish() tallies the patches and reports a mismatch through the device's status word
 // (runtime.hip).  The pool must
 // exist by then -- nothing may be allocated during a capture: one eager launch on the device,

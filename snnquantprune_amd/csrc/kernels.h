@@ -33,10 +33,13 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
 // probe of the matrix pipe's denormal arithmetic behind DQ_TABLE
 uint32_t *device_status_word(int dev);
 // `nwords` 32-bit words at `p` := 0 on `st`, by a kernel of the library (a kernel node when the
-// stream is being captured).  Not hipMemsetAsync: a memset node in front of a captured kernel
-// did not reach its target on replay when the target lay in a framework's graph-private memory
-// pool (tools/capture_ws_debug.py, profiles/r05_capture_memset.txt; round 3 met the same with the
-// conv kernels' queue slots) -- kernel nodes with the same pointers always have.
+// stream is being captured).  Not hipMemsetAsync: on replay the runtime (ROCm 7.2.0) executed a
+// small memset node of one graph with stale data -- the node was present and correctly addressed
+// (hipGraphMemsetNodeGetParams), yet its target received the argument block of the fill kernel of
+// ANOTHER graph's memset node ({dst, pattern chunk, dst}, the chunk advancing per replay) instead
+// of zeros: profiles/r06_capture_memset_nodes.txt (tools/capture_ws_debug.py --dump); round 3 met
+// the same with the conv kernels' queue slots.  A kernel node carries its pointer in its own
+// argument block and always has.
 int zero_words_async(uint32_t *p, int64_t nwords, hipStream_t st);
 uint32_t device_status_read(int dev);
 const char *device_status_text(uint32_t code);

@@ -539,10 +539,14 @@ class CapturedApply:
       # the conv launches recorded below take a work-queue slot each (snnqp.h): remember which,
       # so that they go back to the pool with this object
       mark = ops.workqueue_capture_mark(self._device)
+      # hand-over workspaces allocated inside the capture stay referenced by this object
+      self._workspaces, outer = [], ops._CAPTURE_KEEP
+      ops._CAPTURE_KEEP = self._workspaces
       try:
         with torch.cuda.graph(self._graph, stream=self._stream):
           self.static_output = module.apply(variables, self.static_input, **kwargs)
       finally:
+        ops._CAPTURE_KEEP = outer
         self._slots = (mark, ops.workqueue_capture_mark(self._device))
     cur.wait_stream(self._stream)
 

@@ -979,6 +979,9 @@ def dense_lif_forward(x, weight: Weight, K: int, N: int, neuron: Neuron,
 
 
 _dense_ws = {}
+# workspaces allocated inside the capture that is being recorded: linen.CapturedApply installs a
+# list here and keeps it, so that the block is not handed to a later allocation of the same capture
+_CAPTURE_KEEP = None
 
 
 def _dense_workspace(dev, nbytes: int):
@@ -989,11 +992,16 @@ def _dense_workspace(dev, nbytes: int):
   other -- grown as needed.  A launch that is being captured into a hipGraph gets a workspace of
   its OWN, allocated inside the capture, i.e. from the graph's private memory pool: the address
   baked into the graph lives exactly as long as the graph, is never handed to an eager launch and
-  never to another graph (two live captures replayed on two streams cannot meet in one)."""
+  never to another graph (two live captures replayed on two streams cannot meet in one).  The
+  capture object keeps the tensor (_CAPTURE_KEEP), so no later allocation of the same capture gets
+  the block either."""
   if nbytes <= 0:
     return None
   if torch.cuda.is_current_stream_capturing():
-    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if _CAPTURE_KEEP is not None:
+      _CAPTURE_KEEP.append(ws)
+    return ws
   key = (torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream)
   ws = _dense_ws.get(key)
   if ws is None or ws.numel() < nbytes:

@@ -338,6 +338,76 @@ def test_int_contract_against_reference_literal_float_at_baseline_size(oracle):
   assert c3["argmax_equal"] == "1/1" and c2["argmax_equal"] == "64/64"
 
 
+def test_oracle_free_library_choices_are_bounded(oracle):
+  """The two float32 library functions of the path that live in jax / XLA and whose last bit nothing
+  under /root/reference pins -- the logistic (TCJA gate examples/tcja/models.py:95, PLIF / LIF decay
+  spiking_learning.py:381,432) and BatchNorm's reciprocal square root (flax 0.4.0 _normalize,
+  configured models.py:101-107): the oracle's evaluation of each against the other evaluations a
+  float32 library can produce (oracle/int_vs_float.py --choices).  Committed table: full CextNet
+  geometry (128x128x2, T = 20, random BatchNorm statistics), 16 samples end to end; live: a small
+  geometry, and the hooks themselves."""
+  import json
+  from oracle import int_vs_float as ivf
+  x = np.array([-9.3, -2.0, -0.3, 0.0, 0.11, 0.9, 4.0, 17.5], np.float32)
+  base = oracle.sigmoid_f32(x)
+  assert base.dtype == np.float32 and base[3] == np.float32(0.5)
+  for name, f in ivf.SIGMOID_CHOICES.items():
+    if f is None:
+      continue
+    with ivf._choice(f, None):
+      alt = oracle.sigmoid_f32(x)
+    assert oracle.SIGMOID is None                      # the hook is restored
+    far = 1 << 20 if name == "f32_half_tanh" else 3    # 0.5 tanh(x / 2) + 0.5 loses the small values (absolute error 6e-8)
+    assert ivf._ulp_distance(base, alt) <= far, (name, base, alt)
+    if name.startswith("all"):
+      assert np.all(alt != base)
+  v = np.array([0.3, 1.0 + 1e-5, 1.7, 2.9, 11.0], np.float32)
+  for name, f in ivf.RSQRT_CHOICES.items():
+    if f is None:
+      continue
+    with ivf._choice(None, f):
+      _, mul, _ = oracle.bn_coeffs(np.zeros(5, np.float32), v - np.float32(1e-5), None, None)
+    assert oracle.RSQRT is None
+    assert ivf._ulp_distance(mul, oracle.bn_coeffs(np.zeros(5, np.float32), v - np.float32(1e-5))[1]) <= 3, name
+  # live, small: every alternative runs end to end and is compared layer by layer
+  live = ivf.cextnet_choices(samples=2, frames=4, hw=32, chunk=2)
+  assert set(live["sigmoid"]) == {k for k, f in ivf.SIGMOID_CHOICES.items() if f is not None}
+  assert set(live["rsqrt"]) == {k for k, f in ivf.RSQRT_CHOICES.items() if f is not None}
+  assert live["sigmoid"]["f32_1_over_1p_exp"]["gate_values_changed"]["gate0"] > 0      # they DO differ
+  assert live["bn_multipliers"]["rsqrt_correctly_rounded"]["changed"] > 0
+  for a in live["sigmoid"].values():
+    assert set(a["raster_flips"]) == set(ivf._CEXT_RASTERS)
+    for early in ("pool0", "pool1", "pool2", "conv_t_0"):     # in front of the first gate: untouched
+      assert a["raster_flips"][early]["flips"] == 0
+  # committed, full geometry
+  with open(os.path.join(ROOT, "profiles", "r06_oracle_choices.json")) as f:
+    rep = json.load(f)
+  s, c = rep["summary"], rep["cextnet"]
+  assert s["samples"] >= 8 and "128x128x2, T=20" in c["config"] and "random BatchNorm" in c["config"]
+  assert c["sigmoid"]["f32_1_over_1p_exp"]["raster_flips"]["pool0"]["neuron_steps"] == \
+      s["samples"] * 20 * 64 * 64 * 128
+  for name, r in c["firing_rate"].items():
+    assert 0.01 < r < 0.5, (name, r)
+  # every evaluation a float32 library plausibly produces: no raster flips, logits bit-equal
+  assert s["sigmoid_plausible_total_flips"] == 0 and s["rsqrt_plausible_total_flips"] == 0
+  n = "%d/%d" % (s["samples"], s["samples"])
+  for k, v_ in list(s["sigmoid_logits_bit_equal"].items()) + list(s["rsqrt_logits_bit_equal"].items()):
+    if not k.startswith("all"):
+      assert v_ == n, (k, v_)
+  # the adversarial bound (EVERY multiplier / gate one ulp off): flips stay rare, the class survives
+  for k in ("all+1ulp", "all-1ulp"):
+    assert s["rsqrt_argmax_equal"][k] == n and s["sigmoid_argmax_equal"][k] == n
+    for layer, d in c["rsqrt"][k]["raster_flips"].items():
+      assert d["rate"] <= (3e-3 if layer.startswith("dense") else 1e-4), (k, layer, d)
+  assert s["gate_max_ulps"]["f32_1_over_1p_exp"]["gate0"] <= 3
+  # decays: the plausible logistics change some decay constants by an ulp and no spike
+  for kind in ("parametric_leaky_IF", "LIF"):
+    for k, a in s["decay"][kind].items():
+      if not k.startswith("all"):
+        assert a["flips"] == {"dense1": 0, "dense2": 0}, (kind, k, a)
+  assert int(s["decay"]["LIF"]["f32_1_over_1p_exp"]["decays_changed"].split("/")[0]) > 0
+
+
 def test_gint_contraction_against_the_float_modes(oracle):
   """The `gint` contraction of the conv block behind a TCJA gate (gated_conv: integer sums per
   channel, one fmaf chain over the gates) against the two float32 restatements of the same layer on
