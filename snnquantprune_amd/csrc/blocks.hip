@@ -31,17 +31,6 @@ void note_fallback(bool dense, const char *why) {
 }
 }  // namespace
 
-// a kernel on the device of `st` reported a broken invariant (runtime.hip): refuse to go on
-static int refuse_after_device_report(hipStream_t st, const char *who) {
-  const uint32_t code = device_status_read(stream_device(st));
-  if (code) {
-    set_error("%s: device status 0x%x: %s (snnqp_device_status(..., reset = 1) clears it)", who,
-              (unsigned)code, device_status_text(code));
-    return SNNQP_EHIP;
-  }
-  return SNNQP_OK;
-}
-
 extern "C" {
 
 int snnqp_fallback_counts(int64_t *conv_blocks, int64_t *dense_blocks, char *reason,

@@ -26,7 +26,10 @@ struct GenericArgs {
   void *s_out;               // spikes (neuron) or float32 currents (no neuron)
   int32_t s_type;
   int32_t *acc_out;          // optional int32 accumulators (no-neuron mode)
-  int64_t total;             // B * OH * OW * Cout (OH, OW: pooled when the pool is fused)
+  int64_t total;             // threads: B * OD * WH * WW * Cout
+  int64_t total_out;         // outputs: B * OD * OH * OW * Cout (OH, OW: pooled when the pool is fused)
+  int32_t WH, WW;            // windows walked: OH x OW, or ceil(FH / 2) x ceil(FW / 2) when a fused pool
+                             // over an odd image must still carry the potentials of the edge neurons
   int32_t FH, FW;            // full-resolution output size (u0 / u_out)
   const int32_t *pred;       // nullable device word: skip the launch unless *pred != 0
   // depth axis of a 3-D convolution (images [D][H][W][Cin], kernels [KD][KH][KW][Cin/g][Cout]);
@@ -51,7 +54,10 @@ __device__ __forceinline__ float load_float(const void *x, int64_t pix_off,
 // POOL = 2: a thread owns the 2x2 window of neurons behind one POOLED output (their four membrane
 // potentials) and writes the OR of their spikes -- the max-pool of examples/tcja/models.py:145-147
 // fused, as the MFMA kernels have it; a.total, a.OH / a.OW then count pooled outputs, a.FH / a.FW
-// the full-resolution ones (u0 / u_out).  pred: the whole launch is skipped unless *pred != 0 when
+// the full-resolution ones (u0 / u_out).  An odd FH / FW leaves a last row / column of neurons the
+// pool drops (reduce_window without padding); when their potentials are wanted (u_out) the walk
+// covers ceil(FH / 2) x ceil(FW / 2) windows, the edge ones partly outside, and only windows
+// inside OH x OW write a spike.  pred: the whole launch is skipped unless *pred != 0 when
 // the stream reaches it (the float32 re-evaluation behind a speculative integer launch).
 template <int IN, bool INTPATH, int POOL>
 __global__ void __launch_bounds__(256)
@@ -68,8 +74,8 @@ generic_block_kernel(GenericArgs a) {
     const bool live = idx < a.total;
     int64_t r = live ? idx : 0;
     const int32_t co = (int32_t)(r % g.Cout); r /= g.Cout;
-    const int32_t px = (int32_t)(r % a.OW); r /= a.OW;
-    const int32_t py = (int32_t)(r % a.OH); r /= a.OH;
+    const int32_t px = (int32_t)(r % a.WW); r /= a.WW;
+    const int32_t py = (int32_t)(r % a.WH); r /= a.WH;
     const int32_t pz = (int32_t)(r % a.OD); r /= a.OD;
     const int32_t b = (int32_t)r;
     const int32_t grp = co / a.CoutG;
@@ -82,20 +88,24 @@ generic_block_kernel(GenericArgs a) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       u[p] = 0.0f;
-      if (live && a.u0 && a.nrn.kind != SNNQP_NEURON_NONE)
+      if (live && a.u0 && a.nrn.kind != SNNQP_NEURON_NONE && py * POOL + p / POOL < a.FH && px * POOL + p % POOL < a.FW)
         u[p] = a.u0[((((int64_t)b * a.OD + pz) * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co];
     }
 
     for (int32_t t = 0; t < a.T; ++t) {
       const int64_t img_off = (int64_t)t * a.xs_t + (int64_t)b * a.xs_b;
-      const int64_t o = (int64_t)t * a.total + idx;
+      // (every window inside OH x OW has all its neurons inside FH x FW)
+      const bool out_ok = live && py < a.OH && px < a.OW;
+      const int64_t o_pix = (((int64_t)b * a.OD + pz) * a.OH + py) * a.OW + px;
+      const int64_t o = (int64_t)t * a.total_out + o_pix * g.Cout + co;
       bool s = false;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int32_t oy = py * POOL + p / POOL, ox = px * POOL + p % POOL;
         int iacc = 0;
         float facc = 0.0f;
-        if (live) {
+        const bool inb = live && oy < a.FH && ox < a.FW;
+        if (inb) {
           for (int32_t kd = 0; kd < a.KD; ++kd) {
             const int32_t zd = pz * a.stride_d - a.pad_d_lo + kd * a.k_dil_d;
             if (zd < 0 || zd >= a.Dd || (zd % a.in_dil_d) != 0) continue;
@@ -134,28 +144,29 @@ generic_block_kernel(GenericArgs a) {
           }
           continue;
         }
-        if (live) s |= neuron_step(u[p], cur, a.nrn, dec);
+        if (inb) s |= neuron_step(u[p], cur, a.nrn, dec);
       }
       if (a.nrn.kind == SNNQP_NEURON_NONE) continue;
       if (a.s_type == SNNQP_F32) {
-        if (live) ((float *)a.s_out)[o] = s ? 1.0f : 0.0f;
+        if (out_ok) ((float *)a.s_out)[o] = s ? 1.0f : 0.0f;
       } else if (word_aligned) {
-        // Cout % 32 == 0: the packed layout is the linear bit index idx.
+        // Cout % 32 == 0: the packed layout is the linear bit index o; 32 consecutive lanes are the
+        // 32 channels of one word of one pixel (idx, hence co, is a multiple of 32 at lane 0 / 32)
         const unsigned long long m = __ballot(s);
         const int lane = threadIdx.x & 63;
-        if (live && (lane & 31) == 0)
+        if (out_ok && (lane & 31) == 0)
           ((uint32_t *)a.s_out)[o >> 5] = (uint32_t)(lane ? (m >> 32) : m);
-      } else if (live && s) {
-        const int64_t row = idx / g.Cout;
-        const int64_t rows = a.total / g.Cout;
-        atomicOr(&((uint32_t *)a.s_out)[((int64_t)t * rows + row) * CWout + (co >> 5)],
+      } else if (out_ok && s) {
+        const int64_t rows = a.total_out / g.Cout;
+        atomicOr(&((uint32_t *)a.s_out)[((int64_t)t * rows + o_pix) * CWout + (co >> 5)],
                  1u << (co & 31));
       }
     }
     if (live && a.u_out && a.nrn.kind != SNNQP_NEURON_NONE) {
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        a.u_out[((((int64_t)b * a.OD + pz) * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co] = u[p];
+        if (py * POOL + p / POOL < a.FH && px * POOL + p % POOL < a.FW)
+          a.u_out[((((int64_t)b * a.OD + pz) * a.FH + (py * POOL + p / POOL)) * a.FW + (px * POOL + p % POOL)) * g.Cout + co] = u[p];
     }
   }
 }
@@ -226,7 +237,10 @@ int run_generic(const void *x, int in_type, int64_t xs_t, int64_t xs_b, int32_t 
   a.bn = make_bn(bn); a.nrn = make_neuron(nrn);
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.s_type = s_type;
   a.acc_out = acc_out;
-  a.total = (int64_t)B * a.OD * a.OH * a.OW * g->Cout;
+  a.WH = a.OH; a.WW = a.OW;
+  if (pool == 2 && u_out) { a.WH = (OH + 1) / 2; a.WW = (OW + 1) / 2; }
+  a.total_out = (int64_t)B * a.OD * a.OH * a.OW * g->Cout;
+  a.total = (int64_t)B * a.OD * a.WH * a.WW * g->Cout;
   if (a.total == 0 || T == 0) return SNNQP_OK;
   if (a.nrn.kind == SNNQP_NEURON_LIF)
     SNNQP_REQUIRE(a.nrn.decay, SNNQP_EINVAL, "LIF neuron needs a decay vector");
@@ -297,6 +311,7 @@ extern "C" int snnqp_conv_forward_if(const int32_t *pred, const void *x, int in_
   using namespace snnqp;
   SNNQP_REQUIRE(pred && g, SNNQP_EINVAL, "conv_forward_if: null argument");
   SNNQP_REQUIRE(NB >= 0 && NB < (1ll << 31), SNNQP_EINVAL, "conv_forward_if: bad NB");
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "conv_forward_if")) return rc;
   const int64_t pix = (in_type == SNNQP_BITS) ? (g->Cin + 31) / 32 : g->Cin;
   const int64_t img = (int64_t)g->H * g->W * pix;
   return run_generic(x, in_type, 0, img, 1, (int32_t)NB, g, w, nullptr, nullptr, nullptr, nullptr, y,
@@ -347,6 +362,7 @@ extern "C" int snnqp_conv3d_lif_forward(const int32_t *pred, const void *x, int 
   snnqp_conv_geom_t g;
   GenericDepth dz;
   if (int rc = split_geom3(g3, &g, &dz)) return rc;
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "conv3d_lif_forward")) return rc;
   SNNQP_REQUIRE(!nrn || (nrn->kind >= SNNQP_NEURON_NONE && nrn->kind <= SNNQP_NEURON_LIF), SNNQP_EINVAL,
                 "conv3d_lif_forward: unknown neuron kind %d", nrn ? nrn->kind : -1);
   return run_generic(x, in_type, x_stride_t, x_stride_b, T, B, &g, w, bn, nrn, u0, u_out, s_out, s_type,

@@ -42,6 +42,7 @@ uint32_t *device_status_word(int dev);
 // argument block and always has.
 int zero_words_async(uint32_t *p, int64_t nwords, hipStream_t st);
 uint32_t device_status_read(int dev);
+int refuse_after_device_report(hipStream_t st, const char *who);   // SNNQP_EHIP while the status word is set
 const char *device_status_text(uint32_t code);
 bool dq_table_trusted(int dev, hipStream_t st);
 void check_code_bound_once(int dev, const int8_t *w, int64_t K, int32_t N, int32_t bound, hipStream_t st);

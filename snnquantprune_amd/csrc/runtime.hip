@@ -274,6 +274,17 @@ int64_t dq_table_fallbacks(bool reset) {
   return reset ? g_dq_fallbacks.exchange(0) : g_dq_fallbacks.load(std::memory_order_relaxed);
 }
 
+// a kernel on the device of `st` reported a broken invariant: the block entry points refuse to go on
+int refuse_after_device_report(hipStream_t st, const char *who) {
+  const uint32_t code = device_status_read(stream_device(st));
+  if (code) {
+    set_error("%s: device status 0x%x: %s (snnqp_device_status(..., reset = 1) clears it)", who,
+              (unsigned)code, device_status_text(code));
+    return SNNQP_EHIP;
+  }
+  return SNNQP_OK;
+}
+
 }  // namespace snnqp
 
 extern "C" int snnqp_device_status(int device, uint32_t *codes, int reset) {

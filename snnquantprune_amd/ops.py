@@ -1032,7 +1032,9 @@ def dense_head_forward(x, w1: Weight, K: int, N1: int, nrn1: Neuron, w2: Weight,
     if fallback is None or fallback.x is not None:
       raise ValueError("float32 rows into the fused head need a FloatFallback of the first block")
     x_flags = torch.empty(1, dtype=torch.int32, device=dev)
-  redo = fallback is not None          # the predicated launches go through both rasters
+  elif fallback is not None:
+    raise ValueError("a FloatFallback goes with float32 rows; uint8 / bit-packed rows have nothing to redo")
+  redo = in_type == L.F32              # the predicated launches go through both rasters
   s1 = torch.empty((T, B, (N1 + 31) // 32), dtype=torch.int32, device=dev) if (want_s1 or redo) else None
   s2 = torch.empty((T, B, (N2 + 31) // 32), dtype=torch.int32, device=dev) if (want_s2 or redo) else None
   a, b, n1, n2 = w1.struct(), w2.struct(), nrn1.struct(), nrn2.struct()

@@ -345,22 +345,33 @@ class SpikingBlock(nn.Module):
       fbw = pk.float_weight()
       T_ = x.shape[0] if tm else x.shape[1]
       if is_dense:
+        # what the wide kernel stages in place (dense_wide.hip, dense_wide_unsupported): K a multiple
+        # of 16 and at most 65536 (int32 sums of x - 128), more than 128 features, T <= 64, aligned
+        # rows, and 32-bit byte offsets within a workgroup's 128 samples
+        B_ = x.shape[1] if tm else x.shape[0]
+        xs_t, xs_b = (B_ * cin, cin) if tm else (cin, T_ * cin)
         direct = (x.ndim == 3 and w.wt is not None and w.col_sum is not None and cin % 16 == 0
-                  and conn.features > 128 and T_ <= 64 and self.impl == L.IMPL_AUTO and packed_out
-                  and (x.data_ptr() & 15) == 0 and x.is_contiguous())
+                  and cin <= 65536 and conn.features > 128 and T_ <= 64 and self.impl == L.IMPL_AUTO
+                  and packed_out and (x.data_ptr() & 15) == 0 and x.is_contiguous()
+                  and (max(T_ - 1, 0) * xs_t + 128 * xs_b + cin) * 4 < (1 << 31))
       else:
         direct = (x.ndim == 5 and self.impl != L.IMPL_GENERIC and packed_out
                   and self._event_layer_geometry(conn.geometry(tuple(x.shape[2:-1]), cin)))
+      x_f32 = x
+
+      def narrowed():
+        """One device pass in front of the integer kernel (spike bits for layers wide enough for
+        the bit kernels, else uint8 counts), reporting into the predicate of the float32 launch."""
+        if not is_dense and cin >= 32:
+          xn, pred = ops.pack_bits_checked(x_f32)
+        else:
+          xn, pred = ops.narrow_f32_async(x_f32)
+        return xn, ops.FloatFallback(fbw, x=x_f32, pred=pred)
       if direct:
         fb = ops.FloatFallback(fbw)
-      elif not is_dense and cin >= 32:
-        xb, pred = ops.pack_bits_checked(x)
-        fb = ops.FloatFallback(fbw, x=x, pred=pred)
-        x = xb
       else:
-        xu, pred = ops.narrow_f32_async(x)
-        fb = ops.FloatFallback(fbw, x=x, pred=pred)
-        x = xu
+        x, fb = narrowed()
+        spec = False               # nothing left to retry: the integer kernels take the narrowed tensor
     if flat is not None:
       # float path: the fmaf order is the channel-major one -> reorder the data
       c, h, ww = flat
@@ -406,9 +417,19 @@ class SpikingBlock(nn.Module):
     if is_dense:
       if x.ndim != 3:
         raise ValueError("QuantDense block expects [T, B, K] inputs, got %s" % (x.shape,))
-      u_out, s = ops.dense_lif_forward(x, w, cin, conn.features, nrn, bn=bn, u0=u0,
-                                       want_u=self.return_state, packed_out=packed_out,
-                                       impl=self.impl, time_major=tm, fallback=fb)
+      try:
+        u_out, s = ops.dense_lif_forward(x, w, cin, conn.features, nrn, bn=bn, u0=u0,
+                                         want_u=self.return_state, packed_out=packed_out,
+                                         impl=self.impl, time_major=tm, fallback=fb)
+      except L.SnnqpError as e:
+        # a float32 tensor the integer kernel turned out not to stage in place (a shape the
+        # predicate above does not know): narrow it and launch again -- nothing has run yet
+        if e.code != L.EUNSUPPORTED or not spec:
+          raise
+        x, fb = narrowed()
+        u_out, s = ops.dense_lif_forward(x, w, cin, conn.features, nrn, bn=bn, u0=u0,
+                                         want_u=self.return_state, packed_out=packed_out,
+                                         impl=self.impl, time_major=tm, fallback=fb)
       if self.pool == 2:
         raise ValueError("pool=2 needs a convolutional block")
       return u_out, s
@@ -452,21 +473,38 @@ class SpikingBlock(nn.Module):
       w = dataclasses.replace(w, min_current_bits=ops.current_min_bits(
           w, bn, int(w.abs_sum_max), geom.Cout))
     x_seen = hint.seen_word() if hint is not None else None
-    try:
-      u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
-                                      want_u=self.return_state, packed_out=packed_out,
-                                      pool=self.pool, impl=impl, time_major=tm,
-                                      x_max=x_max, x_seen=x_seen, fallback=fb)
-    except L.SnnqpError as e:
-      if e.code != L.EUNSUPPORTED or self.pool != 2 or impl == L.IMPL_MFMA:
-        raise
-      u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
-                                      want_u=self.return_state, packed_out=packed_out,
-                                      pool=1, impl=impl, time_major=tm, x_max=x_max,
-                                      x_seen=x_seen, fallback=fb)
-      s = ops.maxpool2x2(s)
+    for attempt in (0, 1):
+      try:
+        u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
+                                        want_u=self.return_state, packed_out=packed_out,
+                                        pool=self.pool, impl=impl, time_major=tm,
+                                        x_max=x_max, x_seen=x_seen, fallback=fb)
+        break
+      except L.SnnqpError as e:
+        if (e.code == L.EUNSUPPORTED and spec and attempt == 0 and isinstance(x, torch.Tensor)
+            and x.dtype == torch.float32):
+          # float32 frames the event layer does not stage in place after all (a shape the predicate
+          # above does not know): narrow them and launch again -- nothing has run yet
+          x, fb = narrowed()
+          if nsp == 1:
+            x = x.reshape(T, B, 1, geom.W, cin)
+          spec, hint, x_seen, x_max = False, None, None, 0
+          continue
+        if e.code != L.EUNSUPPORTED or self.pool != 2 or impl == L.IMPL_MFMA:
+          raise
+        u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
+                                        want_u=self.return_state, packed_out=packed_out,
+                                        pool=1, impl=impl, time_major=tm, x_max=x_max,
+                                        x_seen=x_seen, fallback=fb)
+        s = ops.maxpool2x2(s)
+        break
     if hint is not None:
       hint.launched()
+    return self._finish_conv((u_out, s), nsp, T, B)
+
+  @staticmethod
+  def _finish_conv(out, nsp, T, B):
+    u_out, s = out
     if nsp == 1:
       if isinstance(s, ops.PackedSpikes):
         s = s.reshape_leading(T, B, s.shape[3])

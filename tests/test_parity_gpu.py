@@ -3301,6 +3301,99 @@ def test_float32_activations_through_the_narrowing_passes(dev, oracle):
   assert ops.device_status() == 0
 
 
+def test_float32_fallback_keeps_the_edge_neurons_of_an_odd_pooled_image(dev, oracle):
+  """A pooled conv block on a 7 x 7 image with return_state: the 2x2 pool drops the last row and
+  column of neurons from the raster (reduce_window without padding, examples/tcja/models.py:145-147),
+  but the carry holds a membrane potential for every neuron.  Integer-valued float32 input (integer
+  kernels) and input with a non-integer (the predicated float32 kernel, which walks 2x2 windows:
+  ADVICE r05) must both return every potential, the edge ones included, bit-exact."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import ops, synthetic as syn
+  from snnquantprune_amd.flax_qconv import QuantConv
+  from snnquantprune_amd.spiking_learning import SpikingBlock
+  cfg = syn.make_config(bits=4, prune_percentage=0.9)
+  for hw, cin in ((7, 128), (5, 2), (9, 32)):
+    c = cases.conv_block_case(T=3, B=2, hw=hw, cin=cin, seed=931 + hw)
+    qw = qweight_of(oracle, c["leaf"], c["bits"])
+    blk = SpikingBlock(connection_fn=QuantConv(features=128, kernel_size=(3, 3), padding=((1, 1), (1, 1)),
+                                               use_bias=False, config=cfg.quant, bits=4, g_scale=cfg.quant.g_scale),
+                       neural_dynamics=cfg.neuron_dynamics(dtype=torch.float32),
+                       norm_fn=nn.BatchNorm(use_running_average=True, momentum=0.9, epsilon=1e-5),
+                       pool=2, return_state=True)
+    variables = nn.tree_from_numpy({"params": {"connection_fn": c["leaf"],
+                                               "norm_fn": {"scale": c["bn"]["scale"], "bias": c["bn"]["bias"]}},
+                                    "batch_stats": {"norm_fn": {"mean": c["bn"]["mean"], "var": c["bn"]["var"]}}}, dev)
+    x = c["x"].astype(F32)
+    pos = np.arange(x.size).reshape(x.shape)
+    for xin, mode in ((x, "int"), (np.where(pos == 77, 0.5, x).astype(F32), "fseq")):
+      eu, es = oracle.conv_block(xin, qw, c["bn"], None, mode)
+      assert eu.shape == (2, hw, hw, 128) and np.abs(eu[:, hw - 1]).max() > 0      # the edge row is alive
+      u, s = blk.apply(variables, None, _t(xin, dev))
+      np.testing.assert_array_equal(_np(s), packbits_lastaxis(oracle.max_pool_2x2(es)), err_msg="%s %d" % (mode, hw))
+      np.testing.assert_array_equal(_np(u), eu, err_msg="%s %d" % (mode, hw))
+  assert ops.device_status() == 0
+
+
+def test_float32_rows_the_wide_kernel_cannot_stage_are_narrowed_not_refused(dev, oracle):
+  """float32 rows into a wide quantised dense block (more than 128 features) whose shape the wide
+  kernel does not stage in place -- K beyond 65536 (int32 sums of x - 128), or a tensor whose rows
+  lie beyond 32-bit byte offsets within a workgroup (2 GiB of float32) -- must take the narrowing
+  pass like uint8 rows of the same shape take the other kernels, not raise (the host's
+  `direct` predicate now mirrors dense_wide_unsupported, and an EUNSUPPORTED from a speculative
+  launch narrows and relaunches)."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import ops, synthetic as syn
+  from snnquantprune_amd.flax_qdense import QuantDense
+  from snnquantprune_amd.spiking_learning import SpikingBlock
+  cfg8 = syn.make_config(bits=8, prune_percentage=0.5)
+
+  def block(N):
+    return SpikingBlock(connection_fn=QuantDense(N, use_bias=False, config=cfg8.quant, bits=8,
+                                                 g_scale=cfg8.quant.g_scale),
+                        neural_dynamics=cfg8.neuron_dynamics(dtype=torch.float32), return_state=True)
+  # K = 65 552 (a multiple of 16 beyond 65 536), 160 features
+  K, N = 65552, 160
+  leaf = syn.quant_leaf((K, N), 30.0, 941, True, 0.5)
+  qd = qweight_of(oracle, leaf, 8)
+  x = syn.poisson_spikes((3, 4, K), 0.1, seed=942).astype(F32)
+  pos = np.arange(x.size).reshape(x.shape)
+  dvars = nn.tree_from_numpy({"params": {"connection_fn": leaf}}, dev)
+  for xin, mode in ((x, "int"), (np.where(pos == 4321, 0.25, x).astype(F32), "fseq")):
+    eu, es = oracle.dense_block(xin, qd, None, mode)
+    u, s = block(N).apply(dvars, None, _t(xin, dev))
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(es), err_msg=mode)
+    np.testing.assert_array_equal(_np(u), eu, err_msg=mode)
+  assert 0.01 < es.mean() < 0.6
+  # rows beyond 32-bit byte offsets: [T = 64, B = 4200, K = 2048] float32 = 2.2 GB, time-major
+  T, B, K, N = 64, 4200, 2048, 160
+  leaf = syn.quant_leaf((K, N), 4.0, 943, True, 0.5)
+  qd = qweight_of(oracle, leaf, 8)
+  dvars = nn.tree_from_numpy({"params": {"connection_fn": leaf}}, dev)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(944)
+  xu = (torch.rand((T, B, K), device=dev, generator=gen) < 0.1).to(torch.uint8)
+  xf = xu.to(torch.float32)
+  assert xf.numel() * 4 >= (1 << 31)
+  u8, s8 = block(N).apply(dvars, None, xu)
+  uf, sf = block(N).apply(dvars, None, xf)
+  assert torch.equal(s8.bits, sf.bits) and torch.equal(u8, uf)
+  # ... and against the oracle on the first and the last samples of the batch (samples are independent)
+  for sl in (slice(0, 6), slice(B - 6, B)):
+    eu, es = oracle.dense_block(_np(xu[:, sl]), qd, None, "int")
+    np.testing.assert_array_equal(_np(sf.bits[:, sl]), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(uf[sl]), eu)
+  # one non-integer value in the last sample: the float32 kernel redoes the block
+  xf[T - 1, B - 1, 5] = 0.5
+  uf2, sf2 = block(N).apply(dvars, None, xf)
+  eu, es = oracle.dense_block(_np(xf[:, B - 2:]), qd, None, "fseq")
+  np.testing.assert_array_equal(_np(sf2.bits[:, B - 2:]), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(uf2[B - 2:]), eu)
+  del xf, xu
+  torch.cuda.empty_cache()
+  assert ops.device_status() == 0
+
+
 @pytest.mark.parametrize("shape", [(3, 2, 8, 8, 128, 128), (2, 3, 5, 11, 64, 70), (1, 2, 16, 16, 96, 160),
                                    (2, 1, 4, 8, 32, 32), (3, 2, 8, 8, 128, 128, 8), (2, 3, 5, 11, 64, 70, 6)],
                          ids=["cextnet_conv_t_1", "ragged_image_and_outputs", "96_in_160_out", "one_patch",
