@@ -3381,13 +3381,13 @@ def test_float32_rows_the_wide_kernel_cannot_stage_are_narrowed_not_refused(dev,
   # ... and against the oracle on the first and the last samples of the batch (samples are independent)
   for sl in (slice(0, 6), slice(B - 6, B)):
     eu, es = oracle.dense_block(_np(xu[:, sl]), qd, None, "int")
-    np.testing.assert_array_equal(_np(sf.bits[:, sl]), packbits_lastaxis(es))
+    np.testing.assert_array_equal(_np(sf.bits[:, sl]).view(np.uint32), packbits_lastaxis(es))
     np.testing.assert_array_equal(_np(uf[sl]), eu)
   # one non-integer value in the last sample: the float32 kernel redoes the block
   xf[T - 1, B - 1, 5] = 0.5
   uf2, sf2 = block(N).apply(dvars, None, xf)
   eu, es = oracle.dense_block(_np(xf[:, B - 2:]), qd, None, "fseq")
-  np.testing.assert_array_equal(_np(sf2.bits[:, B - 2:]), packbits_lastaxis(es))
+  np.testing.assert_array_equal(_np(sf2.bits[:, B - 2:]).view(np.uint32), packbits_lastaxis(es))
   np.testing.assert_array_equal(_np(uf2[B - 2:]), eu)
   del xf, xu
   torch.cuda.empty_cache()
