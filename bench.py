@@ -297,6 +297,7 @@ def config_leg(base_args, overrides, dev, steps, warmup, capture):
   B, T = a.batch, a.frames
   model, variables, _ = build_model(a, dev)
   x, _ = build_input(a, dev, 0, B, T, 128, ops)
+  ops.reset_count_hints(dev)        # another data stream: what the event layer saw in the last leg does not apply
 
   def step():
     ops.forget_inputs()
@@ -398,6 +399,7 @@ def general_leg(args, model, dev, B, T, parallel, fence, steps, warmup):
                     generator=gen).clamp_(max=15).to(torch.uint8)
   feeder = make_feeder(ops.pack_frames(x, L_.EV4), dev)
   del x
+  ops.reset_count_hints(dev)        # (a stream of count frames begins: the hint settles within two batches)
 
   def step():
     ops.forget_inputs()

@@ -197,9 +197,10 @@ typedef struct {
  * x_flags of snnqp_conv_lif_forward / snnqp_dense_lif_forward_ws / snnqp_dense_head_forward, the
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
  * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if,
- * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max / ch_slots, the *_gated_*_ex pack calls).  A binding compares snnqp_version()
+ * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max / ch_slots, the *_gated_*_ex pack calls; 502:
+ * snnqp_pack_frames_checked, snnqp_conv_lif_forward_pred).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
-#define SNNQP_VERSION 501
+#define SNNQP_VERSION 502
 int snnqp_version(void);
 const char *snnqp_last_error(void);
 /* Extra compiler flags the library was built with: "" for the product build
@@ -274,6 +275,18 @@ int snnqp_pack_frames(const uint8_t *x, int64_t frames, int32_t H, int32_t W, in
                       void *y, int32_t *flags, snnqp_stream_t stream);
 int snnqp_unpack_frames(const void *x, int fmt, int64_t frames, int32_t H, int32_t W,
                         uint8_t *y, snnqp_stream_t stream);
+/* uint8 (in_type SNNQP_U8) or float32 (SNNQP_F32: the reference's own input dtype,
+ * flax_qconv.py:101) frames [frames][H][W][2] -> SNNQP_EV1 in ONE pass at the rate of HBM, with
+ * the check the event layer would make while staging them: `flags` (required; zeroed by this call
+ * on `stream`) receives SNNQP_FLAG_GT_ONE when a value is neither 0 (-0.0 counts) nor 1, and
+ * SNNQP_FLAG_NOT_INTEGER when a float32 value is not an integer in [0, 255].  A flagged result is
+ * not the tensor: it serves as the speculative half of
+ *     snnqp_pack_frames_checked(x, ..., ev1, flags);
+ *     snnqp_conv_lif_forward(ev1, SNNQP_EV1, ...);                 binary frames: 1/8 .. 1/32 of the bytes,
+ *     snnqp_conv_lif_forward_pred(flags, x, in_type, ...);         the event layer's fastest variant
+ * where the last call redoes the block on the frames as they are iff the word is set. */
+int snnqp_pack_frames_checked(const void *x, int in_type, int64_t frames, int32_t H, int32_t W,
+                              uint32_t *y, int32_t *flags, snnqp_stream_t stream);
 int snnqp_pack_bits(const void *x, int in_type, int64_t rows, int32_t C,
                     uint32_t *bits, snnqp_stream_t stream);
 /* the same, and SNNQP_FLAG_GT_ONE is OR-ed into the device word `flags` (nullable; zeroed by the
@@ -425,6 +438,23 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                            float *u_out, void *s_out, int s_type, int pool,
                            int impl, int x_max, int32_t *x_seen, int32_t *x_flags,
                            snnqp_stream_t stream);
+
+/* snnqp_conv_lif_forward on the event layer's MFMA kernel (3x3, stride 1, pad 1, Cin = 2; in_type
+ * SNNQP_U8, SNNQP_EV4 or SNNQP_F32), enqueued unconditionally but EXECUTED only if *pred != 0 when the
+ * stream reaches it: the frames in their own format behind a speculative launch on their
+ * bit-packed copy (snnqp_pack_frames_checked).  Same arguments and results as
+ * snnqp_conv_lif_forward with SNNQP_IMPL_MFMA (x_flags is zeroed on the stream whether or not the
+ * kernel runs; x_seen is reported into only when it runs); SNNQP_EUNSUPPORTED for any other block.
+ * When it does not run it costs one grid of workgroups that return at once.
+ * replaces: the same call site as snnqp_conv_lif_forward. */
+int snnqp_conv_lif_forward_pred(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                                int64_t x_stride_b, int32_t T, int32_t B,
+                                const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                                const int8_t *wt, const snnqp_bn_t *bn,
+                                const snnqp_neuron_t *nrn, const float *u0,
+                                float *u_out, void *s_out, int s_type, int pool,
+                                int x_max, int32_t *x_seen, int32_t *x_flags,
+                                snnqp_stream_t stream);
 
 /* The same block on the direct-form kernel (any geometry, any types; SNNQP_W_F32 weights: the
  * fmaf chain over (kh, kw, cin) ascending), enqueued unconditionally but EXECUTED only if

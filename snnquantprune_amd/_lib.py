@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsnnqp.so")
 
 # include/snnqp.h SNNQP_VERSION the prototypes below were written against
-ABI_VERSION = 501
+ABI_VERSION = 502
 
 # enums of include/snnqp.h
 F32, U8, BITS, EV1, EV4 = 0, 1, 2, 3, 4
@@ -113,6 +113,12 @@ _PROTOTYPES = {
         c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
         POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "snnqp_conv_lif_forward_pred": (c_int, [
+        c_void_p, c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
+        POINTER(WeightT), c_void_p, POINTER(BnT), POINTER(NeuronT), c_void_p,
+        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "snnqp_pack_frames_checked": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                          c_void_p]),
     "snnqp_conv_lif_forward_if": (c_int, [
         c_void_p, c_void_p, c_int, c_int64, c_int64, c_int32, c_int32, POINTER(ConvGeomT),
         POINTER(WeightT), POINTER(BnT), POINTER(NeuronT), c_void_p, c_void_p, c_void_p, c_int, c_int,

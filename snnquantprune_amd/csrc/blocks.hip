@@ -95,6 +95,30 @@ int snnqp_conv_lif_forward(const void *x, int in_type, int64_t x_stride_t,
                      u_out, s_out, s_type, nullptr, (hipStream_t)stream);
 }
 
+int snnqp_conv_lif_forward_pred(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
+                                int64_t x_stride_b, int32_t T, int32_t B,
+                                const snnqp_conv_geom_t *g, const snnqp_weight_t *w,
+                                const int8_t *wt, const snnqp_bn_t *bn,
+                                const snnqp_neuron_t *nrn,
+                                const float *u0, float *u_out, void *s_out,
+                                int s_type, int pool, int x_max, int32_t *x_seen,
+                                int32_t *x_flags, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(pred && g && w && nrn, SNNQP_EINVAL, "conv_lif_forward_pred: null argument");
+  if (in_type == SNNQP_F32 && w->wtype == SNNQP_W_I8)
+    SNNQP_REQUIRE(x_flags != nullptr, SNNQP_EINVAL,
+                  "conv_lif_forward_pred: float32 input into integer codes needs x_flags (snnqp.h)");
+  if (int rc = refuse_after_device_report((hipStream_t)stream, "conv_lif_forward_pred")) return rc;
+  SNNQP_REQUIRE(nrn->kind >= SNNQP_NEURON_MULTI_STEP_LIF && nrn->kind <= SNNQP_NEURON_LIF, SNNQP_EINVAL,
+                "conv_lif_forward_pred: unknown neuron kind %d", nrn->kind);
+  SNNQP_REQUIRE(pool == 1 || pool == 2, SNNQP_EINVAL, "conv_lif_forward_pred: pool must be 1 or 2");
+  SNNQP_REQUIRE(in_type == SNNQP_U8 || in_type == SNNQP_F32 || in_type == SNNQP_EV4, SNNQP_EUNSUPPORTED,
+                "conv_lif_forward_pred: byte, nibble or float32 frames (the event layer's own formats)");
+  const char *why = conv3x3_mfma_unsupported(in_type, g, w, wt, nrn, s_type);
+  SNNQP_REQUIRE(!why, SNNQP_EUNSUPPORTED, "conv_lif_forward_pred: MFMA kernel: %s", why);
+  return run_conv3x3_mfma(x, in_type, x_stride_t, x_stride_b, T, B, g, w, wt, bn, nrn, u0, u_out,
+                          (uint32_t *)s_out, pool, x_max, x_seen, x_flags, (hipStream_t)stream, pred);
+}
+
 int snnqp_conv_lif_forward_if(const int32_t *pred, const void *x, int in_type, int64_t x_stride_t,
                               int64_t x_stride_b, int32_t T, int32_t B,
                               const snnqp_conv_geom_t *g, const snnqp_weight_t *w,

@@ -112,6 +112,12 @@ conv3x3_u8c2_kernel(ConvMfmaArgs a) {
   // converted to the two count bytes and checked while they wait in registers (snnqp.h, x_flags)
   constexpr bool F32IN = IN == SNNQP_F32;
   static_assert(TCHUNK % FL == 0, "flush period must divide the staging chunk");
+  // a predicated launch (snnqp_conv_lif_forward_pred: the frames again in their own format behind
+  // a speculative bit-packed launch) returns at once unless the word is set -- before any
+  // workgroup has touched a queue word, which therefore stay zero for the slot's next user
+  if constexpr (!EV1) {
+    if (a.pred && *(const volatile int32_t *)a.pred == 0) return;
+  }
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tc = a.tchunk;                       // <= TCHUNK
   const int lut_off = tc * HIMG2;
@@ -786,8 +792,10 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st) {
-  SNNQP_REQUIRE(w->w && ((x && s_out) || T == 0 || B == 0), SNNQP_EINVAL, "conv3x3 mfma: null pointer");   // (an empty batch has no buffers)
+                     int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st, const int32_t *pred) {
+  SNNQP_REQUIRE(w->w && ((x && s_out) || T == 0 || B == 0), SNNQP_EINVAL, "conv3x3 mfma: null pointer");
+  SNNQP_REQUIRE(!pred || in_type == SNNQP_U8 || in_type == SNNQP_F32 || in_type == SNNQP_EV4, SNNQP_EUNSUPPORTED,
+                "conv3x3 mfma: only the event layer on byte / nibble / float32 frames takes a predicate");   // (an empty batch has no buffers)
   SNNQP_REQUIRE(in_type != SNNQP_BITS || wt, SNNQP_EINVAL,
                 "conv3x3 mfma: bit input needs the MFMA-tiled codes `wt`");
   SNNQP_REQUIRE(T >= 0 && B >= 0, SNNQP_EINVAL, "conv3x3 mfma: negative T/B");
@@ -809,6 +817,7 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
   a.u0 = u0; a.u_out = u_out; a.s_out = s_out; a.pool = pool;
   a.x_seen = x_seen;
   a.x_flags = nullptr;
+  a.pred = pred;
   if (in_type == SNNQP_F32) {
     SNNQP_REQUIRE(x_flags != nullptr && (((uintptr_t)x) & 7) == 0 && xs_t % 2 == 0 && xs_b % 2 == 0,
                   SNNQP_EINVAL, "conv3x3 mfma: float32 frames need x_flags and 8-byte aligned pixels");

@@ -84,6 +84,7 @@ struct ConvMfmaArgs {
   uint32_t *sched;    // work queues of this launch (launch_persistent), or null: static walk
   uint32_t *status;   // the device's status word (runtime.hip), or null
   int32_t patch_h;    // rows of a patch: 8 (two 4x8 tiles), or 4 (conv3x3_bits.hip, one tile)
+  const int32_t *pred;  // u8c2 kernel on byte / float32 frames: (nullable) the launch runs only if *pred != 0
 };
 
 // Work queues of one launch: per blockIdx.y, one patch counter per XCD queue and one count

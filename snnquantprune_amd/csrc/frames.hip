@@ -4,7 +4,7 @@
 // <= 15) so that the host -> device feed moves 1/8 or 1/2 of the uint8 bytes.  One pass
 // each, HBM-bound; conv3x3_u8c2.hip stages EV1 frames directly, every other consumer
 // unpacks first.
-#include "common.h"
+#include "kernels.h"
 
 namespace snnqp {
 
@@ -51,6 +51,54 @@ pack_ev1_kernel(const uint8_t *__restrict__ x, int64_t frames, int64_t fbytes, i
     y[i] = word;
   }
   if (flags && gt) atomicOr(flags, SNNQP_FLAG_GT_ONE);
+}
+
+// float32 frames (the reference's own input dtype, flax_qconv.py:101) -> EV1: 32 values = 128 bytes
+// per word.  A value that is neither 0.0 (-0.0 counts) nor 1.0 -- a count, a fraction, a NaN --
+// raises SNNQP_FLAG_GT_ONE (and SNNQP_FLAG_NOT_INTEGER when it is not an integer in [0, 255]): the
+// packed frames then are not the tensor.
+__global__ void __launch_bounds__(256)
+pack_ev1_f32_kernel(const float *__restrict__ x, int64_t frames, int64_t fvals, int64_t fwords,
+                    uint32_t *__restrict__ y, int32_t *__restrict__ flags) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int64_t n = frames * fwords;
+  uint32_t notbin = 0, notint = 0;
+  const bool vec = ((uintptr_t)x & 15) == 0 && (fvals & 31) == 0;
+  auto one = [&](float v) -> uint32_t {
+    const bool is1 = v == 1.0f, is0 = v == 0.0f;
+    notbin |= (is1 || is0) ? 0u : 1u;
+    notint |= (v >= 0.0f && v <= 255.0f && v == __builtin_rintf(v)) ? 0u : 1u;
+    return is1 ? 1u : 0u;
+  };
+  if (vec) {
+    // frames of whole words lie back to back: a lane takes 16 bytes (four values, a nibble of the
+    // word), a wave 1 KiB in one coalesced request; the eight lanes of a word OR their nibbles
+    // together (units = 8 x words and the grid stride is a multiple of 64: a word's lanes are
+    // always in the loop together)
+    const int64_t units = n * 8;
+    const int lane8 = threadIdx.x & 7;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+      const v4f v = ((const v4f *)x)[u];
+      uint32_t w = (one(v.x) | (one(v.y) << 1) | (one(v.z) << 2) | (one(v.w) << 3)) << (4 * lane8);
+      w |= (uint32_t)__shfl_xor((int)w, 1);
+      w |= (uint32_t)__shfl_xor((int)w, 2);
+      w |= (uint32_t)__shfl_xor((int)w, 4);
+      if (lane8 == 0) y[u >> 3] = w;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t f = i / fwords, wi = i - f * fwords;
+      const float *src = x + f * fvals + wi * 32;
+      uint32_t word = 0;
+      const int64_t left = fvals - wi * 32;
+      for (int j = 0; j < 32 && j < left; ++j) word |= one(src[j]) << j;
+      y[i] = word;
+    }
+  }
+  if (flags && (notbin | notint))
+    atomicOr(flags, (notbin ? SNNQP_FLAG_GT_ONE : 0) | (notint ? SNNQP_FLAG_NOT_INTEGER : 0));
 }
 
 __global__ void __launch_bounds__(256)
@@ -129,6 +177,27 @@ int snnqp_pack_frames(const uint8_t *x, int64_t frames, int32_t H, int32_t W, in
                        (hipStream_t)stream, x, frames * (int64_t)H * W, (uint8_t *)y, flags);
     SNNQP_CHECK_LAUNCH("pack_ev4_kernel");
   }
+  return SNNQP_OK;
+}
+
+int snnqp_pack_frames_checked(const void *x, int in_type, int64_t frames, int32_t H, int32_t W,
+                              uint32_t *y, int32_t *flags, snnqp_stream_t stream) {
+  SNNQP_REQUIRE(frames >= 0 && H > 0 && W > 0, SNNQP_EINVAL, "pack_frames_checked: bad shape");
+  SNNQP_REQUIRE(in_type == SNNQP_U8 || in_type == SNNQP_F32, SNNQP_EINVAL,
+                "pack_frames_checked: frames must be uint8 or float32");
+  SNNQP_REQUIRE(flags, SNNQP_EINVAL, "pack_frames_checked: null flag word");
+  // the flag word is zeroed on the stream in front of every pass (a kernel node under capture)
+  if (int rc = zero_words_async((uint32_t *)flags, 1, (hipStream_t)stream)) return rc;
+  if (frames == 0) return SNNQP_OK;
+  SNNQP_REQUIRE(x && y, SNNQP_EINVAL, "pack_frames_checked: null argument");
+  const int64_t fvals = (int64_t)H * W * 2, fwords = (fvals + 31) / 32;
+  if (in_type == SNNQP_U8)
+    hipLaunchKernelGGL(pack_ev1_kernel, dim3(grid_of(frames * fwords)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)x, frames, fvals, fwords, y, flags);
+  else
+    hipLaunchKernelGGL(pack_ev1_f32_kernel, dim3(grid_of(frames * fwords * 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)x, frames, fvals, fwords, y, flags);
+  SNNQP_CHECK_LAUNCH("pack_ev1 (checked)");
   return SNNQP_OK;
 }
 

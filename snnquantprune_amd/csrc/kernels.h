@@ -27,7 +27,8 @@ int run_conv3x3_mfma(const void *x, int in_type, int64_t xs_t, int64_t xs_b,
                      const snnqp_weight_t *w, const int8_t *wt,
                      const snnqp_bn_t *bn, const snnqp_neuron_t *nrn,
                      const float *u0, float *u_out, uint32_t *s_out, int pool,
-                     int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st);
+                     int x_max, int32_t *x_seen, int32_t *x_flags, hipStream_t st,
+                     const int32_t *pred = nullptr);
 
 // per-device state (runtime.hip): the status word kernels report broken invariants into, the
 // probe of the matrix pipe's denormal arithmetic behind DQ_TABLE

@@ -212,6 +212,25 @@ def pack_frames(x: torch.Tensor, fmt: int, flags: Optional[torch.Tensor] = None)
   return PackedFrames(data, H, W, fmt)
 
 
+def pack_frames_checked(x: torch.Tensor) -> Tuple[PackedFrames, torch.Tensor]:
+  """uint8 or float32 frames [..., H, W, 2] on the GPU -> (bit-packed EV1 frames, one int32 device
+  word) in one pass (snnqp_pack_frames_checked): the word is zero iff every value is 0 or 1, i.e.
+  iff the packed frames ARE the tensor -- the speculative half of conv_lif_forward(binary_first=True)."""
+  _require_gpu(x)
+  assert x.dtype in (torch.uint8, torch.float32) and x.shape[-1] == 2 and x.ndim >= 3, (x.dtype, tuple(x.shape))
+  x = x.contiguous()
+  H, W = x.shape[-3], x.shape[-2]
+  lead = tuple(x.shape[:-3])
+  frames = 1
+  for d in lead:
+    frames *= d
+  data = torch.empty(lead + (frame_units(H, W, L.EV1),), dtype=torch.int32, device=x.device)
+  flags = torch.empty(1, dtype=torch.int32, device=x.device)
+  L.check(L.lib().snnqp_pack_frames_checked(_ptr(x), L.U8 if x.dtype == torch.uint8 else L.F32, frames, H, W,
+                                            _ptr(data), _ptr(flags), _stream()))
+  return PackedFrames(data, H, W, L.EV1), flags
+
+
 def unpack_frames(p: PackedFrames) -> torch.Tensor:
   """PackedFrames -> uint8 [..., H, W, 2] (snnqp_unpack_frames)."""
   _require_gpu(p.data)
@@ -517,6 +536,14 @@ class CountHint:
     self._host = torch.zeros(8, dtype=torch.int32).pin_memory()
     self._event = None
     self.max_seen = 0
+    self.saw_counts = False      # a value above 1 has been reported on this device (sticky)
+
+  def binary_so_far(self) -> bool:
+    """Every launch that reported so far met binary frames only: byte / float32 frames are then
+    worth packing to bits in front of the event layer (conv_lif_forward(binary_first=True)).
+    Sticky the other way: one count above 1 -- a hot pixel -- and the frames go in as they are
+    from then on, a failed speculation costs the batch twice."""
+    return self.current() == 1 and not self.saw_counts
 
   @staticmethod
   def capturing() -> bool:
@@ -551,6 +578,8 @@ class CountHint:
       self._event = None
       words = [int(v) for v in self._host]
       self.max_seen = words[0]
+      if self.max_seen > 1:
+        self.saw_counts = True
       if sum(words[1:6]) > 0:
         # (never above what was seen: the tables are sized by abs_sum_max * hint, and a bucket
         # bound of 7 where the data stops at 4 can push 8-bit codes past the table's capacity)
@@ -581,6 +610,17 @@ def count_hint(device) -> CountHint:
   if h is None:
     h = _count_hints[key] = CountHint(device)
   return h
+
+
+def reset_count_hints(device=None):
+  """Forget what the event layer has reported about its input on `device` (all devices: None): the
+  next launch starts from "binary frames, nothing seen" again.  For a caller that switches to
+  another data stream (bench.py between its legs); a model fed by one stream never needs it."""
+  if device is None:
+    _count_hints.clear()
+  else:
+    d = torch.device(device)
+    _count_hints.pop(d.index if d.index is not None else torch.cuda.current_device(), None)
 
 
 def f32_to_u8(x: torch.Tensor) -> torch.Tensor:
@@ -870,13 +910,18 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
                      want_u: bool = True, packed_out: bool = False, pool: int = 1,
                      impl: int = L.IMPL_AUTO, time_major: bool = True, x_max: int = 0,
                      x_seen: Optional[torch.Tensor] = None,
-                     fallback: Optional[FloatFallback] = None):
+                     fallback: Optional[FloatFallback] = None, binary_first: bool = False):
   """x [T, B, H, W, Cin] (or [B, T, ...] with time_major=False) ->
   (u_T [B, OH, OW, Cout] | None, spikes [T, B, OH/pool, OW/pool, Cout]).
   x_max: the largest input value expected (a hint, snnqp.h); x_seen: eight int32 device words
   that receive the largest uint8 input value the launch met and the chunk counts by maximum.
   fallback: float32 input into integer codes (FloatFallback): the integer launch is followed by
-  the predicated float32 one into the same outputs."""
+  the predicated float32 one into the same outputs.
+  binary_first: uint8 / float32 frames of the 2-channel event layer that are EXPECTED to be binary
+  (ops.CountHint.binary_so_far): one checked pass packs them to bits, the event layer runs its
+  bit-packed variant on 1/8 (1/32) of the bytes, and a predicated launch on the frames as they are
+  redoes the block iff a value was not 0 or 1 (snnqp_pack_frames_checked,
+  snnqp_conv_lif_forward_pred) -- same results whatever the frames hold, nothing read back."""
   xt, in_type = _in_desc(x)
   xt = xt.contiguous()
   _require_gpu(xt, weight.w, u0)
@@ -912,12 +957,29 @@ def conv_lif_forward(x, geom: ConvGeom, weight: Weight, neuron: Neuron,
   tag = "conv%dx%d[%dx%dx%d->%d]" % (geom.KH, geom.KW, geom.H, geom.W, geom.Cin, geom.Cout)
   if _PROFILE is not None and in_type == L.BITS and weight.is_int and tag not in PROFILE_NOTES:
     PROFILE_NOTES[tag] = {"dequant": conv_dequant_form(weight, neuron)}
+  speculate = (binary_first and not isinstance(x, (PackedFrames, PackedSpikes)) and in_type in (L.U8, L.F32)
+               and geom.Cin == 2 and weight.is_int and impl != L.IMPL_GENERIC and xt.ndim == 5)
   with _timed(tag):
-    L.check(L.lib().snnqp_conv_lif_forward(
-        _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
-        _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
-        _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
-        int(x_max), _ptr(x_seen), _ptr(x_flags), _stream()))
+    if speculate:
+      pf, not_binary = pack_frames_checked(xt)
+      ps_t, ps_b = _tb_strides(pf.data, T, B, time_major, pf.data.shape[-1])
+      L.check(L.lib().snnqp_conv_lif_forward(
+          _ptr(pf.data), L.EV1, ps_t, ps_b, T, B, ctypes.byref(g), ctypes.byref(w),
+          _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
+          _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
+          1, None, None, _stream()))
+      # ... and the frames as they are, iff a value was not 0 or 1
+      L.check(L.lib().snnqp_conv_lif_forward_pred(
+          _ptr(not_binary), _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
+          _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
+          _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool,
+          int(x_max), _ptr(x_seen), _ptr(x_flags), _stream()))
+    else:
+      L.check(L.lib().snnqp_conv_lif_forward(
+          _ptr(xt), in_type, xs_t, xs_b, T, B, ctypes.byref(g), ctypes.byref(w),
+          _ptr(weight.wt), ctypes.byref(b) if b is not None else None, ctypes.byref(n),
+          _ptr(u0), _ptr(u_out), _ptr(s), L.BITS if packed_out else L.F32, pool, impl,
+          int(x_max), _ptr(x_seen), _ptr(x_flags), _stream()))
   if fallback is not None:
     # the same block on the float32 kernel, executed only if the word says so (snnqp.h)
     xf = _f32c(xt if fallback.x is None else fallback.x)

@@ -440,6 +440,7 @@ class SpikingBlock(nn.Module):
                        % (x.shape,))
     geom = conn.geometry(tuple(x.shape[2:-1]), cin)
     hint = None
+    binary_first = False
     if (integer and cin == 2 and nsp == 2 and
         ((isinstance(x, torch.Tensor) and x.dtype in (torch.uint8, torch.float32)) or
          (isinstance(x, ops.PackedFrames) and x.fmt == L.EV4))):
@@ -447,6 +448,10 @@ class SpikingBlock(nn.Module):
       # what to expect -- no inspection pass, no read-back in front of the launch
       hint = ops.count_hint(x.device)
       x_max = hint.current()
+      # byte / float32 frames that have been binary so far: packed to bits in one checked pass, the
+      # event layer on its bit-packed variant, the frames as they are behind it iff the check fails
+      binary_first = (isinstance(x, torch.Tensor) and self.impl != L.IMPL_GENERIC and hint.binary_so_far()
+                      and self._event_layer_geometry(geom) and w.is_int)
     elif isinstance(x, ops.PackedFrames):
       x_max = 1                          # EV1: binary by construction
     else:
@@ -478,7 +483,7 @@ class SpikingBlock(nn.Module):
         u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                         want_u=self.return_state, packed_out=packed_out,
                                         pool=self.pool, impl=impl, time_major=tm,
-                                        x_max=x_max, x_seen=x_seen, fallback=fb)
+                                        x_max=x_max, x_seen=x_seen, fallback=fb, binary_first=binary_first)
         break
       except L.SnnqpError as e:
         if (e.code == L.EUNSUPPORTED and spec and attempt == 0 and isinstance(x, torch.Tensor)
@@ -488,14 +493,14 @@ class SpikingBlock(nn.Module):
           x, fb = narrowed()
           if nsp == 1:
             x = x.reshape(T, B, 1, geom.W, cin)
-          spec, hint, x_seen, x_max = False, None, None, 0
+          spec, hint, x_seen, x_max, binary_first = False, None, None, 0, False
           continue
         if e.code != L.EUNSUPPORTED or self.pool != 2 or impl == L.IMPL_MFMA:
           raise
         u_out, s = ops.conv_lif_forward(x, geom, w, nrn, bn=bn, u0=u0,
                                         want_u=self.return_state, packed_out=packed_out,
                                         pool=1, impl=impl, time_major=tm, x_max=x_max,
-                                        x_seen=x_seen, fallback=fb)
+                                        x_seen=x_seen, fallback=fb, binary_first=binary_first)
         s = ops.maxpool2x2(s)
         break
     if hint is not None:

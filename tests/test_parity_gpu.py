@@ -3251,6 +3251,141 @@ def test_event_layer_stages_float32_frames(dev, oracle, hw, pool):
   assert ops.device_status() == 0
 
 
+@pytest.mark.parametrize("hw,pool", [(24, 2), (13, 1), (16, 2)], ids=["24_pool", "13_clipped", "16_pool"])
+def test_binary_frames_are_packed_in_front_of_the_event_layer(dev, oracle, hw, pool):
+  """conv_lif_forward(binary_first=True): uint8 / float32 frames that are expected to be binary are
+  packed to bits by one checked pass (snnqp_pack_frames_checked), the event layer runs its
+  bit-packed variant, and a predicated launch on the frames as they are (snnqp_conv_lif_forward_pred)
+  redoes the block iff a value was not 0 or 1.  Whatever the frames hold the result is the oracle's:
+  binary frames (-0.0 included), frames with one count of 3 or a hot pixel (the redo runs, on the
+  integer kernel), float32 frames with a value that is not an integer (the redo flags it and the
+  float32 kernel behind it runs: the `fseq` contract); time- and batch-major; images that clip
+  patches and rows that do not start on a word boundary; with a carried-in state."""
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  from tests.helpers import pack_ev1
+  T, B = 7, 5
+  c = cases.conv_block_case(T=T, B=B, hw=hw, cin=2, seed=961, gain=4.0)
+  qw = qweight_of(oracle, c["leaf"], c["bits"])
+  w = _weight(c["leaf"], c["bits"], dev, transposed=True)
+  fb = ops.FloatFallback(_float_weight(c["leaf"], c["bits"], dev))
+  bn, nrn = _bn(c["bn"], dev), _mslif()
+  g = ops.ConvGeom(hw, hw, 2, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  rng = np.random.Generator(np.random.PCG64(hw + 7))
+  binary = (rng.random((T, B, hw, hw, 2)) < 0.1).astype(np.uint8)
+  binary[:, :, hw - 1, hw - 1, :] = 1
+  one3 = binary.copy(); one3[2, 1, 5, 6, 0] = 3
+  hot = binary.copy(); hot[T - 1, B - 1, hw - 1, hw - 2, 1] = 255
+  u0 = (rng.random((B, hw, hw, 128)) * 0.6).astype(F32)
+  seen = torch.zeros(8, dtype=torch.int32, device=dev)
+
+  def run(xt, carry=None, tm=True, hint=1, f=None):
+    return ops.conv_lif_forward(xt, g, w, nrn, bn=bn, u0=None if carry is None else _t(carry, dev), want_u=True,
+                                packed_out=True, pool=pool, impl=L.IMPL_AUTO, x_max=hint, x_seen=seen,
+                                time_major=tm, fallback=f, binary_first=True)
+  for name, x in (("binary", binary), ("one count of 3", one3), ("hot pixel", hot)):
+    for carry in (None, u0):
+      eu, es = oracle.conv_block(x, qw, c["bn"], None, "int", u0=carry)
+      exp = packbits_lastaxis(oracle.max_pool_2x2(es) if pool == 2 else es)
+      for dt in (np.uint8, F32):
+        xn = x.astype(dt)
+        if dt is F32:
+          xn[0, 0, 0, 0, 0] = -0.0 if x[0, 0, 0, 0, 0] == 0 else xn[0, 0, 0, 0, 0]
+        tag = "%s %s carry %s" % (name, np.dtype(dt).name, carry is not None)
+        seen.zero_()
+        u, s = run(_t(xn, dev), carry, f=fb if dt is F32 else None)
+        np.testing.assert_array_equal(_np(s), exp, err_msg=tag)
+        np.testing.assert_array_equal(_np(u), eu, err_msg=tag)
+        # the redo reports what it met; a launch that was not redone reports nothing
+        assert int(seen[0].item()) == (0 if name == "binary" else int(x.max())), tag
+        ub, sb = run(_t(np.ascontiguousarray(np.swapaxes(xn, 0, 1)), dev), carry, tm=False, f=fb if dt is F32 else None)
+        np.testing.assert_array_equal(_np(sb), exp, err_msg=tag + " batch-major")
+        np.testing.assert_array_equal(_np(ub), eu, err_msg=tag + " batch-major")
+  # the checked pass by itself: the word is zero iff the packed frames are the tensor
+  for x, dt, want in ((binary, np.uint8, 0), (one3, np.uint8, L.FLAG_GT_ONE), (binary, F32, 0),
+                      (one3, F32, L.FLAG_GT_ONE)):
+    pf, word = ops.pack_frames_checked(_t(x.astype(dt), dev))
+    assert int(word.item()) == want
+    if want == 0:
+      np.testing.assert_array_equal(_np(pf.data).view(np.uint32), pack_ev1(x))
+  frac = binary.astype(F32); frac[1, 2, 3, 4, 1] = 0.5
+  assert int(ops.pack_frames_checked(_t(frac, dev))[1].item()) == L.FLAG_GT_ONE | L.FLAG_NOT_INTEGER
+  # float32 frames with a value that is not an integer: pack flags it, the redo's own check flags
+  # it, the float32 kernel behind both runs
+  for bad in (0.5, 256.0, -2.0, float("nan")):
+    xb = binary.astype(F32)
+    xb[T - 1, B - 1, hw - 1, hw - 2, 1] = bad
+    if np.isnan(bad):
+      u, s = run(_t(xb, dev), f=fb)          # (no oracle for a NaN: the launch must not fault or hang)
+      torch.cuda.synchronize()
+      continue
+    fu, fs = oracle.conv_block(xb, qw, c["bn"], None, "fseq")
+    u, s = run(_t(xb, dev), f=fb)
+    np.testing.assert_array_equal(_np(s), packbits_lastaxis(oracle.max_pool_2x2(fs) if pool == 2 else fs), err_msg=str(bad))
+    np.testing.assert_array_equal(_np(u), fu, err_msg=str(bad))
+  assert ops.device_status() == 0
+
+
+def test_speculative_packing_follows_what_the_device_has_seen(dev, oracle):
+  """Through the model, as eval.py feeds it: uint8 / float32 frames take the packed path while every
+  report from the device said "binary" (ops.CountHint.binary_so_far), count frames switch it off for
+  good after their first batch -- whose results are right all the same -- and a captured step with
+  the speculation inside replays to the eager result."""
+  from snnquantprune_amd import linen as nn
+  from snnquantprune_amd import models, ops, synthetic as syn
+  ops._count_hints.clear()
+  c = cases.conv_net_case(T=5, B=4, hw=32, p=0.9, gains=(6.0, 9.0, 11.0, 16.0))
+  e = cases.conv_net_expected(oracle, c)
+  model = models.ConvDenseSNN(num_classes=11, config=syn.make_config(bits=4, prune_percentage=0.9))
+  variables = nn.tree_from_numpy(c["vars"], dev)
+  assert c["x"].max() == 1
+  calls = []
+  orig = ops.pack_frames_checked
+
+  def spy(x):
+    calls.append(tuple(x.shape))
+    return orig(x)
+  ops.pack_frames_checked = spy
+  try:
+    for dt in (torch.uint8, torch.float32):
+      (logits, _), mut = model.apply(variables, _t(c["x"], dev).to(dt), trgt=None, train=False, rng=None,
+                                     mutable=["intermediates"])
+      np.testing.assert_array_equal(_np(logits), e["logits"])
+      np.testing.assert_array_equal(_np(mut["intermediates"]["pool0"][0]), e["pool0_bits"])
+    assert len(calls) == 2 and ops.count_hint(dev).binary_so_far()
+    # a captured step with the speculation inside
+    xs = _t(c["x"], dev)
+    cap = nn.capture(model, variables, xs, trgt=None, train=False, rng=None)
+    n_cap = len(calls)
+    assert n_cap >= 3                                   # warm-up applies and the capture itself packed
+    np.testing.assert_array_equal(_np(cap()[0]), e["logits"])
+    # ... replayed on count frames: the predicated launch inside the graph redoes the block
+    cnt = syn.poisson_counts(c["x"].shape, 0.3, seed=77)
+    assert cnt.max() > 1
+    ec = cases.conv_net_expected(oracle, dict(c, x=cnt))
+    np.testing.assert_array_equal(_np(cap(_t(cnt, dev))[0]), ec["logits"])
+    assert len(calls) == n_cap                          # (a replay calls nothing on the host)
+    del cap
+    # eager count frames: right on the first batch (speculation fails, the redo reports), and once
+    # the report has arrived the frames go in as they are
+    (logits, _) = model.apply(variables, _t(cnt, dev), trgt=None, train=False, rng=None)
+    np.testing.assert_array_equal(_np(logits), ec["logits"])
+    torch.cuda.synchronize()
+    hint = ops.count_hint(dev)
+    hint.current()
+    assert hint.saw_counts and not hint.binary_so_far()
+    n = len(calls)
+    for x in (cnt, c["x"]):                             # binary frames afterwards: still as they are
+      (logits, _) = model.apply(variables, _t(x, dev), trgt=None, train=False, rng=None)
+      torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(logits), e["logits"])
+    assert len(calls) == n
+  finally:
+    ops.pack_frames_checked = orig
+    ops._count_hints.clear()
+  assert ops.device_status() == 0
+
+
 def test_float32_activations_through_the_narrowing_passes(dev, oracle):
   """float32 activations into the blocks that do not stage float32 themselves: a 128-channel conv
   block (spike bits packed by one checked device pass), a narrow dense block (uint8 rows by one
