@@ -45,12 +45,12 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s (x 64 lanes each)
 # HBM bytes per launch measured with rocprofv3 --pmc (separate passes of this same
 # command: tools/pmc_profile.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed
-PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
                                                            "r02_pmc_traffic.json",
                                                            "r01_pmc_traffic.json")]
 # per-kernel PMC counters of the same command (tools/pmc_profile.sh), committed: SQ_INSTS_VALU per
 # launch gives the vector instructions per neuron update of the conv kernels
-PMC_SUMMARY = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
+PMC_SUMMARY = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
                                                            "r02_pmc_summary.json")]
 # int-vs-float deviation of the numeric contract (tools/int_vs_float.py, CPU), committed
 PARITY_VS_FLOAT = next((p for p in (os.path.join(ROOT, "profiles", n) for n in
@@ -1042,11 +1042,12 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
 
   c2_traffic = None
   if args.model == "dense" and T == 20 and args.bits == 8:
-    c2_traffic = {(256, "u8"): "r05_pmc_c2_traffic.json", (4096, "f32"): "r05_pmc_c2_b4096_f32_traffic.json"}.get(
+    c2_traffic = {(256, "u8"): "pmc_c2_traffic.json", (4096, "f32"): "pmc_c2_b4096_f32_traffic.json"}.get(
         (B, args.input))
   if c2_traffic:
-    path = os.path.join(ROOT, "profiles", c2_traffic)
-    if os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", r + "_" + c2_traffic) for r in ("r06", "r05"))
+                 if os.path.exists(q)), "")
+    if path:
       with open(path) as f:
         traffic = json.load(f).get("bytes_per_launch", {})
       traffic_src = "committed %s (rocprofv3 --pmc passes of this command; not measured in this run)" \
