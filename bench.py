@@ -525,6 +525,9 @@ def main(argv=None):
     # no launcher around us: become one (nothing in this process has touched a GPU yet)
     sys.exit(launch_ranks(args, argv))
 
+  # (before torch loads the runtime: RCCL shares buffers between the ranks of a node through dmabuf IPC
+  # handles on this image, see launch_ranks -- ranks started by an external launcher get it too)
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   import numpy as np
   import torch
   from snnquantprune_amd import parallel

@@ -20,7 +20,7 @@ with open(src) as f:
     name = r["Kernel_Name"]
     if "snnqp::" not in name:
       continue
-    short = name.split("(")[0].replace("void ", "")[:100]
+    short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:100]
     key = (short, r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"])
     rows[key].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                       r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"]))
