@@ -66,6 +66,15 @@ def conv_block_random(dev, N, seed, verbose=False):
                                     pool=pool, impl=L.IMPL_MFMA, x_max=1)
       ok = ok and torch.equal(se.bits, sg.bits) and torch.equal(ue, ug)
       tag += " +ev1"
+    if first:
+      # round 6: the frames packed to bits by a checked pass in front of the event layer, the frames
+      # as they are behind it (predicated): the same result whatever they hold, uint8 and float32
+      for xt in (x, x.to(torch.float32)):
+        fb = ops.FloatFallback(pk.float_weight()) if xt.dtype == torch.float32 else None
+        ub, sb = ops.conv_lif_forward(xt, g, w, nrn, bn=bn, u0=u0, packed_out=True, pool=pool,
+                                      impl=L.IMPL_AUTO, x_max=1, fallback=fb, binary_first=True)
+        ok = ok and torch.equal(sb.bits, sg.bits) and torch.equal(ub, ug)
+      tag += " +packed-first"
     if not ok:
       failures.append(tag)
     if verbose:
