@@ -374,15 +374,15 @@ RSQRT_CHOICES = {
 
 
 class _choice:
-  def __init__(self, sigmoid=None, rsqrt=None):
-    self.new = (sigmoid, rsqrt)
+  def __init__(self, sigmoid=None, rsqrt=None, bn_folded=False):
+    self.new = (sigmoid, rsqrt, bn_folded)
 
   def __enter__(self):
-    self.old = (o.SIGMOID, o.RSQRT)
-    o.SIGMOID, o.RSQRT = self.new
+    self.old = (o.SIGMOID, o.RSQRT, o.BN_FOLDED)
+    o.SIGMOID, o.RSQRT, o.BN_FOLDED = self.new
 
   def __exit__(self, *exc):
-    o.SIGMOID, o.RSQRT = self.old
+    o.SIGMOID, o.RSQRT, o.BN_FOLDED = self.old
     return False
 
 
@@ -440,9 +440,13 @@ def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, la
   v = syn.cextnet_variables(frames=frames, hw=hw, prune_p=prune, random_bn=True)
   sig = SIGMOID_CHOICES if sigmoids is None else sigmoids
   rsq = RSQRT_CHOICES if rsqrts is None else rsqrts
-  runs = [("sigmoid", k, f, None) for k, f in sig.items() if f is not None] + \
-         [("rsqrt", k, None, f) for k, f in rsq.items() if f is not None]
-  accs = {(kind, name): _new_acc() for kind, name, _, _ in runs}
+  runs = [("sigmoid", k, f, None, False) for k, f in sig.items() if f is not None] + \
+         [("rsqrt", k, None, f, False) for k, f in rsq.items() if f is not None]
+  if rsqrts is None:
+    # the OTHER operation order of BatchNorm (mean folded into the bias), with either rsqrt
+    runs += [("bn_order", "x*mul+(bias-mean*mul)", None, None, True),
+             ("bn_order", "x*mul+(bias-mean*mul), rsqrt correctly rounded", None, _rsqrt_cr, True)]
+  accs = {(kind, name): _new_acc() for kind, name, _, _, _ in runs}
   rates = {n: [] for n in _CEXT_RASTERS}
   for b0 in range(0, samples, chunk):
     nb = min(chunk, samples - b0)
@@ -450,8 +454,8 @@ def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, la
     base = _cextnet_run(v, x, bits, neuron_cfg)
     for n in _CEXT_RASTERS:
       rates[n].append(float(np.mean(base[n])))
-    for kind, name, fs, fr in runs:
-      with _choice(fs, fr):
+    for kind, name, fs, fr, folded in runs:
+      with _choice(fs, fr, folded):
         other = _cextnet_run(v, x, bits, neuron_cfg)
       _against(base, other, accs[(kind, name)])
   # how many of the 5 x C BatchNorm multipliers each rsqrt evaluation changes, and by how much
@@ -465,7 +469,7 @@ def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, la
                    % (hw, hw, frames, bits, prune * 100, lam,
                       "" if not neuron_cfg else ", neuron %s" % neuron_cfg.get("kind")),
          "samples": samples, "firing_rate": {n: float(np.mean(r)) for n, r in rates.items()},
-         "sigmoid": {}, "rsqrt": {},
+         "sigmoid": {}, "rsqrt": {}, "bn_order": {},
          "bn_multipliers": {name: {"changed": int(np.count_nonzero(m != muls[base_name])), "of": int(m.size),
                                    "max_ulps": _ulp_distance(m / np.sign(m), muls[base_name] / np.sign(muls[base_name]))}
                             for name, m in muls.items() if name != base_name}}
@@ -558,6 +562,9 @@ def summarize_choices(cext, decay, cext_plif=None):
        "sigmoid_argmax_equal": {k: a["argmax_equal"] for k, a in cext["sigmoid"].items()},
        "rsqrt_argmax_equal": {k: a["argmax_equal"] for k, a in cext["rsqrt"].items()},
        "gate_max_ulps": {k: a["gate_max_ulps"] for k, a in cext["sigmoid"].items()},
+       "bn_order": {k: {"flips": {l: d["flips"] for l, d in a["raster_flips"].items()},
+                        "logits_bit_equal": a["logits_bit_equal"], "argmax_equal": a["argmax_equal"]}
+                    for k, a in cext.get("bn_order", {}).items()},
        "bn_multipliers": cext["bn_multipliers"],
        "decay": {kind: {k: {"decays_changed": "%d/%d" % (a["decays_changed"], a["decays"]),
                             "flips": a["flips"], "logits_bit_equal": a["logits_bit_equal"]}

@@ -644,6 +644,10 @@ def heaviside(x):
 # evaluations through these two hooks and counts what they change downstream.
 SIGMOID = None       # None: float64 expit rounded once to float32
 RSQRT = None         # None: fl(1 / fl(sqrt(v))), two float32 roundings
+# ... and a third: the ORDER of BatchNorm's three operations.  flax 0.4.0's _normalize is recalled
+# (the file is not under /root/reference) as y = (x - mean) * mul + bias; later
+# flax versions fold the mean into the bias, y = x * mul + (bias - mean * mul).
+BN_FOLDED = False    # False: fl(fl(fl(x - mean) * mul) + bias)
 
 
 def sigmoid_f32(x):
@@ -705,6 +709,8 @@ def bn_coeffs(mean, var, scale=None, bias=None, eps=1e-5):
 def batchnorm_eval(x, mean, var, scale=None, bias=None, eps=1e-5):
   """y = fl(fl(fl(x - mean) * mul) + bias) over the last axis."""
   mean, mul, b = bn_coeffs(mean, var, scale, bias, eps)
+  if BN_FOLDED:
+    return (np.asarray(x, dtype=F32) * mul + (b - mean * mul).astype(F32)).astype(F32)
   y = (np.asarray(x, dtype=F32) - mean) * mul
   return (y + b).astype(F32)
 

@@ -400,6 +400,16 @@ def test_oracle_free_library_choices_are_bounded(oracle):
     for layer, d in c["rsqrt"][k]["raster_flips"].items():
       assert d["rate"] <= (3e-3 if layer.startswith("dense") else 1e-4), (k, layer, d)
   assert s["gate_max_ulps"]["f32_1_over_1p_exp"]["gate0"] <= 3
+  # BatchNorm's other operation order (the mean folded into the bias): nothing flips either
+  assert len(s["bn_order"]) == 2
+  for k, a in s["bn_order"].items():
+    assert sum(a["flips"].values()) == 0 and a["logits_bit_equal"] == n, (k, a)
+  x = np.linspace(-3, 3, 11).astype(np.float32)[:, None] * np.ones((1, 5), np.float32)
+  bn = dict(mean=v * 0.1, var=v, scale=v * 0.5, bias=-v * 0.2)
+  plain = oracle.batchnorm_eval(x, **bn)
+  with ivf._choice(None, None, True):
+    folded = oracle.batchnorm_eval(x, **bn)
+  assert oracle.BN_FOLDED is False and np.any(plain != folded) and np.allclose(plain, folded, rtol=1e-5, atol=1e-6)
   # decays: the plausible logistics change some decay constants by an ulp and no spike
   for kind in ("parametric_leaky_IF", "LIF"):
     for k, a in s["decay"][kind].items():
