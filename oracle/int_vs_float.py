@@ -374,15 +374,15 @@ RSQRT_CHOICES = {
 
 
 class _choice:
-  def __init__(self, sigmoid=None, rsqrt=None, bn_folded=False):
-    self.new = (sigmoid, rsqrt, bn_folded)
+  def __init__(self, sigmoid=None, rsqrt=None, bn_folded=False, fma=False):
+    self.new = (sigmoid, rsqrt, bn_folded, fma)
 
   def __enter__(self):
-    self.old = (o.SIGMOID, o.RSQRT, o.BN_FOLDED)
-    o.SIGMOID, o.RSQRT, o.BN_FOLDED = self.new
+    self.old = (o.SIGMOID, o.RSQRT, o.BN_FOLDED, o.FMA_CONTRACT)
+    o.SIGMOID, o.RSQRT, o.BN_FOLDED, o.FMA_CONTRACT = self.new
 
   def __exit__(self, *exc):
-    o.SIGMOID, o.RSQRT, o.BN_FOLDED = self.old
+    o.SIGMOID, o.RSQRT, o.BN_FOLDED, o.FMA_CONTRACT = self.old
     return False
 
 
@@ -430,7 +430,7 @@ def _new_acc():
 
 
 def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, lam=0.1, seed=991,
-                    neuron_cfg=None, sigmoids=None, rsqrts=None):
+                    neuron_cfg=None, sigmoids=None, rsqrts=None, with_fma=False):
   """Full CextNet (5 conv blocks + 2 TCJA gates + 2 dense, random BatchNorm statistics), run end to
   end under every alternative evaluation of the logistic (gates; decay when `neuron_cfg` names a
   PLIF / LIF neuron) and of BatchNorm's reciprocal square root, each against the oracle's own
@@ -446,7 +446,16 @@ def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, la
     # the OTHER operation order of BatchNorm (mean folded into the bias), with either rsqrt
     runs += [("bn_order", "x*mul+(bias-mean*mul)", None, None, True),
              ("bn_order", "x*mul+(bias-mean*mul), rsqrt correctly rounded", None, _rsqrt_cr, True)]
-  accs = {(kind, name): _new_acc() for kind, name, _, _, _ in runs}
+    # multiply-add pairs contracted into fused multiply-adds (BatchNorm; the PLIF update when the
+    # neuron is one), alone and on top of the other order / the other rsqrt / jax's logistic
+    runs += [("fma", "contracted", None, None, False, True),
+             ("fma", "contracted, mean folded into the bias", None, None, True, True),
+             ("fma", "contracted, rsqrt correctly rounded, float32 logistic", SIGMOID_CHOICES["f32_1_over_1p_exp"],
+              _rsqrt_cr, False, True)]
+  if rsqrts is not None and with_fma:
+    runs += [("fma", "contracted", None, None, False, True)]
+  runs = [r if len(r) == 6 else r + (False,) for r in runs]
+  accs = {(r[0], r[1]): _new_acc() for r in runs}
   rates = {n: [] for n in _CEXT_RASTERS}
   for b0 in range(0, samples, chunk):
     nb = min(chunk, samples - b0)
@@ -454,8 +463,8 @@ def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, la
     base = _cextnet_run(v, x, bits, neuron_cfg)
     for n in _CEXT_RASTERS:
       rates[n].append(float(np.mean(base[n])))
-    for kind, name, fs, fr, folded in runs:
-      with _choice(fs, fr, folded):
+    for kind, name, fs, fr, folded, fma in runs:
+      with _choice(fs, fr, folded, fma):
         other = _cextnet_run(v, x, bits, neuron_cfg)
       _against(base, other, accs[(kind, name)])
   # how many of the 5 x C BatchNorm multipliers each rsqrt evaluation changes, and by how much
@@ -469,7 +478,7 @@ def cextnet_choices(samples=8, frames=20, hw=128, bits=4, prune=0.9, chunk=2, la
                    % (hw, hw, frames, bits, prune * 100, lam,
                       "" if not neuron_cfg else ", neuron %s" % neuron_cfg.get("kind")),
          "samples": samples, "firing_rate": {n: float(np.mean(r)) for n, r in rates.items()},
-         "sigmoid": {}, "rsqrt": {}, "bn_order": {},
+         "sigmoid": {}, "rsqrt": {}, "bn_order": {}, "fma": {},
          "bn_multipliers": {name: {"changed": int(np.count_nonzero(m != muls[base_name])), "of": int(m.size),
                                    "max_ulps": _ulp_distance(m / np.sign(m), muls[base_name] / np.sign(muls[base_name]))}
                             for name, m in muls.items() if name != base_name}}
@@ -512,9 +521,11 @@ def decay_choices(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, 
     return s1, s2, o.vote(s2)
   for kind, plist in taus.items():
     res = {}
-    for name, f in SIGMOID_CHOICES.items():
+    for name, f in list(SIGMOID_CHOICES.items()) + [("fma_contracted", "fma")]:
       if f is None:
         continue
+      fma = f == "fma"
+      f = None if fma else f
       a = {"decays_changed": 0, "decays": 0, "flips": {"dense1": 0, "dense2": 0},
            "neuron_steps": {"dense1": 0, "dense2": 0}, "logits_bit_equal": 0, "samples": 0}
       for pc in plist:
@@ -523,7 +534,7 @@ def decay_choices(B=256, T=20, K=2048, hidden=512, nout=110, bits=8, prune=0.5, 
                                   (cfgs if pc is None else cfgs[:1])])
         base = run(cfgs)
         k0 = o.sigmoid_f32(tau_all)
-        with _choice(f, None):
+        with _choice(f, None, False, fma):
           other = run(cfgs)
           k1 = o.sigmoid_f32(tau_all)
         a["decays_changed"] += int(np.count_nonzero(k0 != k1)); a["decays"] += int(k0.size)
@@ -565,14 +576,18 @@ def summarize_choices(cext, decay, cext_plif=None):
        "bn_order": {k: {"flips": {l: d["flips"] for l, d in a["raster_flips"].items()},
                         "logits_bit_equal": a["logits_bit_equal"], "argmax_equal": a["argmax_equal"]}
                     for k, a in cext.get("bn_order", {}).items()},
+       "fma": {k: {"flips": {l: d["flips"] for l, d in a["raster_flips"].items()},
+                   "logits_bit_equal": a["logits_bit_equal"], "argmax_equal": a["argmax_equal"]}
+               for k, a in cext.get("fma", {}).items()},
        "bn_multipliers": cext["bn_multipliers"],
        "decay": {kind: {k: {"decays_changed": "%d/%d" % (a["decays_changed"], a["decays"]),
                             "flips": a["flips"], "logits_bit_equal": a["logits_bit_equal"]}
                         for k, a in res.items()} for kind, res in decay["kinds"].items()}}
   if cext_plif is not None:
-    s["cextnet_plif_sigmoid_logits_bit_equal"] = {k: a["logits_bit_equal"] for k, a in cext_plif["sigmoid"].items()}
+    both = dict(cext_plif["sigmoid"], **{"fma: " + k: a for k, a in cext_plif.get("fma", {}).items()})
+    s["cextnet_plif_sigmoid_logits_bit_equal"] = {k: a["logits_bit_equal"] for k, a in both.items()}
     s["cextnet_plif_total_flips"] = {k: int(sum(d["flips"] for d in a["raster_flips"].values()))
-                                     for k, a in cext_plif["sigmoid"].items()}
+                                     for k, a in both.items()}
   return s
 
 
@@ -594,7 +609,7 @@ def main():
     decay = decay_choices()
     plif = cextnet_choices(args.plif_samples, neuron_cfg={"kind": "parametric_leaky_IF",
                                                           "tau_param": np.array([0.3], F32)},
-                           rsqrts={"1_over_sqrt": None}) if args.plif_samples > 0 else None
+                           rsqrts={"1_over_sqrt": None}, with_fma=True) if args.plif_samples > 0 else None
     rep = {"summary": summarize_choices(cext, decay, plif), "cextnet": cext, "decay": decay,
            "cextnet_plif": plif, "seconds": round(time.time() - t0, 1),
            "generated_by": "python -m oracle.int_vs_float --choices --samples %d --plif-samples %d"

@@ -648,6 +648,20 @@ RSQRT = None         # None: fl(1 / fl(sqrt(v))), two float32 roundings
 # (the file is not under /root/reference) as y = (x - mean) * mul + bias; later
 # flax versions fold the mean into the bias, y = x * mul + (bias - mean * mul).
 BN_FOLDED = False    # False: fl(fl(fl(x - mean) * mul) + bias)
+# ... and a fourth: CONTRACTION.  XLA's CPU backend lets LLVM fuse a float32 multiply and the add
+# behind it into one fused multiply-add where the host has the instruction (one rounding instead
+# of two).  Where that can change a value on this path: BatchNorm's `y * mul + bias`, PLIF's
+# `u + d * k` and LIF's `u * k + s_in` (multi_step_LIF with tau = 2 divides by a power of two: the
+# product is exact either way).  The oracle rounds every operation by itself, as the source reads.
+FMA_CONTRACT = False
+
+
+def _fma32(a, b, c):
+  """fl(a * b + c) for float32 arrays: the product of two float32 values is exact in float64, the sum is
+  rounded to float64 and then to float32 (a double rounding that differs from a true fused
+  multiply-add about once in 2^29 operations: good enough to COUNT what contraction changes)."""
+  return (np.asarray(a, F32).astype(np.float64) * np.asarray(b, F32).astype(np.float64)
+          + np.asarray(c, F32).astype(np.float64)).astype(F32)
 
 
 def sigmoid_f32(x):
@@ -675,7 +689,10 @@ def parametric_leaky_if(u, s_in, tau_param, v_threshold=1.0, v_reset=0.0):
   s_in = np.asarray(s_in, dtype=F32)
   k = sigmoid_f32(np.asarray(tau_param).reshape(-1)[0])
   vth, vr = F32(v_threshold), F32(v_reset)
-  u = u + (s_in - (u - vr)) * k            # :381
+  if FMA_CONTRACT:
+    u = _fma32((s_in - (u - vr)).astype(F32), k, u)
+  else:
+    u = u + (s_in - (u - vr)) * k          # :381
   s = heaviside(u - vth)
   u = np.where(s != 0, vr, u)
   return u.astype(F32), s
@@ -687,7 +704,7 @@ def lif(u, s_in, tau_vec, v_threshold=1.0, v_reset=0.0):
   s_in = np.asarray(s_in, dtype=F32)
   k = sigmoid_f32(tau_vec)
   vth, vr = F32(v_threshold), F32(v_reset)
-  u = u * k + s_in                         # :432
+  u = _fma32(u, k, s_in) if FMA_CONTRACT else u * k + s_in      # :432
   s = heaviside(u - vth)
   u = np.where(s > F32(0.5), vr, u)        # :436
   return u.astype(F32), s
@@ -711,6 +728,8 @@ def batchnorm_eval(x, mean, var, scale=None, bias=None, eps=1e-5):
   mean, mul, b = bn_coeffs(mean, var, scale, bias, eps)
   if BN_FOLDED:
     return (np.asarray(x, dtype=F32) * mul + (b - mean * mul).astype(F32)).astype(F32)
+  if FMA_CONTRACT:
+    return _fma32((np.asarray(x, dtype=F32) - mean).astype(F32), mul, b)
   y = (np.asarray(x, dtype=F32) - mean) * mul
   return (y + b).astype(F32)
 

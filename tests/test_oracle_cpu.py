@@ -413,8 +413,25 @@ def test_oracle_free_library_choices_are_bounded(oracle):
   # decays: the plausible logistics change some decay constants by an ulp and no spike
   for kind in ("parametric_leaky_IF", "LIF"):
     for k, a in s["decay"][kind].items():
-      if not k.startswith("all"):
+      if not k.startswith("all") and k != "fma_contracted":
         assert a["flips"] == {"dense1": 0, "dense2": 0}, (kind, k, a)
+  # multiply-add pairs contracted into fused multiply-adds (what XLA's CPU backend lets LLVM do):
+  # BatchNorm's y * mul + bias contracted changes no spike on 16 full-geometry samples, alone or on
+  # top of the other choices; the PLIF update u + d * k contracted flips about one neuron-step in
+  # 2e6 on the C2 head (LIF's u * k + s_in: none)
+  assert len(s["fma"]) == 3
+  for k, a in s["fma"].items():
+    assert sum(a["flips"].values()) == 0 and a["logits_bit_equal"] == n, (k, a)
+  fp, fl = s["decay"]["parametric_leaky_IF"]["fma_contracted"], s["decay"]["LIF"]["fma_contracted"]
+  assert fl["flips"] == {"dense1": 0, "dense2": 0} and fp["decays_changed"].startswith("0/")
+  assert fp["flips"]["dense1"] <= 4 and fp["flips"]["dense2"] <= 16
+  assert int(fp["logits_bit_equal"].split("/")[0]) >= 1020
+  # the hook: one rounding instead of two
+  a32 = np.float32(1.0 + 2.0 ** -12)
+  assert oracle._fma32(a32, a32, np.float32(-1.0)) != np.float32(np.float32(a32 * a32) - np.float32(1.0))
+  with ivf._choice(None, None, False, True):
+    assert oracle.FMA_CONTRACT is True
+  assert oracle.FMA_CONTRACT is False
   assert int(s["decay"]["LIF"]["f32_1_over_1p_exp"]["decays_changed"].split("/")[0]) > 0
 
 
