@@ -45,7 +45,8 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s (x 64 lanes each)
 # HBM bytes per launch measured with rocprofv3 --pmc (separate passes of this same
 # command: tools/pmc_profile.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed
-PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r06_pmc_f32_traffic.json", "r06_pmc_u8_traffic.json",
+                                                           "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
                                                            "r02_pmc_traffic.json",
                                                            "r01_pmc_traffic.json")]
 # per-kernel PMC counters of the same command (tools/pmc_profile.sh), committed: SQ_INSTS_VALU per

@@ -6,6 +6,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc
+rm -rf $OUT          # (rocprofv3 adds files beside those of an earlier call: the summary would mix the runs)
 mkdir -p $OUT
 ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-fed-leg $@"
 run() {  # name, counters...

@@ -53,6 +53,10 @@ BENCH_ARGS="--model dense --batch 4096 --bits 8 --prune 0.5" bash tools/pmc_vari
 # the dense head on float32 rows at B = 4096: HBM bytes by the counters
 PMC_INPUT=f32 bash tools/pmc_profile.sh --model dense --batch 4096 --bits 8 --prune 0.5 --input f32 > $O/pmc_c2_f32_traffic.log 2>&1; cp gpurun_out/pmc/traffic.json $O/pmc_c2_b4096_f32_traffic.json
 PMC_INPUT=f32 bash tools/pmc_profile.sh --input f32 > $O/pmc_f32_traffic.log 2>&1; cp gpurun_out/pmc/traffic.json $O/pmc_f32_traffic.json
+PMC_INPUT=u8 bash tools/pmc_profile.sh --input u8 > $O/pmc_u8_traffic.log 2>&1; cp gpurun_out/pmc/traffic.json $O/pmc_u8_traffic.json
+# (tools/pmc_profile.sh clears gpurun_out/pmc at every call since round 6: the first version of this
+#  script let the later calls' summaries mix with the earlier runs' files -- the committed r06 traffic
+#  files were re-made by tools/r06_pmc_traffic.sh)
 python - $O <<'PY' | tee $O/configs.txt
 import json, glob, os, sys
 for f in sorted(glob.glob(sys.argv[1] + "/bench*.json")):

@@ -12,7 +12,7 @@ names = {"bench.json": "bench.json", "bench_under_rocprof.json": "bench_under_ro
          "kernel_stats.csv": "kernel_stats.csv", "pmc_summary.json": "pmc_summary.json",
          "pmc_traffic.json": "pmc_traffic.json", "pmc_product_summary.json": "pmc_lds_summary.json"}
 names.update({n: n for n in ("kernel_stats_c2.csv", "pmc_c2_summary.json", "pmc_c2_b4096_summary.json", "pmc_c2_traffic.json",
-                             "bench_line.json", "kernel_trace_stats.csv", "pmc_c2_b4096_f32_traffic.json", "pmc_f32_traffic.json")
+                             "bench_line.json", "kernel_trace_stats.csv", "pmc_c2_b4096_f32_traffic.json", "pmc_f32_traffic.json", "pmc_u8_traffic.json")
               if os.path.exists(os.path.join(src, n))})
 for a, b in names.items():
   shutil.copy(os.path.join(src, a), os.path.join("profiles", "%s_%s" % (pre, b)))
