@@ -577,6 +577,67 @@ def test_bench_stdout_line_stays_parseable_by_the_driver():
   assert len(buf.getvalue()) < 6000 and json.loads(buf.getvalue())["value"] == full["value"]
 
 
+def test_profile_tools_split_launches_and_count_the_pack_pass(tmp_path):
+  """tools/kernel_trace_stats.py splits the launches of one device function by their place in a
+  step (conv1 / conv2 share a kernel and a grid), and tools/pmc_summary.py adds the checked pack pass
+  to the event layer's bytes only when it runs once per step (a single launch is the bench's own
+  preparation of a resident bit-packed batch)."""
+  trace = tmp_path / "1_kernel_trace.csv"
+  hdr = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id", "Kernel_Name",
+         "Correlation_Id", "Start_Timestamp", "End_Timestamp", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+         "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z",
+         "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"]
+  rows, t, d = [], 1000, 0
+  for step in range(3):
+    for name, dur in (("void snnqp::conv3x3_u8c2_kernel<1, true>(snnqp::ConvMfmaArgs)", 4800),
+                      ("void snnqp::conv3x3_bits_kernel<0, 128>(snnqp::ConvMfmaArgs)", 5100),
+                      ("void snnqp::conv3x3_bits_kernel<0, 128>(snnqp::ConvMfmaArgs)", 1300),
+                      ("void at::native::something<float>(int)", 7)):
+      d += 1
+      rows.append(["KERNEL_DISPATCH", "Agent 2", 1, 0, 1, d, 1, name, d, t, t + dur + step, 0, 0, 64, 0, 16, 256, 1, 1,
+                   131072, 1, 1])
+      t += dur + 100
+  import csv
+  with open(trace, "w", newline="") as f:
+    w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+    w.writerow(hdr)
+    w.writerows(rows)
+  out = tmp_path / "stats.csv"
+  p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_trace_stats.py"), str(trace), str(out),
+                      "--steps", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+  assert p.returncode == 0, p.stderr.decode()
+  got = {(r["Name"], r["Slot"]): r for r in csv.DictReader(open(out))}
+  assert set(got) == {("snnqp::conv3x3_u8c2_kernel<1, true>", ""), ("snnqp::conv3x3_bits_kernel<0, 128>", "0"),
+                      ("snnqp::conv3x3_bits_kernel<0, 128>", "1")}
+  assert float(got[("snnqp::conv3x3_bits_kernel<0, 128>", "0")]["AverageNs"]) == 5101.0
+  assert float(got[("snnqp::conv3x3_bits_kernel<0, 128>", "1")]["AverageNs"]) == 1301.0
+  assert got[("snnqp::conv3x3_u8c2_kernel<1, true>", "")]["Calls"] == "3"
+  # counters: FETCH_SIZE / WRITE_SIZE in KiB per dispatch, two passes in two directories
+  for setup_only in (True, False):
+    root = tmp_path / ("pmc_%d" % setup_only)
+    disp = []
+    if setup_only:
+      disp.append(("snnqp::pack_ev1_kernel(unsigned char const*)", 1000, 100))          # one launch: preparation
+    for step in range(3):
+      if not setup_only:
+        disp.append(("snnqp::pack_ev1_kernel(unsigned char const*)", 1000, 100))        # once per step
+      disp.append(("void snnqp::conv3x3_u8c2_kernel<1, true>(snnqp::ConvMfmaArgs)", 500, 300))
+    for counter, col in (("FETCH_SIZE", 1), ("WRITE_SIZE", 2)):
+      os.makedirs(root / counter.lower() / "box")
+      with open(root / counter.lower() / "box" / "1_counter_collection.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+        for i, dd in enumerate(disp):
+          w.writerow([i + 1, dd[0], counter, dd[col]])
+    tj = tmp_path / ("traffic_%d.json" % setup_only)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(root), "--steps", "3",
+                        "--traffic", str(tj), "--input-format", "u8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()
+    conv0 = json.load(open(tj))["bytes_per_launch"]["conv3x3[128x128x2->128]"]
+    assert conv0 == (2 * 500 + 300) * 1024 + (0 if setup_only else (2 * 1000 + 100) * 1024)
+
+
 def test_bench_labels_the_unquantised_dense_net_as_c1():
   sys.path.insert(0, ROOT)
   import bench
