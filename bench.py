@@ -854,7 +854,8 @@ def main(argv=None):
                  + (", event counts" if args.counts else ", binary events")
                  + (", fed from host memory" if args.feed == "host" else ""),
         "bn_flags": "random statistics: sub, mul, add" if args.random_bn else
-                    "mean 0 / bias 0 (as initialised): the multiply alone",
+                    "mean 0 / bias 0 / one multiplier for every channel (as initialised): no BatchNorm "
+                    "instruction in conv1 / conv2 (the multiplier is folded into the shared table's entries)",
         "dequant_form": {t: v.get("dequant") for t, v in notes_main.items()}}
   line.update(rooflines_of(args, prof, B, T, lb, notes_main))
   if os.path.exists(PARITY_VS_FLOAT):

@@ -145,9 +145,14 @@ typedef struct {
  * initialised BatchNorm has both).  Equal as numbers: for x = -0.0 the skipped form keeps
  * -0.0 where fl(-0.0 + 0.0) is +0.0.  The sign of a zero current never changes a spike or a
  * non-zero potential; it can show in the sign bit of a membrane potential that is exactly
- * zero (u_out), which compares equal.  0 = nothing known; other bits are refused. */
+ * zero (u_out), which compares equal.  SNNQP_BN_MUL_UNIFORM = every `mul` entry holds the same
+ * bits (a freshly initialised BatchNorm: rsqrt(1 + eps) for every channel): a kernel that reads the
+ * dequantised current from a table all channels share may fold the multiply into the entries --
+ * fl(x * mul) computed once per entry instead of once per neuron update, the same float32
+ * product.  0 = nothing known; other bits are refused. */
 #define SNNQP_BN_MEAN_ZERO 1
 #define SNNQP_BN_BIAS_ZERO 2
+#define SNNQP_BN_MUL_UNIFORM 4
 typedef struct {
   const float *mean;
   const float *mul;
@@ -198,7 +203,7 @@ typedef struct {
  * predicated snnqp_*_if entry points, snnqp_pack_bits_checked, snnqp_conv_gated_forward,
  * snnqp_dense_gated_forward, snnqp_quantize_ex, snnqp_conv_forward_if,
  * snnqp_conv3d_*; 501: snnqp_weight_t.ch_stack_max / ch_slots, the *_gated_*_ex pack calls; 502:
- * snnqp_pack_frames_checked, snnqp_conv_lif_forward_pred).  A binding compares snnqp_version()
+ * snnqp_pack_frames_checked, snnqp_conv_lif_forward_pred, SNNQP_BN_MUL_UNIFORM).  A binding compares snnqp_version()
  * with the SNNQP_VERSION it was written against and refuses a library of another version (_lib.py does). */
 #define SNNQP_VERSION 502
 int snnqp_version(void);

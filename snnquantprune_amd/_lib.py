@@ -37,7 +37,7 @@ class WeightT(Structure):
               ("ch_slots", c_void_p)]
 
 
-BN_MEAN_ZERO, BN_BIAS_ZERO = 1, 2
+BN_MEAN_ZERO, BN_BIAS_ZERO, BN_MUL_UNIFORM = 1, 2, 4
 
 
 class BnT(Structure):

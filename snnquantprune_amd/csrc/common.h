@@ -128,7 +128,7 @@ __device__ __forceinline__ bool neuron_step(float &u, float x, const NeuronP &p,
 
 struct BnP {
   const float *mean, *mul, *bias;
-  int flags;            // SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO (caller-asserted)
+  int flags;            // SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO | SNNQP_BN_MUL_UNIFORM (caller-asserted)
 };
 
 // a BatchNorm descriptor is either absent or complete, and carries no flag bits this build
@@ -139,7 +139,7 @@ struct BnP {
     if (bn) {                                                                           \
       SNNQP_REQUIRE((bn)->mean && (bn)->mul && (bn)->bias, SNNQP_EINVAL,                \
                     "batch-norm descriptor with null arrays");                          \
-      SNNQP_REQUIRE(((bn)->flags & ~(SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO)) == 0,    \
+      SNNQP_REQUIRE(((bn)->flags & ~(SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO | SNNQP_BN_MUL_UNIFORM)) == 0, \
                     SNNQP_EINVAL, "batch-norm descriptor with unknown flag bits 0x%x "  \
                     "(built against another snnqp.h?)", (unsigned)(bn)->flags);         \
     }                                                                                   \
@@ -150,7 +150,7 @@ inline BnP make_bn(const snnqp_bn_t *b) {
   p.mean = b ? b->mean : nullptr;
   p.mul = b ? b->mul : nullptr;
   p.bias = b ? b->bias : nullptr;
-  p.flags = b ? b->flags : (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO);
+  p.flags = b ? b->flags : (SNNQP_BN_MEAN_ZERO | SNNQP_BN_BIAS_ZERO | SNNQP_BN_MUL_UNIFORM);   // (no BatchNorm: mul = 1)
   return p;
 }
 

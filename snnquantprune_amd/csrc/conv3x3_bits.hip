@@ -106,16 +106,20 @@ __device__ __forceinline__ void fp6_pack32(const v4i &lo, const v4i &hi, int (&d
 //   (round 1's table form -- v_cvt + shift + ds_read_b32 on an int32 accumulator -- saved one
 //   instruction per value; this one saves three of the epilogue's 8.6)
 // BNF: every BatchNorm mean and bias of the launch is zero (snnqp_bn_t.flags): x = y * mul
+// BNU: ... and every channel has the same multiplier (SNNQP_BN_MUL_UNIFORM; DQ_TABLE only): the
+//      table entry is fl(current * mul) -- the same float32 product, once per entry instead of once
+//      per neuron update -- and the epilogue has no BatchNorm instruction left
 enum { FMT_FP6 = 0, FMT_I8 = 1 };
 
 constexpr int F6_WR_SLOT = 2;    // slot of a step after which the staged halo is written
 constexpr int F6_BAR_SLOT = 4;   // slot of a step after which the step's barrier sits
 constexpr int F6_PF = 4;         // A fragments in flight (ring of 6); 2 when a step has 9 slots
 
-template <int FMT, int CIN, int NF, bool POOL, int DQ, bool FMA = false, bool BNF = false>
+template <int FMT, int CIN, int NF, bool POOL, int DQ, bool FMA = false, bool BNF = false, bool BNU = false>
 __global__ void __launch_bounds__(F6_NT, 2)
 conv3x3_bits_kernel(ConvMfmaArgs a) {
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel planes");
+  static_assert(!BNU || (BNF && DQ == DQ_TABLE), "the uniform multiplier folds into the shared table");
   static_assert(DQ == DQ_ARITH || DQ == DQ_ONE || DQ == DQ_TABLE, "dequantisation mode");
   constexpr bool I8 = FMT == FMT_I8;
   constexpr bool TABLE = DQ == DQ_TABLE;
@@ -186,10 +190,12 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   const uint32_t dqt_mid = lds0 + (uint32_t)DQT_OFF + 4u * (uint32_t)(TABLE ? a.lut_bound : 0);
   const float chain0 = TABLE ? __uint_as_float(dqt_mid) : 0.0f;
   if (TABLE) {
+    const float mul0 = (BNU && a.bn.mul) ? a.bn.mul[0] : 1.0f;      // BNU: the same for every channel
     for (int i = tid; i <= 2 * a.lut_bound; i += F6_NT) {
       const float af = (float)(i - a.lut_bound);
       const float q = __builtin_fmaf(af, a.dq.rL, af * a.dq.rLlo);   // exact af / L (common.h)
-      ((float *)(lds + DQT_OFF))[i] = q * a.dq.m;
+      const float cur = q * a.dq.m;
+      ((float *)(lds + DQT_OFF))[i] = BNU ? cur * mul0 : cur;
     }
   }
 
@@ -378,7 +384,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
           e.ey[(j + YD) % EYN][1] = dequant1(accC[2 * (j + YD) + 1]);
         }
       } else if (q == 1) {
-        if (BNF) {                   // mean == 0: fl(y - 0) = y
+        if (BNU) {                   // the table entry is fl(y * mul) already
+          e.ex[jg][0] = e.ey[j % EYN][0];
+          e.ex[jg][1] = e.ey[j % EYN][1];
+        } else if (BNF) {            // mean == 0: fl(y - 0) = y
           e.ex[jg][0] = e.ey[j % EYN][0] * lc.bmul;
           e.ex[jg][1] = e.ey[j % EYN][1] * lc.bmul;
         } else {
@@ -581,10 +590,10 @@ conv3x3_bits_kernel(ConvMfmaArgs a) {
   if (pw.queue && tid == 0) pw.finish(processed, a.npatch, a.status);
 }
 
-template <int FMT, int CIN, int NF, int DQ, bool FMA, bool BNF>
+template <int FMT, int CIN, int NF, int DQ, bool FMA, bool BNF, bool BNU = false>
 static void launch_bits_pool(const ConvMfmaArgs &a, bool pool, unsigned gy, hipStream_t st) {
-  if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, DQ, FMA, BNF>, a, gy, st, 0, F6_NT);
-  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, DQ, FMA, BNF>, a, gy, st, 0, F6_NT);
+  if (pool) launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, true, DQ, FMA, BNF, BNU>, a, gy, st, 0, F6_NT);
+  else launch_persistent(conv3x3_bits_kernel<FMT, CIN, NF, false, DQ, FMA, BNF, BNU>, a, gy, st, 0, F6_NT);
 }
 
 // The general instance of a neuron form (three-instruction dequantisation, full BatchNorm,
@@ -600,6 +609,9 @@ static void launch_bits_nf(const ConvMfmaArgs &a, int nf, bool pool, int dq, boo
   if (nf == NF_DECAY) return launch_bits_pool<FMT, CIN, NF_DECAY, DQ_ARITH, false, false>(a, pool, gy, st);
   if constexpr (FMT == FMT_FP6) {
     if (dq == DQ_TABLE) {
+      // (the multiplier every channel shares folded into the table: the headline's form)
+      if (fma && bnf && (a.bn.flags & SNNQP_BN_MUL_UNIFORM))
+        return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, true, true, true>(a, pool, gy, st);
       if (fma && bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, true, true>(a, pool, gy, st);
       if (fma) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, true, false>(a, pool, gy, st);
       if (bnf) return launch_bits_pool<FMT, CIN, NF_MUL0, DQ_TABLE, false, true>(a, pool, gy, st);

@@ -471,6 +471,11 @@ class BatchNorm(Module):
     # a freshly initialised BatchNorm has zero running mean and zero bias: fl(x - 0) and
     # fl(x + 0) are x, and the fused kernels may skip those two instructions
     flags = (0 if m.any() else L.BN_MEAN_ZERO) | (0 if b.any() else L.BN_BIAS_ZERO)
+    # ... and one multiplier for every channel (the same bits): a kernel whose channels share a
+    # dequantisation table folds it into the entries (snnqp.h, SNNQP_BN_MUL_UNIFORM)
+    mul32 = mul.astype(np.float32)
+    if mul32.size and np.all(mul32.view(np.uint32) == mul32.view(np.uint32).flat[0]) and np.isfinite(mul32.flat[0]):
+      flags |= L.BN_MUL_UNIFORM
     out = ops.BnCoeffs(torch.from_numpy(m).to(dev),
                        torch.from_numpy(mul.astype(np.float32)).to(dev),
                        torch.from_numpy(b).to(dev), flags)

@@ -338,7 +338,7 @@ class BnCoeffs:
   mean: torch.Tensor
   mul: torch.Tensor
   bias: torch.Tensor
-  flags: int = 0      # _lib.BN_MEAN_ZERO | _lib.BN_BIAS_ZERO: known from the host-side fold
+  flags: int = 0      # _lib.BN_MEAN_ZERO | BN_BIAS_ZERO | BN_MUL_UNIFORM: known from the host-side fold
 
   def struct(self) -> L.BnT:
     return L.BnT(self.mean.data_ptr(), self.mul.data_ptr(), self.bias.data_ptr(), int(self.flags))

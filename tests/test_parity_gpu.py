@@ -1795,6 +1795,62 @@ def test_conv_bits_kernel_dequantises_through_the_accumulator_addressed_table(de
     np.testing.assert_array_equal(_np(sp), packbits_lastaxis(oracle.max_pool_2x2(es)))
 
 
+@pytest.mark.parametrize("cin", [64, 128])
+def test_conv_bits_kernel_folds_a_uniform_batchnorm_multiplier_into_its_table(dev, oracle, cin):
+  """BatchNorm with zero means and biases and ONE multiplier for every channel (a freshly initialised
+  BatchNorm: rsqrt(1 + eps); here also 0.83 and none at all) on the table form of the bits kernel with
+  the fused membrane update: the entries of the table every channel shares are fl(current * mul)
+  (snnqp.h, SNNQP_BN_MUL_UNIFORM) and the epilogue has no BatchNorm instruction left.  Rasters,
+  pooled rasters and potentials bit-exact against the oracle; the same launch without the flag (the
+  multiply per update) gives the same bits; a carried-in state keeps the fold out (no fused update)
+  and stays exact."""
+  import dataclasses
+  from snnquantprune_amd import _lib as L
+  from snnquantprune_amd import ops
+  c = cases.conv_block_case(T=7, B=3, hw=8, cin=cin, cout=128, bits=4, seed=2301 + cin, gain=5.0)
+  w = _weight(c["leaf"], 4, dev, transposed=True)
+  assert ops.conv_dequant_form(w, _mslif()) == "table"
+  geom = ops.ConvGeom(8, 8, cin, 128, 3, 3, (1, 1), ((1, 1), (1, 1)))
+  xin = ops.pack_bits(_t(c["x"], dev))
+  z, one = np.zeros(128, F32), np.ones(128, F32)
+  u0 = (np.random.Generator(np.random.PCG64(5)).random((3, 8, 8, 128)) * 0.6).astype(F32)
+  for var, scale in ((one, one), (one * F32(1.7), one * F32(1.0823)), (None, None)):
+    if var is None:
+      bnd, bn_plain = None, None
+    else:
+      bnd = dict(mean=z, var=var, scale=scale, bias=z)
+      bn_plain = _bn(bnd, dev)
+      assert len(set(_np(bn_plain.mul).view(np.uint32).tolist())) == 1
+    qw = qweight_of(oracle, c["leaf"], 4)
+    for carry in (None, u0):
+      eu, es = oracle.conv_block(c["x"], qw, bnd, None, "int", u0=carry)
+      assert 0.01 < es.mean() < 0.7
+      outs = []
+      for flags in ((L.BN_MEAN_ZERO | L.BN_BIAS_ZERO | L.BN_MUL_UNIFORM, L.BN_MEAN_ZERO | L.BN_BIAS_ZERO, 0)
+                    if bn_plain is not None else (0,)):
+        bn = None if bn_plain is None else dataclasses.replace(bn_plain, flags=flags)
+        mb = ops.current_min_bits(w, bn, int(w.abs_sum_max), 128)
+        ww = dataclasses.replace(w, min_current_bits=mb)
+        for pool in (1, 2):
+          u, s = ops.conv_lif_forward(xin, geom, ww, _mslif(), bn=bn, u0=None if carry is None else _t(carry, dev),
+                                      packed_out=True, pool=pool, impl=L.IMPL_MFMA, x_max=1)
+          np.testing.assert_array_equal(_np(s), packbits_lastaxis(oracle.max_pool_2x2(es) if pool == 2 else es))
+          np.testing.assert_array_equal(_np(u), eu)
+  # the module computes the flag when it folds the statistics on the host
+  from snnquantprune_amd import linen as nn
+
+  class Probe(nn.Module):
+    def __call__(self, n):
+      return nn.BatchNorm(use_running_average=True, momentum=0.9, epsilon=1e-5).coeffs(n)
+
+  def flags_of(scale):
+    v = {"params": {"BatchNorm_0": {"scale": scale, "bias": z}}, "batch_stats": {"BatchNorm_0": {"mean": z, "var": one}}}
+    return Probe().apply(nn.tree_from_numpy(v, dev), 128).flags
+  assert flags_of(one) == L.BN_MEAN_ZERO | L.BN_BIAS_ZERO | L.BN_MUL_UNIFORM
+  assert flags_of(np.linspace(0.8, 1.2, 128).astype(F32)) == L.BN_MEAN_ZERO | L.BN_BIAS_ZERO
+  assert ops.device_status() == 0
+
+
 def test_conv_bits_kernel_forms_agree_at_the_headline_shape(dev):
   """The dequantisation forms of the bits kernel are bit-equal by construction; at conv1's own
   shape (64 x 64 x 128 -> 128, T = 20, 4-bit / 90 % pruned, B = 32: 4096 patches, every
