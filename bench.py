@@ -124,6 +124,10 @@ def parse(argv=None):
                        "gpurun_out/ when that directory exists.  stdout carries ONE compact line (< 6 KB)")
   ap.add_argument("--full-line", action="store_true",
                   help="print the full record on stdout instead of the compact line (tools/*.sh)")
+  ap.add_argument("--no-live-traffic", action="store_true",
+                  help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE: one step each) that the "
+                       "default headline run uses to MEASURE `roofline.traffic`; the committed profiles/ "
+                       "figure is reported instead, labelled as such")
   ap.add_argument("--allow-diag", action="store_true",
                   help="accept a diagnostic libsnnqp (SNNQP_DIAG_LIB); the line is marked")
   # test plumbing: the same step / fence / all-reduce code on CPU tensors over gloo with a
@@ -857,6 +861,23 @@ def main(argv=None):
                     "mean 0 / bias 0 / one multiplier for every channel (as initialised): no BatchNorm "
                     "instruction in conv1 / conv2 (the multiplier is folded into the shared table's entries)",
         "dequant_form": {t: v.get("dequant") for t, v in notes_main.items()}}
+  # the default headline run measures the HBM bytes of its kernels itself (two counter passes of one
+  # step each in child processes); any failure falls back to the committed figure, labelled
+  default_headline = (world == 1 and args.model == "c3" and args.input == "ev1" and B == 1024 and T == 20
+                      and not args.layer_bits and args.bits == 4 and not args.counts and not args.random_bn
+                      and args.feed == "resident" and not args.no_fed_leg and not args.graph
+                      and not args.no_legs)
+  if default_headline and not args.no_live_traffic and not os.environ.get("SNNQP_BENCH_NO_PMC"):
+    global LIVE_TRAFFIC
+    try:
+      tags, src = live_traffic([])
+    except Exception as e:          # never at the price of the line
+      tags, src = None, "%s: %s" % (type(e).__name__, e)
+    if tags is not None:
+      LIVE_TRAFFIC = (tags, src)
+      args._live_traffic_ok = True
+    else:
+      line["traffic_live"] = "not measured: %s" % src
   line.update(rooflines_of(args, prof, B, T, lb, notes_main))
   if os.path.exists(PARITY_VS_FLOAT):
     with open(PARITY_VS_FLOAT) as f:
@@ -866,10 +887,6 @@ def main(argv=None):
   # the other single-GPU BASELINE configurations, timed in the same run: C2 as
   # BASELINE.json configs[1] names it (B = 256, T = 20, 8-bit, 50 % pruned; uint8 rows) and C5's
   # per-GPU share (B = 512, T = 50, mixed 2/4-bit, 95 % pruned, 10 classes; EV1 frames)
-  default_headline = (world == 1 and args.model == "c3" and args.input == "ev1" and B == 1024 and T == 20
-                      and not args.layer_bits and args.bits == 4 and not args.counts and not args.random_bn
-                      and args.feed == "resident" and not args.no_fed_leg and not args.graph
-                      and not args.no_legs)
   if default_headline:
     del x, frames_u8
     torch.cuda.empty_cache()
@@ -919,6 +936,8 @@ def compact(line):
                                                 "parallelism", "launch"))
   if line.get("roofline"):
     out["roofline"] = pick(line["roofline"], _ROOFLINE_KEYS)
+    src = line["roofline"].get("traffic_source") or ""
+    out["roofline"]["traffic_measured"] = "live" if src.startswith("measured in this run") else "committed file"
   if line.get("roofline_dense"):
     out["roofline_dense"] = pick(line["roofline_dense"], _DENSE_KEYS)
   if line.get("cpu_baseline"):
@@ -978,6 +997,48 @@ def emit(args, line):
   print(text, flush=True)
 
 
+LIVE_TRAFFIC = None      # {tag: HBM bytes per launch} measured by live_traffic() in this run, or None
+
+
+def live_traffic(argv_model, timeout=150.0):
+  """HBM bytes per launch of this run's kernels, MEASURED: two child runs of this script (one step
+  each, no legs, no CPU baseline) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE`
+  -- separate passes, counters only, as MI355X_MICROARCH.md prescribes -- summed per kernel by
+  tools/pmc_summary.py (bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB on gfx950).  Returns
+  ({tag: bytes}, source) or (None, why).  The parent holds its batch in HBM meanwhile and is idle."""
+  import shutil
+  import tempfile
+  prof = shutil.which("rocprofv3")
+  if prof is None:
+    return None, "rocprofv3 not on PATH"
+  t0 = time.time()
+  with tempfile.TemporaryDirectory(prefix="snnqp_pmc_", dir="/tmp") as tmp:
+    env = dict(os.environ, TMPDIR="/tmp")
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+      cmd = [prof, "--kernel-trace", "--pmc", name, "--output-format", "csv", "-d", os.path.join(tmp, name.lower()),
+             "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--no-fed-leg", "--no-legs", "--no-live-traffic", "--detail", os.devnull] + list(argv_model)
+      try:
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                           timeout=max(10.0, timeout - (time.time() - t0)))
+      except (subprocess.TimeoutExpired, OSError) as e:
+        return None, "rocprofv3 pass %s: %s" % (name, type(e).__name__)
+      if p.returncode != 0:
+        return None, "rocprofv3 pass %s exited with %d" % (name, p.returncode)
+    out = os.path.join(tmp, "traffic.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), tmp, "--steps", "3",
+                        "--traffic", out, "--input-format", "live"], stdout=subprocess.DEVNULL,
+                       stderr=subprocess.PIPE, cwd=ROOT)
+    if p.returncode != 0 or not os.path.exists(out):
+      return None, "tools/pmc_summary.py failed"
+    with open(out) as f:
+      tags = json.load(f).get("bytes_per_launch", {})
+  if not tags:
+    return None, "no library kernel in the counter files"
+  return tags, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two child runs of one "
+                "step each (%.0f s), bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB" % (time.time() - t0))
+
+
 def rooflines_of(args, prof, B, T, lb, notes=None):
   """Per-kernel rooflines from the HIP events recorded on the launch stream inside the timed
   region: {roofline (dominant kernel), roofline_dense, rooflines, kernels}."""
@@ -1028,7 +1089,9 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
   }
   traffic, traffic_src, pmc, pmc_src = {}, None, {}, None
   headline = (B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3")
-  if headline:
+  if headline and LIVE_TRAFFIC is not None and getattr(args, "_live_traffic_ok", False):
+    traffic, traffic_src = LIVE_TRAFFIC
+  elif headline:
     for path in PMC_TRAFFIC:
       if os.path.exists(path):
         with open(path) as f:
@@ -1038,6 +1101,7 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
           traffic_src = "committed %s (rocprofv3 --pmc passes of this command; not measured in this run)" \
               % os.path.relpath(path, ROOT)
           break
+  if headline:
     for path in PMC_SUMMARY:
       if os.path.exists(path):
         with open(path) as f:

@@ -553,6 +553,10 @@ def test_bench_stdout_line_stays_parseable_by_the_driver():
             "achieved", "peak", "unit", "frac"):
     assert short["roofline"][k] == full["roofline"][k]
   assert abs(short["roofline"]["frac"] - short["roofline"]["achieved"] / short["roofline"]["peak"]) < 1e-12
+  # where `traffic` comes from is in the line: the committed file (round 5's record) or this run's own counters
+  assert short["roofline"]["traffic_measured"] == "committed file"
+  live = dict(full, roofline=dict(full["roofline"], traffic_source="measured in this run: rocprofv3 ..."))
+  assert bench.compact(live)["roofline"]["traffic_measured"] == "live"
   assert set(short["cpu_baseline"]) == {"value", "unit", "cores", "kind", "cpu", "sample"}
   assert set(short["legs"]) == {"fed", "resident_u8", "captured", "general"} | set(full["legs"])
   for name, leg in short["legs"].items():
