@@ -874,7 +874,7 @@ def main(argv=None):
     except Exception as e:          # never at the price of the line
       tags, src = None, "%s: %s" % (type(e).__name__, e)
     if tags is not None:
-      LIVE_TRAFFIC = (tags, src)
+      LIVE_TRAFFIC = (tags, src, (args.input, bool(args.counts), bool(args.random_bn)))
       args._live_traffic_ok = True
     else:
       line["traffic_live"] = "not measured: %s" % src
@@ -1089,8 +1089,9 @@ def rooflines_of(args, prof, B, T, lb, notes=None):
   }
   traffic, traffic_src, pmc, pmc_src = {}, None, {}, None
   headline = (B == 1024 and T == 20 and not args.layer_bits and args.bits == 4 and args.model == "c3")
-  if headline and LIVE_TRAFFIC is not None and getattr(args, "_live_traffic_ok", False):
-    traffic, traffic_src = LIVE_TRAFFIC
+  if (headline and LIVE_TRAFFIC is not None and getattr(args, "_live_traffic_ok", False)
+      and LIVE_TRAFFIC[2] == (args.input, bool(args.counts), bool(args.random_bn))):
+    traffic, traffic_src = LIVE_TRAFFIC[:2]      # (the legs on other formats keep their committed figures)
   elif headline:
     for path in PMC_TRAFFIC:
       if os.path.exists(path):
